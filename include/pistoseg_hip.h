@@ -1,0 +1,188 @@
+/*
+ * pistoseg_hip.h -- C-ABI of libpistoseg_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * PistoSeg segmentation hot path.
+ *
+ * The reference (Vison307/PistoSeg) has no FFI of its own: every arithmetic step on its hot path is a
+ * stock torch op call site.  Each entry point below replaces one of those call sites;
+ * the citation after "replaces:" is the reference file:line (relative to the reference root).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch types.  All pointers are DEVICE pointers unless a
+ *    parameter says "host".  No ownership transfer, no allocation, no synchronisation inside a call:
+ *    every function enqueues work on `stream` (a hipStream_t passed as void*) and returns.
+ *  - return value: 0 on success, negative ps_status on error; ps_last_error() gives a message
+ *    (thread-local).
+ *  - dtype: PS_F32 = exact-f32 MFMA path (parity), PS_BF16 = bf16 storage / f32 accumulate (throughput).
+ *  - activation layout: channels-last  [N, H, W, C]  with an explicit channel stride `ldc` (elements per
+ *    pixel), so a tensor may be a channel slice of a wider buffer.  Per-channel vectors (BN scale/shift)
+ *    and all loss/optimizer state are f32.  Network inputs/outputs at the API edge are the reference's
+ *    NCHW f32 (conv1a reads NCHW, the upsample writes NCHW).
+ *  - conv weight layouts:  W_fwd[cout][kh][kw][cin]  (== an OIHW tensor in torch.channels_last memory
+ *    format) and  W_dgrad[cin][kh][kw][cout]  (made by ps_weight_transpose).
+ */
+#ifndef PISTOSEG_HIP_H
+#define PISTOSEG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PS_VERSION 100 /* major*10000 + minor*100 + patch */
+
+typedef enum ps_status {
+  PS_OK = 0,
+  PS_ERR_ARG = -1,     /* bad shape / unsupported geometry / misaligned pointer */
+  PS_ERR_LAUNCH = -2,  /* hipLaunchKernel or other HIP runtime failure */
+  PS_ERR_NOGPU = -3    /* no gfx950 device visible */
+} ps_status;
+
+typedef enum ps_dtype { PS_F32 = 0, PS_BF16 = 1 } ps_dtype;
+
+int ps_version(void);
+const char* ps_last_error(void);
+/* Number of visible HIP devices (0 if none); never initialises a context beyond hipGetDeviceCount. */
+int ps_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution (implicit GEMM on MFMA).  replaces: F.conv2d behind every nn.Conv2d of
+ * models/resnet38d.py:16-24,60-71,123-146 and models/revise_net.py:13-19 (k in {1,3}, stride in {1,2},
+ * dilation in {1,2,4}, padding == dilation for 3x3 and 0 for 1x1, bias-free), plus the eval-mode
+ * BatchNorm+ReLU (+Dropout2d) that follows it (resnet38d.py:28-29,39-40,75-90,186) and the residual
+ * add (resnet38d.py:43,93), fused into the epilogue.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ps_conv_geom {
+  int32_t dtype;          /* ps_dtype of activations and weights */
+  int32_t n, h, w;        /* the conv's INPUT activation [n, h, w, cin] (forward sense) */
+  int32_t cin, cout;      /* cin*esize and cout*esize must be multiples of 128 bytes; see ps_conv_supported */
+  int32_t ksize;          /* 1 or 3 */
+  int32_t stride;         /* 1 or 2 */
+  int32_t dilation;       /* >= 1 */
+  int32_t ldc_x;          /* channel stride of the forward input activation (elements) */
+  int32_t ldc_y;          /* channel stride of the forward output activation / its gradient */
+} ps_conv_geom;
+
+/* Epilogue applied to the f32 accumulator `acc` of every produced element (pixel m, channel c):
+ *   v = acc + (add0 ? add0[m,c] : 0)
+ *   if (out_raw) out_raw[m,c] = v
+ *   mode PS_EPI_BNRELU : out[m,c] = max(v*scale[c] + shift[c], 0) * (drop ? drop[n(m),c] : 1)
+ *   mode PS_EPI_RELUBWD: out[m,c] = (mask_src[m,c] > 0 ? v*scale[c]*(drop ? drop[n(m),c] : 1) : 0)
+ *                                   + (add1 ? add1[m,c] : 0)
+ * scale/shift may be NULL (1 / 0).  All activation-typed pointers use the geom's dtype. */
+enum { PS_EPI_NONE = 0, PS_EPI_BNRELU = 1, PS_EPI_RELUBWD = 2 };
+typedef struct ps_epilogue {
+  const void* add0;     int32_t ldc_add0;  int32_t _pad0;
+  void*       out_raw;  int32_t ldc_raw;   int32_t mode;
+  const float* scale;
+  const float* shift;
+  const float* drop;                        /* [n, C] f32 multipliers, or NULL */
+  const void* mask_src; int32_t ldc_mask;  int32_t _pad1;
+  const void* add1;     int32_t ldc_add1;  int32_t _pad2;
+  void*       out;      int32_t ldc_out;   int32_t _pad3;
+} ps_epilogue;
+
+/* 1 if the MFMA implicit-GEMM path handles this geometry, else 0 (message in ps_last_error). */
+int ps_conv_supported(const ps_conv_geom* g);
+
+/* y = conv(x, W_fwd) with epilogue.  x: [n,h,w,cin]; produces [n,ho,wo,cout], ho = (h-1)/stride+1. */
+int ps_conv2d_fwd(const ps_conv_geom* g, const void* x, const void* w_fwd, const ps_epilogue* epi, void* stream);
+
+/* dx = conv_transpose(dy, W) with epilogue.  dy: [n,ho,wo,cout] (ldc_y); produces [n,h,w,cin].
+ * replaces: autograd of F.conv2d w.r.t. its input (Lightning backward / l.backward(),
+ * revise_pseudo_labels.py:300). */
+int ps_conv2d_dgrad(const ps_conv_geom* g, const void* dy, const void* w_dgrad, const ps_epilogue* epi, void* stream);
+
+/* dW_fwd[cout][kh][kw][cin] (f32) += sum over pixels dy[m,cout] * x[m@tap,cin].  ACCUMULATES with f32
+ * atomics (split over pixel ranges): zero dw first.  replaces: autograd of F.conv2d w.r.t. its weight. */
+int ps_conv2d_wgrad(const ps_conv_geom* g, const void* x, const void* dy, float* dw, void* stream);
+
+/* dst[cin][taps][cout] = src[cout][taps][cin]; src/dst dtype in {PS_F32, PS_BF16} (cast allowed f32->bf16). */
+int ps_weight_transpose(int32_t src_dtype, int32_t dst_dtype, const void* src, void* dst, int32_t cout, int32_t taps,
+                        int32_t cin, void* stream);
+/* dst = (bf16)src, n elements.  (per-step refresh of the bf16 forward weights from the f32 master arena) */
+int ps_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
+
+/* conv1a: 3x3, 3 -> 64, stride 1, pad 1, reads the reference's NCHW f32 image, writes channels-last
+ * activation out[m,c] = max(conv*scale[c]+shift[c], 0) (b2.bn_branch2a fused) and/or the raw conv.
+ * replaces: models/resnet38d.py:123,161 (+ :28-29 of the first ResBlock).  w: f32 [64][3][3][3] (OIHW). */
+int ps_conv1a_fwd(int32_t out_dtype, const float* x_nchw, const float* w_oihw, const float* scale, const float* shift,
+                  void* out_act, void* out_raw, int32_t n, int32_t h, int32_t w, void* stream);
+
+/* fc8 head (4096 -> C, C <= 8, 1x1, no bias) on dropout7(conv6).  replaces: models/revise_net.py:50.
+ *   cam[m,c] = sum_k x[m,k] * (drop ? drop[n(m),k] : 1) * w[c,k]      cam: f32 [M, C] (pixel-major)   */
+int ps_fc8_fwd(int32_t dtype, const void* x, int32_t ldc_x, const float* w, const float* drop, float* cam, int32_t m_total,
+               int32_t pix_per_image, int32_t k, int32_t c, void* stream);
+/* backward of ps_fc8_fwd fused with the ReLU(bn7) mask:  dx[m,k] = (x[m,k] > 0) * scale7[k] * drop * sum_c dcam[m,c] w[c,k]
+ * (dx typed like x, written with stride ldc_dx), and dw[c,k] += sum_m dcam[m,c] * x[m,k]*drop (f32 atomics). */
+int ps_fc8_bwd(int32_t dtype, const void* x, int32_t ldc_x, const float* w, const float* drop, const float* scale7,
+               const float* dcam, void* dx, int32_t ldc_dx, float* dw, int32_t m_total, int32_t pix_per_image, int32_t k,
+               int32_t c, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-pixel kernels (HBM-bound)
+ * ---------------------------------------------------------------------------------------------- */
+/* Bilinear resize, F.interpolate(mode='bilinear') semantics.  replaces: models/revise_net.py:64,78-86,93,
+ * revise_pseudo_labels.py:273-274 (align_corners=1) and infer_pseudo_masks.py:89-90 (align_corners=0).
+ * src / dst are strided 4-d views (f32 or bf16 elements): both NCHW and channels-last views are
+ * expressible; arithmetic is f32 with torch's index rules (area_pixel_compute_source_index). */
+typedef struct ps_tensor4 {
+  void* ptr;
+  int32_t dtype;          /* ps_dtype of the elements */
+  int32_t n, c, h, w;
+  int32_t _pad;
+  int64_t sn, sc, sh, sw; /* element strides */
+} ps_tensor4;
+int ps_bilinear_fwd(const ps_tensor4* src, const ps_tensor4* dst, int32_t align_corners, void* stream);
+/* dsrc = d(bilinear)/d(src)^T * ddst, gather form (deterministic, no atomics); dsrc is overwritten. */
+int ps_bilinear_bwd(const ps_tensor4* ddst, const ps_tensor4* dsrc, int32_t align_corners, void* stream);
+
+/* Per-pixel softmax cross-entropy over NCHW f32 logits, int64 targets.
+ * replaces: models/segmentation_module.py:63-66,101-102 -- CrossEntropyLoss(reduction='none', ignore_index)
+ * followed by torch.mean over ALL n*h*w pixels (ignored pixels add 0 but count in the denominator).
+ *   loss_out[0] = (1/(n*h*w)) * sum_pix [t != ignore] (logsumexp(z) - z_t)
+ *   dlogits     = grad_scale/(n*h*w) * (softmax(z) - onehot(t)) for t != ignore, else 0   (if dlogits != NULL)
+ * ignore_index < 0 disables ignoring.  partials: f32 workspace of >= ps_ce_workspace_floats() floats. */
+int64_t ps_ce_workspace_floats(void);
+int ps_softmax_ce(const float* logits, const int64_t* target, float* loss_out, float* dlogits, float grad_scale,
+                  int32_t n, int32_t c, int32_t h, int32_t w, int32_t ignore_index, float* partials, void* stream);
+
+/* CAM/logit -> mask reduction.  replaces: infer_revise_masks.py:137-143 (mode PS_MASK_MUL: argmax over
+ * channels first_ch.. of x*label), infer_pseudo_masks.py:76-85 (mode PS_MASK_FILL: channels with label 0
+ * are filled with -1e10, softmax, entropy = -sum p*log(p+1e-10), argmax of p; single-label tiles get the
+ * constant mask and zero entropy; tissue==0 pixels get index C), loss.py:57-60 (mode PS_MASK_PLAIN:
+ * argmax of softmax(x) / of x).  First maximum wins ties, NaN is treated as maximal (torch.argmax).
+ * x: NCHW f32 [n,c,h,w]; label: f32 [n,c] or NULL; tissue: u8 [n,h,w] or NULL; mask_out: u8 [n,h,w];
+ * entropy_out: f32 [n,h,w] or NULL. */
+enum { PS_MASK_PLAIN = 0, PS_MASK_MUL = 1, PS_MASK_FILL = 2 };
+int ps_argmax_mask(const float* x, const float* label, const uint8_t* tissue, uint8_t* mask_out, float* entropy_out,
+                   int32_t mode, int32_t softmax_first, int32_t first_ch, int32_t n, int32_t c, int32_t h, int32_t w,
+                   void* stream);
+
+/* Confusion matrix accumulate, loss.py:16-26 as called (rows = ground truth, cols = prediction; ground
+ * truth >= num_class dropped).  cm: int64 [num_class*num_class], accumulated with atomics. */
+int ps_confusion_accum(const uint8_t* pred, const int64_t* gt, int64_t* cm, int64_t npix, int32_t num_class, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimisers over a flat f32 arena.  replaces: torch.optim.AdamW (models/segmentation_module.py:86-90)
+ * and utils.PolyOptimizer / torch.optim.SGD (utils.py:166-187).
+ * ---------------------------------------------------------------------------------------------- */
+/* Decoupled-weight-decay Adam, torch.optim.AdamW semantics (eps outside the bias-corrected sqrt):
+ *   p *= 1 - lr*wd;  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;
+ *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * Optionally refreshes a bf16 shadow copy of p (p_bf16 may be NULL). */
+int ps_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int32_t step, void* stream);
+/* torch.optim.SGD with momentum (dampening 0, no nesterov) and L2 weight decay:
+ *   g' = g + wd*p;  buf = first ? g' : mom*buf + g';  p -= lr*buf */
+int ps_sgd_step(float* p, const float* g, float* buf, void* p_bf16, int64_t n, float lr, float momentum,
+                float weight_decay, int32_t first_step, void* stream);
+
+/* Testing hook: 1 (default) stages conv operands with LDS-DMA (global_load_lds), 0 through registers.
+ * Both variants compute identical results; the tests run the parity suite over both. */
+void ps_debug_set_glds(int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PISTOSEG_HIP_H */

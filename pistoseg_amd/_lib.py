@@ -1,0 +1,108 @@
+"""ctypes binding of libpistoseg_hip.so (the C-ABI declared in include/pistoseg_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, the op raises.  Build the library
+with `python -m pistoseg_amd.build` (or `__graft_entry__.build()`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpistoseg_hip.so")
+
+PS_F32, PS_BF16 = 0, 1
+PS_EPI_NONE, PS_EPI_BNRELU, PS_EPI_RELUBWD = 0, 1, 2
+PS_MASK_PLAIN, PS_MASK_MUL, PS_MASK_FILL = 0, 1, 2
+
+
+class PsError(RuntimeError):
+    pass
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+        ("cin", C.c_int32), ("cout", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32),
+        ("dilation", C.c_int32), ("ldc_x", C.c_int32), ("ldc_y", C.c_int32),
+    ]
+
+
+class Epilogue(C.Structure):
+    _fields_ = [
+        ("add0", C.c_void_p), ("ldc_add0", C.c_int32), ("_pad0", C.c_int32),
+        ("out_raw", C.c_void_p), ("ldc_raw", C.c_int32), ("mode", C.c_int32),
+        ("scale", C.c_void_p), ("shift", C.c_void_p), ("drop", C.c_void_p),
+        ("mask_src", C.c_void_p), ("ldc_mask", C.c_int32), ("_pad1", C.c_int32),
+        ("add1", C.c_void_p), ("ldc_add1", C.c_int32), ("_pad2", C.c_int32),
+        ("out", C.c_void_p), ("ldc_out", C.c_int32), ("_pad3", C.c_int32),
+    ]
+
+
+class Tensor4(C.Structure):
+    _fields_ = [
+        ("ptr", C.c_void_p), ("dtype", C.c_int32), ("n", C.c_int32), ("c", C.c_int32), ("h", C.c_int32),
+        ("w", C.c_int32), ("_pad", C.c_int32), ("sn", C.c_int64), ("sc", C.c_int64), ("sh", C.c_int64), ("sw", C.c_int64),
+    ]
+
+
+_P = C.c_void_p
+_I = C.c_int32
+_L = C.c_int64
+_F = C.c_float
+
+# name -> (restype, argtypes); every symbol include/pistoseg_hip.h declares
+PROTOTYPES = {
+    "ps_version": (C.c_int, []),
+    "ps_last_error": (C.c_char_p, []),
+    "ps_device_count": (C.c_int, []),
+    "ps_conv_supported": (C.c_int, [C.POINTER(ConvGeom)]),
+    "ps_conv2d_fwd": (C.c_int, [C.POINTER(ConvGeom), _P, _P, C.POINTER(Epilogue), _P]),
+    "ps_conv2d_dgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _P, C.POINTER(Epilogue), _P]),
+    "ps_conv2d_wgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _P, _P, _P]),
+    "ps_weight_transpose": (C.c_int, [_I, _I, _P, _P, _I, _I, _I, _P]),
+    "ps_cast_f32_bf16": (C.c_int, [_P, _P, _L, _P]),
+    "ps_conv1a_fwd": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "ps_fc8_fwd": (C.c_int, [_I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ps_fc8_bwd": (C.c_int, [_I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "ps_bilinear_fwd": (C.c_int, [C.POINTER(Tensor4), C.POINTER(Tensor4), _I, _P]),
+    "ps_bilinear_bwd": (C.c_int, [C.POINTER(Tensor4), C.POINTER(Tensor4), _I, _P]),
+    "ps_ce_workspace_floats": (C.c_int64, []),
+    "ps_softmax_ce": (C.c_int, [_P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P, _P]),
+    "ps_argmax_mask": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "ps_confusion_accum": (C.c_int, [_P, _P, _P, _L, _I, _P]),
+    "ps_adamw_step": (C.c_int, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
+    "ps_sgd_step": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _I, _P]),
+    "ps_debug_set_glds": (None, [C.c_int]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the library (once) and bind every declared symbol; raises PsError if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PsError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m pistoseg_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise PsError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().ps_last_error().decode(errors="replace")
+        raise PsError(f"{what} failed (rc={rc}): {msg}")

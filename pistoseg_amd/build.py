@@ -1,0 +1,70 @@
+"""Builds libpistoseg_hip.so (gfx950) in-tree with hipcc.  No torch extension machinery: the library is a
+plain C-ABI shared object loaded with ctypes (pistoseg_amd/_lib.py)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libpistoseg_hip.so")
+SOURCES = ["api.cpp", "conv_igemm.hip", "conv_wgrad.hip", "small_ops.hip", "pixel_ops.hip", "rfm_ops.hip"]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm >= 7.0 for gfx950)")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, "ps_internal.h"), os.path.join(HERE, "..", "include", "pistoseg_hip.h")]
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    jobs = []
+    for s in srcs:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
+        if force or _stale(obj, [src] + headers):
+            cmd = [hipcc, *FLAGS, "-x", "hip", "-c", src, "-o", obj]
+            jobs.append((s, cmd))
+
+    def run(job):
+        name, cmd = job
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return name, r
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            for name, r in ex.map(run, jobs):
+                if verbose and (r.stderr.strip() or r.returncode):
+                    sys.stderr.write(f"[build] {name}:\n{r.stderr}\n")
+                if r.returncode:
+                    raise RuntimeError(f"hipcc failed on {name}")
+    objs = [os.path.join(objdir, os.path.splitext(s)[0] + ".o") for s in srcs]
+    if force or jobs or _stale(LIB, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            sys.stderr.write(r.stderr)
+            raise RuntimeError("link failed")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

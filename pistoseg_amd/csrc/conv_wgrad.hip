@@ -1,0 +1,263 @@
+// Weight gradient of the 1x1 / 3x3 convolutions on gfx950 MFMA.
+//
+//   dW[cout][tap][cin] += sum_{pixel m} dY[m][cout] * X[m@tap][cin]
+//
+// GEMM view per tap: rows = cout, cols = cin, K = produced pixels.  Both operands are channels-last, i.e.
+// K is the SLOW index of both tiles: pixel rows (contiguous channels) are staged HBM -> LDS with 16-byte
+// LDS-DMA exactly as they lie in memory, and the K-major MFMA fragments are produced by the gfx950
+// transposed LDS read `ds_read_b64_tr_b16` (bf16) or by one ds_read_b32 per k (exact-f32 MFMA 16x16x4).
+// The chunk index of every LDS row is XOR-swizzled (on the DMA source address) so the transposed reads of
+// a 32-lane half hit 8 distinct 32-byte bank slices.
+// Block = 4 waves (2x2), tile BCO x BCI in {64,128}^2, one tap and one pixel range (split-K) per block;
+// partial sums are added to the f32 gradient with global_atomic_add_f32 (64-byte row segments).
+#include "ps_internal.h"
+
+namespace {
+
+__device__ __attribute__((aligned(256))) unsigned char g_zero_row[512];
+
+struct FastDiv {
+  uint32_t magic, shift, d;
+};
+static FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  uint32_t l = 0;
+  while ((1u << l) < d) ++l;
+  f.shift = 31 + l;
+  f.magic = static_cast<uint32_t>(((1ull << f.shift) + d - 1) / d);  // exact for dividends < 2^31
+  return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+  return static_cast<uint32_t>((static_cast<unsigned long long>(n) * f.magic) >> f.shift);
+}
+
+struct WgradArgs {
+  const unsigned char* x;   // forward input  [n,h,w,cin]
+  const unsigned char* dy;  // output gradient [n,ho,wo,cout]
+  float* dw;                // [cout][taps][cin]
+  int H, W, Ho, Wo, M;      // M = n*ho*wo
+  int stride, dil, taps, ctr;
+  int cin, cout;
+  long long x_pix_bytes, dy_pix_bytes;
+  int tiles_co, tiles_ci, splits, ksteps;  // ksteps = ceil(M / KP)
+  FastDiv div_hw, div_w;
+};
+
+struct WTraitsBF16 {
+  static constexpr int ES = 2, KP = 64;
+};
+struct WTraitsF32 {
+  static constexpr int ES = 4, KP = 32;
+};
+
+// XOR applied to the 16-byte chunk index of LDS row R (row = RB bytes); see file header.
+template <int ES, int RB>
+__device__ __forceinline__ int row_swz(int R) {
+  if constexpr (ES == 4) return (R & 1) << 2;
+  else if constexpr (RB == 256) return ((R & 3) << 1) | (((R >> 3) & 1) << 3);
+  else return (((R >> 1) & 1) << 1) | (((R >> 3) & 1) << 2);
+}
+
+#define GLDS16(gptr, lptr)                                                                              \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),               \
+                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+template <typename Tr, int BCO, int BCI>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+  constexpr int ES = Tr::ES, KP = Tr::KP;
+  constexpr int RBG = BCO * ES, RBX = BCI * ES;           // LDS row bytes of the dY / X tiles
+  constexpr int G_BYTES = KP * RBG, X_BYTES = KP * RBX, STAGE = G_BYTES + X_BYTES;
+  constexpr int NIG = BCO / 32, NIX = BCI / 32;           // LDS-DMA instructions per wave per stage
+  constexpr int RPG = 1024 / RBG, RPX = 1024 / RBX;       // rows covered by one wave instruction
+  constexpr int MI = BCO / 32, NI = BCI / 32;             // 16x16 fragments per wave (2x2 waves)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // block -> (co tile, ci tile, tap, split)
+  int bid = blockIdx.x;
+  const int split = bid % a.splits; bid /= a.splits;
+  const int tci = bid % a.tiles_ci; bid /= a.tiles_ci;
+  const int tco = bid % a.tiles_co; bid /= a.tiles_co;
+  const int tap = bid;
+  const int co0 = tco * BCO, ci0 = tci * BCI;
+  const int ty = a.taps == 1 ? a.ctr : tap / 3, tx = a.taps == 1 ? a.ctr : tap - (tap / 3) * 3;
+  const int dy_off = (ty - a.ctr) * a.dil, dx_off = (tx - a.ctr) * a.dil;
+  const int per = (a.ksteps + a.splits - 1) / a.splits;
+  const int ks0 = split * per, ks1 = min(a.ksteps, ks0 + per);
+  if (ks0 >= ks1) return;
+
+  const int wr = wave >> 1, wc = wave & 1;
+
+  // staging lanes
+  const int g_rowin = lane / (RBG / 16), g_pos = lane % (RBG / 16);
+  const int x_rowin = lane / (RBX / 16), x_pos = lane % (RBX / 16);
+
+  auto stage = [&](int buf, int ks) {
+    const int mbase = ks * KP;
+    unsigned char* sg = smem + buf * STAGE;
+    unsigned char* sx = sg + G_BYTES;
+#pragma unroll
+    for (int j = 0; j < NIG; ++j) {
+      const int R = (wave * NIG + j) * RPG + g_rowin;
+      const int m = mbase + R;
+      const int chunk = g_pos ^ row_swz<ES, RBG>(R);
+      const unsigned char* src = (m < a.M) ? a.dy + (long long)m * a.dy_pix_bytes + (long long)co0 * ES + chunk * 16
+                                           : g_zero_row + (chunk & 15) * 16;
+      GLDS16(src, sg + (wave * NIG + j) * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < NIX; ++j) {
+      const int R = (wave * NIX + j) * RPX + x_rowin;
+      const int m = mbase + R;
+      const int chunk = x_pos ^ row_swz<ES, RBX>(R);
+      const unsigned char* src = g_zero_row + (chunk & 15) * 16;
+      if (m < a.M) {
+        const uint32_t n = fdiv(m, a.div_hw);
+        const uint32_t rem = m - n * a.div_hw.d;
+        const uint32_t p = fdiv(rem, a.div_w);
+        const uint32_t q = rem - p * a.div_w.d;
+        const int y = (int)p * a.stride + dy_off, xx = (int)q * a.stride + dx_off;
+        if (y >= 0 && y < a.H && xx >= 0 && xx < a.W)
+          src = a.x + ((long long)(n * a.H + y) * a.W + xx) * a.x_pix_bytes + (long long)ci0 * ES + chunk * 16;
+      }
+      GLDS16(src, sx + (wave * NIX + j) * 1024);
+    }
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int g = lane >> 4, l16 = lane & 15;
+  stage(0, ks0);
+  __syncthreads();
+  for (int ks = ks0; ks < ks1; ++ks) {
+    const int cur = (ks - ks0) & 1;
+    if (ks + 1 < ks1) stage(cur ^ 1, ks + 1);
+    const unsigned char* sg = smem + cur * STAGE;
+    const unsigned char* sx = sg + G_BYTES;
+    if constexpr (ES == 2) {
+      // bf16: K = 32 pixels per MFMA; lane group g owns k = 8g..8g+7, fetched by two transposed reads
+      const int q4 = l16 >> 2, p4 = l16 & 3;
+#pragma unroll
+      for (int kk = 0; kk < KP / 32; ++kk) {
+        bf16x8 af[MI], bf[NI];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int R = kk * 32 + 8 * g + 4 * h + q4;
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            const int c0 = wr * (BCO / 2) + i * 16;  // channel base inside the tile
+            const int chunk = (c0 >> 3) + (p4 >> 1);
+            const unsigned char* ad = sg + R * RBG + ((chunk ^ row_swz<ES, RBG>(R)) << 4) + (p4 & 1) * 8;
+            const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ad));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) af[i][4 * h + e] = t[e];
+          }
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            const int c0 = wc * (BCI / 2) + j * 16;
+            const int chunk = (c0 >> 3) + (p4 >> 1);
+            const unsigned char* ad = sx + R * RBX + ((chunk ^ row_swz<ES, RBX>(R)) << 4) + (p4 & 1) * 8;
+            const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ad));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bf[j][4 * h + e] = t[e];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      // exact f32: K = 4 pixels per MFMA; lane group g owns pixel row 4*kk + g
+#pragma unroll
+      for (int kk = 0; kk < KP / 4; ++kk) {
+        const int R = kk * 4 + g;
+        float af[MI], bf[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int c = wr * (BCO / 2) + i * 16 + l16;
+          af[i] = *reinterpret_cast<const float*>(sg + R * RBG + (((c >> 2) ^ row_swz<ES, RBG>(R)) << 4) + (c & 3) * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int c = wc * (BCI / 2) + j * 16 + l16;
+          bf[j] = *reinterpret_cast<const float*>(sx + R * RBX + (((c >> 2) ^ row_swz<ES, RBX>(R)) << 4) + (c & 3) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // D[row = cout: 4g + r][col = cin: l16]
+  const long long wrow = (long long)a.taps * a.cin;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + wr * (BCO / 2) + i * 16 + 4 * g + r;
+        const int ci = ci0 + wc * (BCI / 2) + j * 16 + l16;
+        atomicAdd(a.dw + co * wrow + (long long)tap * a.cin + ci, acc[i][j][r]);
+      }
+}
+
+template <typename Tr, int BCO, int BCI>
+int launch_wgrad(WgradArgs a, hipStream_t s) {
+  a.tiles_co = a.cout / BCO;
+  a.tiles_ci = a.cin / BCI;
+  a.ksteps = (a.M + Tr::KP - 1) / Tr::KP;
+  const long long tiles = (long long)a.tiles_co * a.tiles_ci * a.taps;
+  long long splits = (1536 + tiles - 1) / tiles;           // aim for >= ~1.5k blocks (256 CUs x 2-3 resident)
+  const long long max_splits = (a.ksteps + 7) / 8;          // at least 8 K-steps per block
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  a.splits = (int)splits;
+  const size_t lds = 2 * (size_t)Tr::KP * (BCO + BCI) * Tr::ES;
+  hipLaunchKernelGGL((conv_wgrad_kernel<Tr, BCO, BCI>), dim3((unsigned)(tiles * splits)), dim3(256), lds, s, a);
+  PS_CHECK_LAUNCH("conv_wgrad");
+  return PS_OK;
+}
+
+template <typename Tr>
+int dispatch_wgrad(const WgradArgs& a, hipStream_t s) {
+  const bool co128 = a.cout % 128 == 0, ci128 = a.cin % 128 == 0;
+  if (co128 && ci128) return launch_wgrad<Tr, 128, 128>(a, s);
+  if (co128) return launch_wgrad<Tr, 128, 64>(a, s);
+  if (ci128) return launch_wgrad<Tr, 64, 128>(a, s);
+  return launch_wgrad<Tr, 64, 64>(a, s);
+}
+
+}  // namespace
+
+extern "C" int ps_conv2d_wgrad(const ps_conv_geom* g, const void* x, const void* dy, float* dw, void* stream) {
+  PS_REQUIRE(g && x && dy && dw, "conv2d_wgrad: null argument");
+  PS_REQUIRE(ps_conv_supported(g), "conv2d_wgrad: unsupported geometry (%s)", ps_last_error());
+  PS_REQUIRE(ps_aligned16(x) && ps_aligned16(dy) && ps_aligned16(dw), "conv2d_wgrad: misaligned pointer");
+  const int es = ps_esize(g->dtype);
+  WgradArgs a{};
+  a.x = static_cast<const unsigned char*>(x);
+  a.dy = static_cast<const unsigned char*>(dy);
+  a.dw = dw;
+  a.H = g->h; a.W = g->w;
+  a.Ho = (g->h - 1) / g->stride + 1; a.Wo = (g->w - 1) / g->stride + 1;
+  a.M = g->n * a.Ho * a.Wo;
+  a.stride = g->stride; a.dil = g->dilation;
+  a.taps = g->ksize * g->ksize; a.ctr = g->ksize / 2;
+  a.cin = g->cin; a.cout = g->cout;
+  a.x_pix_bytes = (long long)g->ldc_x * es;
+  a.dy_pix_bytes = (long long)g->ldc_y * es;
+  a.div_hw = make_fastdiv((uint32_t)(a.Ho * a.Wo));
+  a.div_w = make_fastdiv((uint32_t)a.Wo);
+  return g->dtype == PS_BF16 ? dispatch_wgrad<WTraitsBF16>(a, static_cast<hipStream_t>(stream))
+                             : dispatch_wgrad<WTraitsF32>(a, static_cast<hipStream_t>(stream));
+}

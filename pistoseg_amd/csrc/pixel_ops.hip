@@ -1,0 +1,319 @@
+// Per-pixel, HBM-bound kernels: bilinear resize (fwd + gather-form bwd), softmax cross-entropy (fwd+bwd fused),
+// CAM/logit -> mask reductions and the confusion matrix.  One lane per pixel, channel loops in registers,
+// wavefront (64-lane) shuffles for the reductions.
+#include <math.h>
+
+#include "ps_internal.h"
+
+namespace {
+
+struct T4 {
+  unsigned char* ptr;
+  int dtype, n, c, h, w;
+  long long sn, sc, sh, sw;
+};
+static T4 to_t4(const ps_tensor4* t) {
+  T4 r;
+  r.ptr = static_cast<unsigned char*>(t->ptr);
+  r.dtype = t->dtype; r.n = t->n; r.c = t->c; r.h = t->h; r.w = t->w;
+  r.sn = t->sn; r.sc = t->sc; r.sh = t->sh; r.sw = t->sw;
+  return r;
+}
+__device__ __forceinline__ float t4_load(const T4& t, long long off) {
+  if (t.dtype == PS_BF16) return ps_bf16_to_f32(reinterpret_cast<const uint16_t*>(t.ptr)[off]);
+  return reinterpret_cast<const float*>(t.ptr)[off];
+}
+__device__ __forceinline__ void t4_store(const T4& t, long long off, float v) {
+  if (t.dtype == PS_BF16) reinterpret_cast<uint16_t*>(t.ptr)[off] = ps_f32_to_bf16(v);
+  else reinterpret_cast<float*>(t.ptr)[off] = v;
+}
+
+// torch's area_pixel_compute_scale / _source_index (aten/src/ATen/native/UpSample.h), f32 arithmetic.
+__host__ __device__ inline float interp_scale(int in, int out, bool align) {
+  if (align) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  return (float)in / (float)out;
+}
+__device__ __forceinline__ void interp_index(float scale, int dst, int in, bool align, int& i0, int& i1, float& l0, float& l1) {
+  float src;
+  if (align) src = scale * (float)dst;
+  else {
+    src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+  }
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T4 src, const T4 dst, int align, float sy, float sx) {
+  const long long total = (long long)dst.n * dst.h * dst.w;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ox = (int)(i % dst.w);
+    const long long t = i / dst.w;
+    const int oy = (int)(t % dst.h), n = (int)(t / dst.h);
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    interp_index(sy, oy, src.h, align, y0, y1, ly0, ly1);
+    interp_index(sx, ox, src.w, align, x0, x1, lx0, lx1);
+    const long long b = (long long)n * src.sn;
+    const long long o = (long long)n * dst.sn + (long long)oy * dst.sh + (long long)ox * dst.sw;
+    for (int c = 0; c < dst.c; ++c) {
+      const long long bc = b + (long long)c * src.sc;
+      const float v00 = t4_load(src, bc + y0 * src.sh + x0 * src.sw), v01 = t4_load(src, bc + y0 * src.sh + x1 * src.sw);
+      const float v10 = t4_load(src, bc + y1 * src.sh + x0 * src.sw), v11 = t4_load(src, bc + y1 * src.sh + x1 * src.sw);
+      t4_store(dst, o + (long long)c * dst.sc, ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11));
+    }
+  }
+}
+
+// Gather-form backward: one wave per source pixel (n, iy, ix); lanes sweep the window of destination
+// pixels whose interpolation footprint touches it, then a wave reduction per channel.  Deterministic.
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T4 dd, const T4 ds, int align, float sy, float sx, int wy, int wx) {
+  const int lane = threadIdx.x & 63;
+  const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long total = (long long)ds.n * ds.h * ds.w;
+  if (wave_id >= total) return;
+  const int ix = (int)(wave_id % ds.w);
+  const long long t = wave_id / ds.w;
+  const int iy = (int)(t % ds.h), n = (int)(t / ds.h);
+  // candidate destination window: every oy with i0 in {iy-1, iy}
+  int oy_lo, ox_lo;
+  {
+    const float inv_y = sy > 0.f ? 1.f / sy : 0.f, inv_x = sx > 0.f ? 1.f / sx : 0.f;
+    // smallest dst whose source coordinate reaches iy-1 (align: src = s*dst; else src = s*(dst+.5)-.5)
+    const float hb = align ? 0.f : 0.5f;
+    oy_lo = sy > 0.f ? max(0, (int)floorf(((float)iy - 1.f + hb) * inv_y - hb) - 1) : 0;
+    ox_lo = sx > 0.f ? max(0, (int)floorf(((float)ix - 1.f + hb) * inv_x - hb) - 1) : 0;
+  }
+  constexpr int MAXC = 8;
+  for (int c0 = 0; c0 < ds.c; c0 += MAXC) {
+    float acc[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) acc[c] = 0.f;
+    for (int k = lane; k < wy * wx; k += 64) {
+      const int oy = oy_lo + k / wx, ox = ox_lo + k % wx;
+      if (oy >= dd.h || ox >= dd.w) continue;
+      int y0, y1, x0, x1;
+      float ly0, ly1, lx0, lx1;
+      interp_index(sy, oy, ds.h, align, y0, y1, ly0, ly1);
+      interp_index(sx, ox, ds.w, align, x0, x1, lx0, lx1);
+      const float wyv = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+      const float wxv = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+      const float wgt = wyv * wxv;
+      if (wgt == 0.f) continue;
+      const long long o = (long long)n * dd.sn + (long long)oy * dd.sh + (long long)ox * dd.sw;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c)
+        if (c0 + c < ds.c) acc[c] = fmaf(wgt, t4_load(dd, o + (long long)(c0 + c) * dd.sc), acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      if (c0 + c < ds.c) {
+        const float s = ps_wave_sum(acc[c]);
+        if (lane == 0) t4_store(ds, (long long)n * ds.sn + (long long)(c0 + c) * ds.sc + (long long)iy * ds.sh + (long long)ix * ds.sw, s);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// softmax cross-entropy, mean over ALL pixels
+// ------------------------------------------------------------------------------------------------
+constexpr int CE_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ z, const long long* __restrict__ tgt, float* __restrict__ dz,
+                                                 float* __restrict__ partials, float gscale, int n, int c, long long hw, int ignore) {
+  __shared__ float red[4];
+  const long long total = (long long)n * hw;
+  float local = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long img = i / hw, pix = i - img * hw;
+    const float* zp = z + img * c * hw + pix;
+    const long long t = tgt[i];
+    float mx = -INFINITY;
+    for (int k = 0; k < c; ++k) mx = fmaxf(mx, zp[k * hw]);
+    float se = 0.f;
+    for (int k = 0; k < c; ++k) se += expf(zp[k * hw] - mx);
+    const float lse = mx + logf(se);
+    const bool live = (t != ignore) && t >= 0 && t < c;
+    if (live) local += lse - zp[t * hw];
+    if (dz) {
+      float* dp = dz + img * c * hw + pix;
+      for (int k = 0; k < c; ++k) {
+        float g = 0.f;
+        if (live) g = (expf(zp[k * hw] - lse) - (k == t ? 1.f : 0.f)) * gscale;
+        dp[k * hw] = g;
+      }
+    }
+  }
+  local = ps_wave_sum(local);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void ce_finish_kernel(const float* __restrict__ partials, int nparts, float inv_total, float* __restrict__ out) {
+  __shared__ float red[4];
+  float v = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) v += partials[i];
+  v = ps_wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = ((red[0] + red[1]) + (red[2] + red[3])) * inv_total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CAM / logit -> mask
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool better(float v, float best) { return v > best || (v != v && best == best); }
+
+__global__ __launch_bounds__(256) void argmax_mask_kernel(const float* __restrict__ x, const float* __restrict__ label,
+                                                          const uint8_t* __restrict__ tissue, uint8_t* __restrict__ mask,
+                                                          float* __restrict__ entropy, int mode, int softmax_first, int first_ch, int n,
+                                                          int c, long long hw) {
+  const long long total = (long long)n * hw;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long img = i / hw, pix = i - img * hw;
+    const float* xp = x + img * c * hw + pix;
+    const float* lb = label ? label + img * c : nullptr;
+    int best_i = 0;
+    float ent = 0.f;
+    if (mode == PS_MASK_FILL) {
+      float lsum = 0.f;
+      for (int k = 0; k < c; ++k) lsum += lb[k];
+      if (lsum == 1.f) {  // single tissue type: constant mask (patch_label.index(1)), zero entropy
+        int first1 = 0;
+        for (int k = c - 1; k >= 0; --k)
+          if (lb[k] == 1.f) first1 = k;
+        best_i = first1;
+      } else {
+        float mx = -INFINITY;
+        for (int k = 0; k < c; ++k) mx = fmaxf(mx, lb[k] == 0.f ? -1e10f : xp[k * hw]);
+        float se = 0.f;
+        for (int k = 0; k < c; ++k) se += expf((lb[k] == 0.f ? -1e10f : xp[k * hw]) - mx);
+        float best = -INFINITY;
+        for (int k = 0; k < c; ++k) {
+          const float p = expf((lb[k] == 0.f ? -1e10f : xp[k * hw]) - mx) / se;
+          ent -= p * logf(p + 1e-10f);
+          if (k == 0 || better(p, best)) { best = p; best_i = k; }
+        }
+      }
+      if (tissue && tissue[i] == 0) best_i = c;
+    } else {
+      float mx = -INFINITY, se = 1.f;
+      if (softmax_first) {
+        for (int k = first_ch; k < c; ++k) mx = fmaxf(mx, xp[k * hw]);
+        se = 0.f;
+        for (int k = first_ch; k < c; ++k) se += expf(xp[k * hw] - mx);
+      }
+      float best = 0.f;
+      for (int k = first_ch; k < c; ++k) {
+        float v = xp[k * hw];
+        if (softmax_first) v = expf(v - mx) / se;
+        if (mode == PS_MASK_MUL) v *= lb[k];
+        if (k == first_ch || better(v, best)) { best = v; best_i = k - first_ch; }
+      }
+    }
+    mask[i] = (uint8_t)best_i;
+    if (entropy) entropy[i] = ent;
+  }
+}
+
+__global__ __launch_bounds__(256) void confusion_kernel(const uint8_t* __restrict__ pred, const long long* __restrict__ gt,
+                                                        unsigned long long* __restrict__ cm, long long npix, int nc) {
+  __shared__ unsigned int hist[256];
+  if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+  __syncthreads();
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+    // loss.py:63 casts the mask with .byte() before the range test
+    const int g = (int)(uint8_t)gt[i], p = pred[i];
+    if (g < nc && p < nc) atomicAdd(&hist[g * nc + p], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < nc * nc && hist[threadIdx.x]) atomicAdd(&cm[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+}
+
+static inline int grid_for(long long items, int per_block, int cap = 2048) {
+  long long b = (items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+int check_t4(const ps_tensor4* t, const char* who) {
+  PS_REQUIRE(t && t->ptr, "%s: null tensor", who);
+  PS_REQUIRE(t->dtype == PS_F32 || t->dtype == PS_BF16, "%s: dtype %d unsupported", who, t->dtype);
+  PS_REQUIRE(t->n > 0 && t->c > 0 && t->h > 0 && t->w > 0, "%s: empty tensor", who);
+  return PS_OK;
+}
+
+}  // namespace
+
+extern "C" int ps_bilinear_fwd(const ps_tensor4* src, const ps_tensor4* dst, int32_t align, void* stream) {
+  if (int rc = check_t4(src, "bilinear_fwd")) return rc;
+  if (int rc = check_t4(dst, "bilinear_fwd")) return rc;
+  PS_REQUIRE(src->n == dst->n && src->c == dst->c, "bilinear_fwd: batch/channel mismatch");
+  const float sy = interp_scale(src->h, dst->h, align != 0), sx = interp_scale(src->w, dst->w, align != 0);
+  const long long total = (long long)dst->n * dst->h * dst->w;
+  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, static_cast<hipStream_t>(stream), to_t4(src),
+                     to_t4(dst), align, sy, sx);
+  PS_CHECK_LAUNCH("bilinear_fwd");
+  return PS_OK;
+}
+
+extern "C" int ps_bilinear_bwd(const ps_tensor4* ddst, const ps_tensor4* dsrc, int32_t align, void* stream) {
+  if (int rc = check_t4(ddst, "bilinear_bwd")) return rc;
+  if (int rc = check_t4(dsrc, "bilinear_bwd")) return rc;
+  PS_REQUIRE(ddst->n == dsrc->n && ddst->c == dsrc->c, "bilinear_bwd: batch/channel mismatch");
+  const float sy = interp_scale(dsrc->h, ddst->h, align != 0), sx = interp_scale(dsrc->w, ddst->w, align != 0);
+  // window of destination pixels per source pixel: ~2/scale (+ slack for the floor/ceil and rounding)
+  const int wy = sy > 0.f ? (int)ceilf(2.f / sy) + 4 : ddst->h;
+  const int wx = sx > 0.f ? (int)ceilf(2.f / sx) + 4 : ddst->w;
+  const long long waves = (long long)dsrc->n * dsrc->h * dsrc->w;
+  PS_REQUIRE((waves + 3) / 4 < (1LL << 31), "bilinear_bwd: too many source pixels");
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), to_t4(ddst),
+                     to_t4(dsrc), align, sy, sx, wy, wx);
+  PS_CHECK_LAUNCH("bilinear_bwd");
+  return PS_OK;
+}
+
+extern "C" int64_t ps_ce_workspace_floats(void) { return CE_BLOCKS; }
+
+extern "C" int ps_softmax_ce(const float* logits, const int64_t* target, float* loss_out, float* dlogits, float grad_scale, int32_t n,
+                             int32_t c, int32_t h, int32_t w, int32_t ignore_index, float* partials, void* stream) {
+  PS_REQUIRE(logits && target && loss_out && partials, "softmax_ce: null argument");
+  PS_REQUIRE(n > 0 && c > 0 && h > 0 && w > 0, "softmax_ce: empty input");
+  const long long hw = (long long)h * w, total = (long long)n * hw;
+  const int grid = grid_for(total, 256, CE_BLOCKS);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(ce_kernel, dim3(grid), dim3(256), 0, s, logits, (const long long*)target, dlogits, partials,
+                     grad_scale / (float)total, n, c, hw, ignore_index < 0 ? -1 : ignore_index);
+  PS_CHECK_LAUNCH("softmax_ce");
+  hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, s, partials, grid, 1.f / (float)total, loss_out);
+  PS_CHECK_LAUNCH("softmax_ce_finish");
+  return PS_OK;
+}
+
+extern "C" int ps_argmax_mask(const float* x, const float* label, const uint8_t* tissue, uint8_t* mask_out, float* entropy_out,
+                              int32_t mode, int32_t softmax_first, int32_t first_ch, int32_t n, int32_t c, int32_t h, int32_t w,
+                              void* stream) {
+  PS_REQUIRE(x && mask_out, "argmax_mask: null argument");
+  PS_REQUIRE(mode >= PS_MASK_PLAIN && mode <= PS_MASK_FILL, "argmax_mask: bad mode %d", mode);
+  PS_REQUIRE(mode == PS_MASK_PLAIN || label, "argmax_mask: mode %d needs label", mode);
+  PS_REQUIRE(n > 0 && c > 0 && c < 255 && h > 0 && w > 0 && first_ch >= 0 && first_ch < c, "argmax_mask: bad shape");
+  const long long hw = (long long)h * w;
+  hipLaunchKernelGGL(argmax_mask_kernel, dim3(grid_for((long long)n * hw, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, label,
+                     tissue, mask_out, entropy_out, mode, softmax_first, mode == PS_MASK_FILL ? 0 : first_ch, n, c, hw);
+  PS_CHECK_LAUNCH("argmax_mask");
+  return PS_OK;
+}
+
+extern "C" int ps_confusion_accum(const uint8_t* pred, const int64_t* gt, int64_t* cm, int64_t npix, int32_t num_class, void* stream) {
+  PS_REQUIRE(pred && gt && cm && npix >= 0, "confusion_accum: null argument");
+  PS_REQUIRE(num_class >= 1 && num_class <= 16, "confusion_accum: num_class %d unsupported (1..16)", num_class);
+  if (npix == 0) return PS_OK;
+  hipLaunchKernelGGL(confusion_kernel, dim3(grid_for(npix, 256 * 16, 1024)), dim3(256), 0, static_cast<hipStream_t>(stream), pred,
+                     (const long long*)gt, (unsigned long long*)cm, (long long)npix, num_class);
+  PS_CHECK_LAUNCH("confusion_accum");
+  return PS_OK;
+}

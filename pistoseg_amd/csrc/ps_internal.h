@@ -1,0 +1,100 @@
+// Internal helpers shared by the kernel translation units of libpistoseg_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/pistoseg_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+void ps_set_error(const char* fmt, ...);
+
+#define PS_REQUIRE(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      ps_set_error(__VA_ARGS__);         \
+      return PS_ERR_ARG;                 \
+    }                                    \
+  } while (0)
+
+#define PS_CHECK_LAUNCH(what)                                                        \
+  do {                                                                               \
+    hipError_t e__ = hipGetLastError();                                              \
+    if (e__ != hipSuccess) {                                                         \
+      ps_set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e__));       \
+      return PS_ERR_LAUNCH;                                                          \
+    }                                                                                \
+  } while (0)
+
+static inline int ps_esize(int dtype) { return dtype == PS_BF16 ? 2 : 4; }
+static inline bool ps_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- device helpers -------------------------------------------------------------------------
+__device__ __forceinline__ float ps_bf16_to_f32(uint16_t b) { return __uint_as_float(static_cast<uint32_t>(b) << 16); }
+__device__ __forceinline__ uint16_t ps_f32_to_bf16(float f) {
+  __bf16 h = static_cast<__bf16>(f);  // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
+  return __builtin_bit_cast(uint16_t, h);
+}
+
+// 8 consecutive channels <-> 8 floats
+template <typename T>
+__device__ __forceinline__ void ps_load8(const T* p, float* v);
+template <>
+__device__ __forceinline__ void ps_load8<float>(const float* p, float* v) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+template <>
+__device__ __forceinline__ void ps_load8<__bf16>(const __bf16* p, float* v) {
+  const uint4 a = *reinterpret_cast<const uint4*>(p);
+  v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+  v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+  v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+  v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+template <typename T>
+__device__ __forceinline__ void ps_store8(T* p, const float* v);
+template <>
+__device__ __forceinline__ void ps_store8<float>(float* p, const float* v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <>
+__device__ __forceinline__ void ps_store8<__bf16>(__bf16* p, const float* v) {
+  uint4 a;
+  a.x = ps_f32_to_bf16(v[0]) | (static_cast<uint32_t>(ps_f32_to_bf16(v[1])) << 16);
+  a.y = ps_f32_to_bf16(v[2]) | (static_cast<uint32_t>(ps_f32_to_bf16(v[3])) << 16);
+  a.z = ps_f32_to_bf16(v[4]) | (static_cast<uint32_t>(ps_f32_to_bf16(v[5])) << 16);
+  a.w = ps_f32_to_bf16(v[6]) | (static_cast<uint32_t>(ps_f32_to_bf16(v[7])) << 16);
+  *reinterpret_cast<uint4*>(p) = a;
+}
+
+__device__ __forceinline__ float ps_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float ps_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float ps_wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Bijective XCD-aware remap of a 1-D block id: blocks that share `id % 8` share an XCD (observed
+// round-robin dispatch; speed only, never correctness), so give each XCD a contiguous chunk of tiles.
+__device__ __forceinline__ int ps_xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

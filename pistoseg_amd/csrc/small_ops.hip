@@ -1,0 +1,378 @@
+// HBM-bound kernels of the segmentation hot path: conv1a (K = 27 direct conv), the fc8 class head and its
+// backward, weight layout transforms, and the flat-arena optimisers.  wave64 everywhere; 16-byte accesses.
+#include <math.h>
+
+#include "ps_internal.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// conv1a: NCHW f32 image -> channels-last activation.  4 lanes per pixel, 16 couts each.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv1a_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     T* __restrict__ out_act, T* __restrict__ out_raw, int n, int h, int wd) {
+  __shared__ float ws[27][64];  // [k][cout], k = ci*9 + ky*3 + kx (OIHW order)
+  __shared__ float ssc[64], ssh[64];
+  for (int i = threadIdx.x; i < 27 * 64; i += 256) {
+    const int co = i / 27, k = i - co * 27;
+    ws[k][co] = w[i];
+  }
+  if (threadIdx.x < 64) {
+    ssc[threadIdx.x] = scale ? scale[threadIdx.x] : 1.f;
+    ssh[threadIdx.x] = shift ? shift[threadIdx.x] : 0.f;
+  }
+  __syncthreads();
+  const long long total = (long long)n * h * wd;
+  const int cg = threadIdx.x & 3;  // cout group of 16
+  for (long long pix = (long long)blockIdx.x * 64 + (threadIdx.x >> 2); pix < total; pix += (long long)gridDim.x * 64) {
+    const int img = (int)(pix / ((long long)h * wd));
+    const int rem = (int)(pix - (long long)img * h * wd);
+    const int y = rem / wd, xx = rem - y * wd;
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int yy = y + ky - 1, xs = xx + kx - 1;
+          float v = 0.f;
+          if (yy >= 0 && yy < h && xs >= 0 && xs < wd) v = x[(((long long)img * 3 + ci) * h + yy) * wd + xs];
+          const float* wr = &ws[ci * 9 + ky * 3 + kx][cg * 16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[i] = fmaf(v, wr[i], acc[i]);
+        }
+    if (out_raw) {
+      ps_store8<T>(out_raw + pix * 64 + cg * 16, acc);
+      ps_store8<T>(out_raw + pix * 64 + cg * 16 + 8, acc + 8);
+    }
+    if (out_act) {
+      float a[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a[i] = fmaxf(acc[i] * ssc[cg * 16 + i] + ssh[cg * 16 + i], 0.f);
+      ps_store8<T>(out_act + pix * 64 + cg * 16, a);
+      ps_store8<T>(out_act + pix * 64 + cg * 16 + 8, a + 8);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fc8 forward: cam[m,c] = sum_k x[m,k]*drop[n,k]*w[c,k].  One wave per 8 pixels; a lane owns 8 channels
+// of every 512-channel chunk (weights for the chunk live in registers across the 8 pixels).
+// ------------------------------------------------------------------------------------------------
+constexpr int FC8_MAXC = 8;
+template <typename T>
+__global__ __launch_bounds__(256) void fc8_fwd_kernel(const T* __restrict__ x, int ldc, const float* __restrict__ w,
+                                                      const float* __restrict__ drop, float* __restrict__ cam, int M, int ppi,
+                                                      int K, int C) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m0 = (blockIdx.x * 4 + wave) * 8;
+  if (m0 >= M) return;
+  float acc[8][FC8_MAXC];
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int c = 0; c < FC8_MAXC; ++c) acc[p][c] = 0.f;
+  for (int k0 = lane * 8; k0 < K; k0 += 512) {
+    float wv[FC8_MAXC][8];
+#pragma unroll
+    for (int c = 0; c < FC8_MAXC; ++c) {
+      if (c < C) ps_load8<float>(w + (long long)c * K + k0, wv[c]);
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int m = m0 + p;
+      if (m >= M) break;
+      float xv[8];
+      ps_load8<T>(x + (long long)m * ldc + k0, xv);
+      if (drop) {
+        float dv[8];
+        ps_load8<float>(drop + (long long)(m / ppi) * K + k0, dv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xv[i] *= dv[i];
+      }
+#pragma unroll
+      for (int c = 0; c < FC8_MAXC; ++c) {
+        if (c < C) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[p][c] = fmaf(xv[i], wv[c][i], acc[p][c]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+#pragma unroll
+    for (int c = 0; c < FC8_MAXC; ++c) {
+      if (c < C) {
+        const float s = ps_wave_sum(acc[p][c]);
+        if (lane == 0 && m0 + p < M) cam[(long long)(m0 + p) * C + c] = s;
+      }
+    }
+  }
+}
+
+// fc8 backward (+ ReLU(bn7) mask): a thread owns 8 channels and walks a pixel range.
+template <typename T>
+__global__ __launch_bounds__(256) void fc8_bwd_kernel(const T* __restrict__ x, int ldc, const float* __restrict__ w,
+                                                      const float* __restrict__ drop, const float* __restrict__ scale7,
+                                                      const float* __restrict__ dcam, T* __restrict__ dx, int ldc_dx,
+                                                      float* __restrict__ dw, int M, int ppi, int K, int C, int pix_per_block) {
+  const int kblocks = K / 2048;
+  const int kb = blockIdx.x % kblocks, mb = blockIdx.x / kblocks;
+  const int k0 = kb * 2048 + threadIdx.x * 8;
+  const int ma = mb * pix_per_block, me = min(M, ma + pix_per_block);
+  float wv[FC8_MAXC][8], gw[FC8_MAXC][8], s7[8];
+#pragma unroll
+  for (int c = 0; c < FC8_MAXC; ++c) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gw[c][i] = 0.f;
+    if (c < C) ps_load8<float>(w + (long long)c * K + k0, wv[c]);
+  }
+  ps_load8<float>(scale7 + k0, s7);
+  for (int m = ma; m < me; ++m) {
+    float xv[8], dv[8], g[8];
+    ps_load8<T>(x + (long long)m * ldc + k0, xv);
+    if (drop) ps_load8<float>(drop + (long long)(m / ppi) * K + k0, dv);
+    else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dv[i] = 1.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < FC8_MAXC; ++c) {
+      if (c < C) {
+        const float d = dcam[(long long)m * C + c];  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          g[i] = fmaf(d, wv[c][i], g[i]);
+          gw[c][i] = fmaf(d, xv[i] * dv[i], gw[c][i]);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[i] = xv[i] > 0.f ? g[i] * dv[i] * s7[i] : 0.f;
+    ps_store8<T>(dx + (long long)m * ldc_dx + k0, g);
+  }
+#pragma unroll
+  for (int c = 0; c < FC8_MAXC; ++c) {
+    if (c < C) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) atomicAdd(dw + (long long)c * K + k0 + i, gw[c][i]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight layout: dst[cin][tap][cout] = src[cout][tap][cin]  (32x32 LDS tile transpose per tap)
+// ------------------------------------------------------------------------------------------------
+template <typename S>
+__device__ __forceinline__ float to_f32(S v);
+template <>
+__device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ float to_f32<uint16_t>(uint16_t v) { return ps_bf16_to_f32(v); }
+template <typename D>
+__device__ __forceinline__ D from_f32(float v);
+template <>
+__device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ uint16_t from_f32<uint16_t>(float v) { return ps_f32_to_bf16(v); }
+
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void weight_transpose_kernel(const S* __restrict__ src, D* __restrict__ dst, int cout, int taps,
+                                                               int cin) {
+  __shared__ float tile[32][33];
+  const int tap = blockIdx.z;
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    tile[r][tx] = (co < cout && ci < cin) ? to_f32<S>(src[((long long)co * taps + tap) * cin + ci]) : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < cin && co < cout) dst[((long long)ci * taps + tap) * cout + co] = from_f32<D>(tile[tx][r]);
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long long n) {
+  const long long stride = (long long)gridDim.x * 256 * 8;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += stride) {
+    if (i + 8 <= n) {
+      float v[8];
+      ps_load8<float>(src + i, v);
+      ps_store8<__bf16>(dst + i, v);
+    } else {
+      for (long long j = i; j < n; ++j) dst[j] = static_cast<__bf16>(src[j]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// optimisers over a flat arena
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, __bf16* __restrict__ pb, long long n, float lr,
+                                                    float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+  const long long stride = (long long)gridDim.x * 256 * 4;
+  const float step_size = lr / bc1;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    const int cnt = (i + 4 <= n) ? 4 : (int)(n - i);
+    for (int j = 0; j < cnt; ++j) {
+      const long long k = i + j;
+      float pk = p[k];
+      const float gk = g[k];
+      pk *= 1.f - lr * wd;
+      const float mk = m[k] + (gk - m[k]) * (1.f - b1);          // torch: exp_avg.lerp_(grad, 1 - beta1)
+      const float vk = b2 * v[k] + (1.f - b2) * gk * gk;          // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+      const float denom = sqrtf(vk) / bc2_sqrt + eps;
+      pk -= step_size * (mk / denom);
+      p[k] = pk; m[k] = mk; v[k] = vk;
+      if (pb) pb[k] = static_cast<__bf16>(pk);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                  __bf16* __restrict__ pb, long long n, float lr, float mom, float wd, int first) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
+    float pk = p[k];
+    float gk = g[k];
+    if (wd != 0.f) gk = fmaf(wd, pk, gk);
+    if (mom != 0.f) {
+      const float b = first ? gk : mom * buf[k] + gk;
+      buf[k] = b;
+      gk = b;
+    }
+    pk -= lr * gk;
+    p[k] = pk;
+    if (pb) pb[k] = static_cast<__bf16>(pk);
+  }
+}
+
+static inline int grid_for(long long work_items, int per_block, int cap = 256 * 8) {
+  long long b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int ps_conv1a_fwd(int32_t out_dtype, const float* x, const float* w, const float* scale, const float* shift,
+                             void* out_act, void* out_raw, int32_t n, int32_t h, int32_t wd, void* stream) {
+  PS_REQUIRE(x && w && (out_act || out_raw), "conv1a: null argument");
+  PS_REQUIRE(n > 0 && h > 0 && wd > 0, "conv1a: empty input");
+  PS_REQUIRE((!out_act || ps_aligned16(out_act)) && (!out_raw || ps_aligned16(out_raw)), "conv1a: misaligned output");
+  const long long pix = (long long)n * h * wd;
+  const int grid = grid_for(pix, 64, 256 * 16);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (out_dtype == PS_BF16)
+    hipLaunchKernelGGL(conv1a_kernel<__bf16>, dim3(grid), dim3(256), 0, s, x, w, scale, shift, (__bf16*)out_act, (__bf16*)out_raw, n, h, wd);
+  else if (out_dtype == PS_F32)
+    hipLaunchKernelGGL(conv1a_kernel<float>, dim3(grid), dim3(256), 0, s, x, w, scale, shift, (float*)out_act, (float*)out_raw, n, h, wd);
+  else
+    PS_REQUIRE(false, "conv1a: dtype %d unsupported", out_dtype);
+  PS_CHECK_LAUNCH("conv1a");
+  return PS_OK;
+}
+
+extern "C" int ps_fc8_fwd(int32_t dtype, const void* x, int32_t ldc_x, const float* w, const float* drop, float* cam,
+                          int32_t m_total, int32_t ppi, int32_t k, int32_t c, void* stream) {
+  PS_REQUIRE(x && w && cam, "fc8_fwd: null argument");
+  PS_REQUIRE(c >= 1 && c <= FC8_MAXC, "fc8_fwd: C=%d unsupported (1..%d)", c, FC8_MAXC);
+  PS_REQUIRE(k % 512 == 0 && m_total > 0 && ppi > 0, "fc8_fwd: K=%d must be a multiple of 512", k);
+  PS_REQUIRE(ps_aligned16(x) && ps_aligned16(w) && (ldc_x * ps_esize(dtype)) % 16 == 0, "fc8_fwd: misaligned input");
+  const int grid = (m_total + 31) / 32;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == PS_BF16)
+    hipLaunchKernelGGL(fc8_fwd_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, ldc_x, w, drop, cam, m_total, ppi, k, c);
+  else if (dtype == PS_F32)
+    hipLaunchKernelGGL(fc8_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ldc_x, w, drop, cam, m_total, ppi, k, c);
+  else
+    PS_REQUIRE(false, "fc8_fwd: dtype %d unsupported", dtype);
+  PS_CHECK_LAUNCH("fc8_fwd");
+  return PS_OK;
+}
+
+extern "C" int ps_fc8_bwd(int32_t dtype, const void* x, int32_t ldc_x, const float* w, const float* drop, const float* scale7,
+                          const float* dcam, void* dx, int32_t ldc_dx, float* dw, int32_t m_total, int32_t ppi, int32_t k,
+                          int32_t c, void* stream) {
+  PS_REQUIRE(x && w && scale7 && dcam && dx && dw, "fc8_bwd: null argument");
+  PS_REQUIRE(c >= 1 && c <= FC8_MAXC, "fc8_bwd: C=%d unsupported (1..%d)", c, FC8_MAXC);
+  PS_REQUIRE(k % 2048 == 0 && m_total > 0 && ppi > 0, "fc8_bwd: K=%d must be a multiple of 2048", k);
+  const int es = ps_esize(dtype);
+  PS_REQUIRE(ps_aligned16(x) && ps_aligned16(dx) && (ldc_x * es) % 16 == 0 && (ldc_dx * es) % 16 == 0, "fc8_bwd: misaligned tensor");
+  const int ppb = 64;
+  const int grid = (k / 2048) * ((m_total + ppb - 1) / ppb);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == PS_BF16)
+    hipLaunchKernelGGL(fc8_bwd_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, ldc_x, w, drop, scale7, dcam, (__bf16*)dx,
+                       ldc_dx, dw, m_total, ppi, k, c, ppb);
+  else if (dtype == PS_F32)
+    hipLaunchKernelGGL(fc8_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ldc_x, w, drop, scale7, dcam, (float*)dx,
+                       ldc_dx, dw, m_total, ppi, k, c, ppb);
+  else
+    PS_REQUIRE(false, "fc8_bwd: dtype %d unsupported", dtype);
+  PS_CHECK_LAUNCH("fc8_bwd");
+  return PS_OK;
+}
+
+extern "C" int ps_weight_transpose(int32_t sdt, int32_t ddt, const void* src, void* dst, int32_t cout, int32_t taps, int32_t cin,
+                                   void* stream) {
+  PS_REQUIRE(src && dst && cout > 0 && taps > 0 && cin > 0, "weight_transpose: bad argument");
+  dim3 grid((cin + 31) / 32, (cout + 31) / 32, taps);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (sdt == PS_F32 && ddt == PS_F32)
+    hipLaunchKernelGGL((weight_transpose_kernel<float, float>), grid, dim3(256), 0, s, (const float*)src, (float*)dst, cout, taps, cin);
+  else if (sdt == PS_F32 && ddt == PS_BF16)
+    hipLaunchKernelGGL((weight_transpose_kernel<float, uint16_t>), grid, dim3(256), 0, s, (const float*)src, (uint16_t*)dst, cout, taps, cin);
+  else if (sdt == PS_BF16 && ddt == PS_BF16)
+    hipLaunchKernelGGL((weight_transpose_kernel<uint16_t, uint16_t>), grid, dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst, cout, taps, cin);
+  else
+    PS_REQUIRE(false, "weight_transpose: dtype pair (%d,%d) unsupported", sdt, ddt);
+  PS_CHECK_LAUNCH("weight_transpose");
+  return PS_OK;
+}
+
+extern "C" int ps_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  PS_REQUIRE(src && dst && n >= 0, "cast_f32_bf16: bad argument");
+  if (n == 0) return PS_OK;
+  PS_REQUIRE(ps_aligned16(src) && ps_aligned16(dst), "cast_f32_bf16: misaligned pointer");
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n, 256 * 8)), dim3(256), 0, static_cast<hipStream_t>(stream), src, (__bf16*)dst,
+                     (long long)n);
+  PS_CHECK_LAUNCH("cast_f32_bf16");
+  return PS_OK;
+}
+
+extern "C" int ps_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int32_t step, void* stream) {
+  PS_REQUIRE(p && g && m && v && n >= 0 && step >= 1, "adamw_step: bad argument");
+  if (n == 0) return PS_OK;
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, (__bf16*)p_bf16,
+                     (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt);
+  PS_CHECK_LAUNCH("adamw_step");
+  return PS_OK;
+}
+
+extern "C" int ps_sgd_step(float* p, const float* g, float* buf, void* p_bf16, int64_t n, float lr, float momentum,
+                           float weight_decay, int32_t first_step, void* stream) {
+  PS_REQUIRE(p && g && n >= 0 && (momentum == 0.f || buf), "sgd_step: bad argument");
+  if (n == 0) return PS_OK;
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, buf, (__bf16*)p_bf16,
+                     (long long)n, lr, momentum, weight_decay, first_step);
+  PS_CHECK_LAUNCH("sgd_step");
+  return PS_OK;
+}

@@ -1,0 +1,265 @@
+"""Tensor-level wrappers over the C-ABI (include/pistoseg_hip.h).
+
+torch is used here for device memory and streams only: every function passes raw device pointers, sizes
+and the current HIP stream to libpistoseg_hip.so.  Activations are channels-last `[N, H, W, C]` torch
+tensors (f32 or bf16) that may be channel slices of wider buffers (`stride(2)` = channel stride `ldc`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import PS_BF16, PS_EPI_BNRELU, PS_EPI_NONE, PS_EPI_RELUBWD, PS_F32, ConvGeom, Epilogue, Tensor4
+
+Tensor = torch.Tensor
+
+
+def _dt(t_or_dtype) -> int:
+    d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
+    if d == torch.float32:
+        return PS_F32
+    if d == torch.bfloat16:
+        return PS_BF16
+    raise TypeError(f"unsupported dtype {d}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _require_gpu(*ts: Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.PsError("pistoseg_amd ops need device tensors: the HIP path has no CPU fallback")
+
+
+def _ldc(t: Tensor) -> int:
+    """Channel stride of a channels-last activation [N,H,W,C] (pixels must be densely packed rows of ldc)."""
+    assert t.dim() == 4 and t.stride(3) == 1, "activation must be [N,H,W,C] with unit channel stride"
+    ldc = t.stride(2)
+    assert t.stride(1) == ldc * t.shape[2] and t.stride(0) == ldc * t.shape[2] * t.shape[1], "pixels must be contiguous"
+    return ldc
+
+
+@dataclass
+class ConvSpec:
+    """Geometry of one convolution of the net (forward sense)."""
+
+    cin: int
+    cout: int
+    ksize: int
+    stride: int = 1
+    dilation: int = 1
+
+    def out_hw(self, h: int, w: int):
+        return (h - 1) // self.stride + 1, (w - 1) // self.stride + 1
+
+
+def _geom(spec: ConvSpec, dtype: int, n: int, h: int, w: int, ldc_x: int, ldc_y: int) -> ConvGeom:
+    return ConvGeom(dtype, n, h, w, spec.cin, spec.cout, spec.ksize, spec.stride, spec.dilation, ldc_x, ldc_y)
+
+
+def _epilogue(mode=PS_EPI_NONE, add0=None, out_raw=None, scale=None, shift=None, drop=None, mask_src=None, add1=None, out=None) -> Epilogue:
+    e = Epilogue()
+    e.mode = mode
+    if add0 is not None:
+        e.add0, e.ldc_add0 = add0.data_ptr(), _ldc(add0)
+    if out_raw is not None:
+        e.out_raw, e.ldc_raw = out_raw.data_ptr(), _ldc(out_raw)
+    e.scale, e.shift, e.drop = _ptr(scale), _ptr(shift), _ptr(drop)
+    if mask_src is not None:
+        e.mask_src, e.ldc_mask = mask_src.data_ptr(), _ldc(mask_src)
+    if add1 is not None:
+        e.add1, e.ldc_add1 = add1.data_ptr(), _ldc(add1)
+    if out is not None:
+        e.out, e.ldc_out = out.data_ptr(), _ldc(out)
+    return e
+
+
+def conv2d_fwd(spec: ConvSpec, x: Tensor, w_fwd: Tensor, *, add0=None, out_raw=None, bn_scale=None, bn_shift=None, drop=None,
+               out_act=None, relu=False) -> None:
+    """y = conv(x, W) [+ add0]; out_raw <- y; out_act <- max(y*scale+shift, 0)*drop (if out_act given)."""
+    _require_gpu(x, w_fwd)
+    n, h, w, c = x.shape
+    assert c == spec.cin and w_fwd.numel() == spec.cout * spec.cin * spec.ksize**2 and w_fwd.dtype == x.dtype
+    mode = PS_EPI_BNRELU if out_act is not None else PS_EPI_NONE
+    ref = out_act if out_act is not None else out_raw
+    g = _geom(spec, _dt(x), n, h, w, _ldc(x), _ldc(ref))
+    e = _epilogue(mode, add0=add0, out_raw=out_raw, scale=bn_scale, shift=bn_shift, drop=drop, out=out_act)
+    lib = _lib.load()
+    _lib.check(lib.ps_conv2d_fwd(C.byref(g), x.data_ptr(), w_fwd.data_ptr(), C.byref(e), _stream()), "ps_conv2d_fwd")
+
+
+def conv2d_dgrad(spec: ConvSpec, dy: Tensor, w_dgrad: Tensor, x_hw, *, add0=None, out_raw=None, mask_src=None, bn_scale=None,
+                 drop=None, add1=None, out=None) -> None:
+    """dx = conv^T(dy, W) [+ add0]; out_raw <- dx; out <- (mask_src>0 ? dx*scale*drop : 0) [+ add1]."""
+    _require_gpu(dy, w_dgrad)
+    n = dy.shape[0]
+    h, w = x_hw
+    assert dy.shape[3] == spec.cout and tuple(dy.shape[1:3]) == spec.out_hw(h, w) and w_dgrad.dtype == dy.dtype
+    mode = PS_EPI_RELUBWD if out is not None else PS_EPI_NONE
+    ref = out if out is not None else out_raw
+    g = _geom(spec, _dt(dy), n, h, w, _ldc(ref), _ldc(dy))
+    e = _epilogue(mode, add0=add0, out_raw=out_raw, scale=bn_scale, drop=drop, mask_src=mask_src, add1=add1, out=out)
+    lib = _lib.load()
+    _lib.check(lib.ps_conv2d_dgrad(C.byref(g), dy.data_ptr(), w_dgrad.data_ptr(), C.byref(e), _stream()), "ps_conv2d_dgrad")
+
+
+def conv2d_wgrad(spec: ConvSpec, x: Tensor, dy: Tensor, dw: Tensor) -> None:
+    """dw[cout][kh][kw][cin] (f32, channels-last OIHW storage) += sum_pixels dy * x@tap."""
+    _require_gpu(x, dy, dw)
+    n, h, w, c = x.shape
+    assert c == spec.cin and dy.shape[3] == spec.cout and dw.dtype == torch.float32 and x.dtype == dy.dtype
+    assert dw.numel() == spec.cout * spec.cin * spec.ksize**2
+    g = _geom(spec, _dt(x), n, h, w, _ldc(x), _ldc(dy))
+    lib = _lib.load()
+    _lib.check(lib.ps_conv2d_wgrad(C.byref(g), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _stream()), "ps_conv2d_wgrad")
+
+
+def weight_transpose(src: Tensor, dst: Tensor, cout: int, taps: int, cin: int) -> None:
+    _require_gpu(src, dst)
+    assert src.numel() == dst.numel() == cout * taps * cin
+    lib = _lib.load()
+    _lib.check(lib.ps_weight_transpose(_dt(src), _dt(dst), src.data_ptr(), dst.data_ptr(), cout, taps, cin, _stream()), "ps_weight_transpose")
+
+
+def cast_f32_bf16(src: Tensor, dst: Tensor) -> None:
+    _require_gpu(src, dst)
+    assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
+    lib = _lib.load()
+    _lib.check(lib.ps_cast_f32_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), "ps_cast_f32_bf16")
+
+
+def conv1a_fwd(x_nchw: Tensor, w_oihw: Tensor, bn_scale: Optional[Tensor], bn_shift: Optional[Tensor], out_act: Optional[Tensor],
+               out_raw: Optional[Tensor] = None) -> None:
+    _require_gpu(x_nchw, w_oihw)
+    n, c, h, w = x_nchw.shape
+    assert c == 3 and x_nchw.is_contiguous() and x_nchw.dtype == torch.float32
+    assert w_oihw.is_contiguous() and w_oihw.dtype == torch.float32 and tuple(w_oihw.shape) == (64, 3, 3, 3)
+    ref = out_act if out_act is not None else out_raw
+    assert ref.is_contiguous() and tuple(ref.shape) == (n, h, w, 64)
+    lib = _lib.load()
+    _lib.check(
+        lib.ps_conv1a_fwd(_dt(ref), x_nchw.data_ptr(), w_oihw.data_ptr(), _ptr(bn_scale), _ptr(bn_shift), _ptr(out_act), _ptr(out_raw), n, h, w, _stream()),
+        "ps_conv1a_fwd",
+    )
+
+
+def fc8_fwd(x: Tensor, w: Tensor, drop: Optional[Tensor], cam: Tensor) -> None:
+    """cam[N,g,g,C] (f32) = fc8(dropout7(x)); x channels-last [N,g,g,K]; w f32 [C,K]."""
+    _require_gpu(x, w, cam)
+    n, h, wd, k = x.shape
+    c = w.shape[0]
+    assert w.dtype == torch.float32 and w.is_contiguous() and cam.dtype == torch.float32 and cam.is_contiguous()
+    assert tuple(cam.shape) == (n, h, wd, c)
+    lib = _lib.load()
+    _lib.check(lib.ps_fc8_fwd(_dt(x), x.data_ptr(), _ldc(x), w.data_ptr(), _ptr(drop), cam.data_ptr(), n * h * wd, h * wd, k, c, _stream()), "ps_fc8_fwd")
+
+
+def fc8_bwd(x: Tensor, w: Tensor, drop: Optional[Tensor], scale7: Tensor, dcam: Tensor, dx: Tensor, dw: Tensor) -> None:
+    _require_gpu(x, w, dcam, dx, dw)
+    n, h, wd, k = x.shape
+    c = w.shape[0]
+    assert dcam.is_contiguous() and dcam.dtype == torch.float32 and dw.dtype == torch.float32 and dw.is_contiguous()
+    lib = _lib.load()
+    _lib.check(
+        lib.ps_fc8_bwd(_dt(x), x.data_ptr(), _ldc(x), w.data_ptr(), _ptr(drop), scale7.data_ptr(), dcam.data_ptr(), dx.data_ptr(), _ldc(dx),
+                       dw.data_ptr(), n * h * wd, h * wd, k, c, _stream()),
+        "ps_fc8_bwd",
+    )
+
+
+def _t4(t: Tensor, layout: str) -> Tensor4:
+    """View a 4-d tensor as (n, c, h, w) with element strides. layout: 'nchw' or 'nhwc' (how t's dims are ordered)."""
+    if layout == "nchw":
+        n, c, h, w = t.shape
+        sn, sc, sh, sw = t.stride()
+    else:
+        n, h, w, c = t.shape
+        sn, sh, sw, sc = t.stride()
+    return Tensor4(t.data_ptr(), _dt(t), n, c, h, w, 0, sn, sc, sh, sw)
+
+
+def bilinear_fwd(src: Tensor, src_layout: str, dst: Tensor, dst_layout: str, align_corners: bool) -> None:
+    _require_gpu(src, dst)
+    a, b = _t4(src, src_layout), _t4(dst, dst_layout)
+    lib = _lib.load()
+    _lib.check(lib.ps_bilinear_fwd(C.byref(a), C.byref(b), int(align_corners), _stream()), "ps_bilinear_fwd")
+
+
+def bilinear_bwd(ddst: Tensor, ddst_layout: str, dsrc: Tensor, dsrc_layout: str, align_corners: bool) -> None:
+    _require_gpu(ddst, dsrc)
+    a, b = _t4(ddst, ddst_layout), _t4(dsrc, dsrc_layout)
+    lib = _lib.load()
+    _lib.check(lib.ps_bilinear_bwd(C.byref(a), C.byref(b), int(align_corners), _stream()), "ps_bilinear_bwd")
+
+
+def softmax_ce(logits: Tensor, target: Tensor, ignore_index: Optional[int], want_grad: bool, grad_scale: float = 1.0):
+    """Mean-over-all-pixels CE (SegmentationModule.training_step).  Returns (loss[1] f32, dlogits or None)."""
+    _require_gpu(logits, target)
+    n, c, h, w = logits.shape
+    assert logits.is_contiguous() and logits.dtype == torch.float32 and target.dtype == torch.int64 and target.is_contiguous()
+    lib = _lib.load()
+    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    partials = torch.empty(int(lib.ps_ce_workspace_floats()), device=logits.device, dtype=torch.float32)
+    dlogits = torch.empty_like(logits) if want_grad else None
+    _lib.check(
+        lib.ps_softmax_ce(logits.data_ptr(), target.data_ptr(), loss.data_ptr(), _ptr(dlogits), float(grad_scale), n, c, h, w,
+                          -1 if ignore_index is None else int(ignore_index), partials.data_ptr(), _stream()),
+        "ps_softmax_ce",
+    )
+    return loss, dlogits
+
+
+def argmax_mask(x: Tensor, *, mode: int = _lib.PS_MASK_PLAIN, softmax_first: bool = False, first_ch: int = 0, label: Optional[Tensor] = None,
+                tissue: Optional[Tensor] = None, want_entropy: bool = False):
+    """NCHW f32 scores -> uint8 mask [N,H,W] (+ optional f32 entropy)."""
+    _require_gpu(x)
+    n, c, h, w = x.shape
+    assert x.is_contiguous() and x.dtype == torch.float32
+    mask = torch.empty((n, h, w), device=x.device, dtype=torch.uint8)
+    ent = torch.empty((n, h, w), device=x.device, dtype=torch.float32) if want_entropy else None
+    if label is not None:
+        label = label.reshape(n, c).to(torch.float32).contiguous()
+    if tissue is not None:
+        assert tissue.dtype == torch.uint8 and tissue.is_contiguous() and tuple(tissue.shape) == (n, h, w)
+    lib = _lib.load()
+    _lib.check(
+        lib.ps_argmax_mask(x.data_ptr(), _ptr(label), _ptr(tissue), mask.data_ptr(), _ptr(ent), mode, int(softmax_first), first_ch, n, c, h, w, _stream()),
+        "ps_argmax_mask",
+    )
+    return (mask, ent) if want_entropy else mask
+
+
+def confusion_accum(pred: Tensor, gt: Tensor, cm: Tensor, num_class: int) -> None:
+    _require_gpu(pred, gt, cm)
+    assert pred.dtype == torch.uint8 and gt.dtype == torch.int64 and cm.dtype == torch.int64 and cm.numel() == num_class * num_class
+    assert pred.is_contiguous() and gt.is_contiguous() and pred.numel() == gt.numel()
+    lib = _lib.load()
+    _lib.check(lib.ps_confusion_accum(pred.data_ptr(), gt.data_ptr(), cm.data_ptr(), pred.numel(), num_class, _stream()), "ps_confusion_accum")
+
+
+def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, p_bf16: Optional[Tensor], lr: float, betas, eps: float, weight_decay: float, step: int) -> None:
+    _require_gpu(p, g, m, v)
+    lib = _lib.load()
+    _lib.check(
+        lib.ps_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(p_bf16), p.numel(), lr, betas[0], betas[1], eps, weight_decay, step, _stream()),
+        "ps_adamw_step",
+    )
+
+
+def sgd_step(p: Tensor, g: Tensor, buf: Optional[Tensor], p_bf16: Optional[Tensor], lr: float, momentum: float, weight_decay: float, first_step: bool) -> None:
+    _require_gpu(p, g)
+    lib = _lib.load()
+    _lib.check(
+        lib.ps_sgd_step(p.data_ptr(), g.data_ptr(), _ptr(buf), _ptr(p_bf16), p.numel(), lr, momentum, weight_decay, int(first_step), _stream()),
+        "ps_sgd_step",
+    )

@@ -1,0 +1,327 @@
+"""GPU parity of the individual HIP kernels (through the C-ABI) against the torch-CPU primitives the oracle
+is made of.  f32 path: 1e-4 relative (north_star); bf16 path: compared against the same CPU op on
+bf16-rounded operands (only accumulation order and output rounding differ)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-4
+BF16_TOL = 1.2e-2
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def nhwc(t):  # NCHW -> channels-last [N,H,W,C]
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def w_fwd_layout(w):  # OIHW -> [cout][kh][kw][cin]
+    return w.permute(0, 2, 3, 1).contiguous()
+
+
+def w_dgrad_layout(w):  # OIHW -> [cin][kh][kw][cout]
+    return w.permute(1, 2, 3, 0).contiguous()
+
+
+# the distinct (cin, cout, k, s, d) classes of SURVEY 8a plus head shapes
+CONV_CASES = [
+    (64, 128, 3, 2, 1), (64, 128, 1, 2, 1), (128, 128, 3, 1, 1), (128, 256, 3, 2, 1), (256, 256, 3, 1, 1),
+    (256, 512, 1, 2, 1), (512, 512, 3, 1, 1), (512, 1024, 1, 1, 1), (512, 1024, 3, 1, 2), (1024, 512, 3, 1, 2),
+    (512, 1024, 3, 1, 4), (1024, 2048, 1, 1, 1), (512, 64, 1, 1, 1), (256, 192, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("glds", [1, 0])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(case, dtype, glds):
+    from pistoseg_amd import _lib, ops
+
+    lib = _lib.load()
+    lib.ps_debug_set_glds(glds)
+    try:
+        cin, cout, k, s, d = case
+        if glds == 0 and cin > 256:
+            pytest.skip("register-staging variant is covered on the small cases")
+        n, h, w = 2, 13, 10  # odd/even sizes, M not a multiple of 128
+        g = torch.Generator().manual_seed(sum(case) * 7 + k)
+        x = torch.randn(n, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+        if dtype == torch.bfloat16:
+            x, wt = x.bfloat16().float(), wt.bfloat16().float()
+        x.requires_grad_(True)
+        wt.requires_grad_(True)
+        y = F.conv2d(x, wt, stride=s, padding=d if k == 3 else 0, dilation=d)
+        gy = torch.randn(y.shape, generator=g)
+        if dtype == torch.bfloat16:
+            gy = gy.bfloat16().float()
+        y.backward(gy)
+        tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+
+        spec = ops.ConvSpec(cin, cout, k, s, d)
+        xd = nhwc(x.detach()).to(dev(), dtype)
+        wf = w_fwd_layout(wt.detach()).to(dev(), dtype)
+        ho, wo = spec.out_hw(h, w)
+        yd = torch.full((n, ho, wo, cout), float("nan"), device=dev(), dtype=dtype)
+        ops.conv2d_fwd(spec, xd, wf, out_raw=yd)
+        assert rel_err(yd.float().cpu(), nhwc(y.detach())) < tol
+
+        # dgrad
+        gyd = nhwc(gy).to(dev(), dtype)
+        wd = w_dgrad_layout(wt.detach()).to(dev(), dtype)
+        gxd = torch.full((n, h, w, cin), float("nan"), device=dev(), dtype=dtype)
+        ops.conv2d_dgrad(spec, gyd, wd, (h, w), out_raw=gxd)
+        assert rel_err(gxd.float().cpu(), nhwc(x.grad)) < tol
+
+        # weight transpose kernel produces the dgrad layout
+        wd2 = torch.empty_like(wd)
+        ops.weight_transpose(wf, wd2, cout, k * k, cin)
+        assert torch.equal(wd2, wd)
+
+        # wgrad (f32 accumulate, atomics)
+        dw = torch.zeros((cout, k, k, cin), device=dev(), dtype=torch.float32)
+        ops.conv2d_wgrad(spec, xd, gyd, dw)
+        assert rel_err(dw.cpu(), w_fwd_layout(wt.grad)) < tol
+    finally:
+        lib.ps_debug_set_glds(1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_epilogues(dtype):
+    from pistoseg_amd import ops
+
+    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    n, h, w, cin, cout = 3, 9, 11, 128, 256
+    g = torch.Generator().manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    x, wt, res = q(rnd(n, cin, h, w)), q(rnd(cout, cin, 3, 3) * 0.03), q(rnd(n, cout, h, w))
+    scale, shift = torch.rand(cout, generator=g) + 0.5, rnd(cout) * 0.2
+    drop = (torch.rand(n, cout, generator=g) > 0.3).float() / 0.7
+    spec = ops.ConvSpec(cin, cout, 3, 1, 2)
+    y = F.conv2d(x, wt, padding=2, dilation=2) + res
+    act = F.relu(y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)) * drop.view(n, cout, 1, 1)
+    D = dev()
+    xd, wf, resd = nhwc(x).to(D, dtype), w_fwd_layout(wt).to(D, dtype), nhwc(res).to(D, dtype)
+    # outputs are channel slices of wider buffers (ldc > C)
+    wide_raw = torch.zeros((n, h, w, cout + 64), device=D, dtype=dtype)
+    wide_act = torch.zeros((n, h, w, cout + 128), device=D, dtype=dtype)
+    out_raw, out_act = wide_raw[..., 64:], wide_act[..., :cout]
+    ops.conv2d_fwd(spec, xd, wf, add0=resd, out_raw=out_raw, bn_scale=scale.to(D), bn_shift=shift.to(D), drop=drop.to(D), out_act=out_act)
+    assert rel_err(out_raw.float().cpu(), nhwc(y)) < tol
+    assert rel_err(out_act.float().cpu(), nhwc(act)) < tol
+    assert float(wide_raw[..., :64].abs().max()) == 0 and float(wide_act[..., cout:].abs().max()) == 0
+
+    # backward epilogue: dx = ((conv^T(dy) + add0) * [mask>0] * scale * drop) + add1
+    dy = q(rnd(n, cout, h, w))
+    mask_src = q(F.relu(rnd(n, cin, h, w)))
+    add0, add1 = q(rnd(n, cin, h, w)), q(rnd(n, cin, h, w))
+    sc2 = torch.rand(cin, generator=g) + 0.5
+    drop2 = (torch.rand(n, cin, generator=g) > 0.3).float() / 0.7
+    dx = F.conv_transpose2d(dy, wt, padding=2, dilation=2) + add0
+    ref = torch.where(mask_src > 0, dx * sc2.view(1, -1, 1, 1) * drop2.view(n, cin, 1, 1), torch.zeros(())) + add1
+    wd = w_dgrad_layout(wt).to(D, dtype)
+    out = torch.empty((n, h, w, cin), device=D, dtype=dtype)
+    ops.conv2d_dgrad(spec, nhwc(dy).to(D, dtype), wd, (h, w), add0=nhwc(add0).to(D, dtype), mask_src=nhwc(mask_src).to(D, dtype),
+                     bn_scale=sc2.to(D), drop=drop2.to(D), add1=nhwc(add1).to(D, dtype), out=out)
+    assert rel_err(out.float().cpu(), nhwc(ref)) < tol
+
+
+def test_conv_full_size_tile_properties():
+    """BASELINE-size layer (b7 3x3 d4 at 28x28, bs=4) checked through linearity and a sampled oracle."""
+    from pistoseg_amd import ops
+
+    D = dev()
+    n, h, w, cin, cout = 4, 28, 28, 1024, 2048
+    g = torch.Generator().manual_seed(11)
+    x1, x2 = torch.randn(n, h, w, cin, generator=g), torch.randn(n, h, w, cin, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.01
+    spec = ops.ConvSpec(cin, cout, 3, 1, 4)
+    wf = w_fwd_layout(wt).to(D)
+
+    def run(x):
+        y = torch.empty((n, h, w, cout), device=D)
+        ops.conv2d_fwd(spec, x.to(D), wf, out_raw=y)
+        return y
+
+    y1, y2, y12 = run(x1), run(x2), run(x1 + 2 * x2)
+    assert rel_err(y12.cpu(), (y1 + 2 * y2).cpu()) < 1e-5  # linearity
+    ref = F.conv2d(x1[:1].permute(0, 3, 1, 2), wt, padding=4, dilation=4)  # one image on the CPU
+    assert rel_err(y1[:1].cpu(), nhwc(ref)) < F32_TOL
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv1a_and_fc8(dtype):
+    from pistoseg_amd import ops
+
+    D = dev()
+    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    g = torch.Generator().manual_seed(3)
+    n, h, w = 2, 17, 20
+    x = torch.randn(n, 3, h, w, generator=g)
+    wt = torch.randn(64, 3, 3, 3, generator=g) * 0.2
+    scale, shift = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    y = F.conv2d(x, wt, padding=1)
+    act = F.relu(y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    out_act = torch.empty((n, h, w, 64), device=D, dtype=dtype)
+    out_raw = torch.empty((n, h, w, 64), device=D, dtype=dtype)
+    ops.conv1a_fwd(x.to(D), wt.to(D), scale.to(D), shift.to(D), out_act, out_raw)
+    assert rel_err(out_raw.float().cpu(), nhwc(y)) < tol
+    assert rel_err(out_act.float().cpu(), nhwc(act)) < tol
+
+    # fc8 forward / backward
+    k, c, gsz = 4096, 4, 5
+    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    feat = q(F.relu(torch.randn(n, k, gsz, gsz, generator=g)))
+    w8 = torch.randn(c, k, generator=g) * 0.02
+    drop = (torch.rand(n, k, generator=g) > 0.5).float() * 2
+    s7 = torch.rand(k, generator=g) + 0.5
+    feat.requires_grad_(True)
+    w8.requires_grad_(True)
+    cam = F.conv2d(feat * drop.view(n, k, 1, 1), w8.view(c, k, 1, 1))
+    dcam = torch.randn(cam.shape, generator=g)
+    cam.backward(dcam)
+    fd = nhwc(feat.detach()).to(D, dtype)
+    camd = torch.empty((n, gsz, gsz, c), device=D)
+    ops.fc8_fwd(fd, w8.detach().to(D), drop.to(D), camd)
+    assert rel_err(camd.cpu(), nhwc(cam.detach())) < tol
+    dx = torch.empty_like(fd)
+    dw = torch.zeros((c, k), device=D)
+    ops.fc8_bwd(fd, w8.detach().to(D), drop.to(D), s7.to(D), nhwc(dcam).to(D), dx, dw)
+    ref_dx = feat.grad * (feat.detach() > 0) * s7.view(1, -1, 1, 1)
+    assert rel_err(dx.float().cpu(), nhwc(ref_dx)) < tol
+    assert rel_err(dw.cpu(), w8.grad) < tol
+
+
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("sizes", [((28, 28), (224, 224)), ((32, 32), (28, 28)), ((7, 9), (40, 33)), ((224, 224), (32, 32)), ((256, 256), (32, 32)), ((5, 5), (5, 5))])
+def test_bilinear_fwd_bwd(sizes, align):
+    from pistoseg_amd import ops
+
+    D = dev()
+    (hi, wi), (ho, wo) = sizes
+    g = torch.Generator().manual_seed(hi * 131 + ho)
+    x = torch.randn(2, 5, hi, wi, generator=g, requires_grad=True)
+    y = F.interpolate(x, (ho, wo), mode="bilinear", align_corners=align)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    # channels-last f32 source -> NCHW destination (the cam upsample) ...
+    src = nhwc(x.detach()).to(D)
+    dst = torch.empty((2, 5, ho, wo), device=D)
+    ops.bilinear_fwd(src, "nhwc", dst, "nchw", align)
+    assert rel_err(dst.cpu(), y.detach()) < 1e-5
+    # ... and NCHW -> channels-last bf16 slice (the x_s feature of the affinity head)
+    wide = torch.zeros((2, ho, wo, 16), device=D, dtype=torch.bfloat16)
+    ops.bilinear_fwd(x.detach().to(D), "nchw", wide[..., 8:13], "nhwc", align)
+    assert rel_err(wide[..., 8:13].float().cpu(), nhwc(y.detach())) < 1e-2
+    dsrc = torch.full((2, hi, wi, 5), float("nan"), device=D)
+    ops.bilinear_bwd(gy.to(D), "nchw", dsrc, "nhwc", align)
+    assert rel_err(dsrc.cpu(), nhwc(x.grad)) < 1e-5
+
+
+@pytest.mark.parametrize("ignore", [3, None])
+def test_softmax_ce(ignore):
+    from pistoseg_amd import ops
+
+    D = dev()
+    g = torch.Generator().manual_seed(9)
+    c = 3 if ignore == 3 else 4
+    logits = (torch.randn(3, c, 37, 41, generator=g) * 3).requires_grad_(True)
+    tgt = torch.randint(0, 4, (3, 37, 41), generator=g)
+    ce = F.cross_entropy(logits, tgt, reduction="none", **({"ignore_index": ignore} if ignore is not None else {}))
+    loss = ce.mean()
+    loss.backward()
+    l, dl = ops.softmax_ce(logits.detach().to(D), tgt.to(D), ignore, want_grad=True)
+    assert abs(float(l) - float(loss)) <= 1e-5 * abs(float(loss))
+    assert rel_err(dl.cpu(), logits.grad) < 1e-5
+    if ignore is not None:
+        assert float(dl.cpu().permute(0, 2, 3, 1)[tgt == ignore].abs().max()) == 0.0
+
+
+def test_argmax_modes_match_oracle(golden_dir):
+    """Mask indices are bit-exact against the oracle / reference goldens on identical inputs."""
+    from oracle import ref_cpu
+    from pistoseg_amd import _lib, ops
+
+    D = dev()
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(3, 5, 64, 48, generator=g)
+    x[0, 1] = x[0, 2]  # ties: first maximum must win
+    # loss.py:57-60
+    for probs in (False, True):
+        ref = ref_cpu.logits_to_mask(x, probs=probs)
+        got = ops.argmax_mask(x.to(D), mode=_lib.PS_MASK_PLAIN, softmax_first=not probs).cpu()
+        assert torch.equal(ref, got)
+    xn = x.clone()
+    xn[1, 3, 5, 5] = float("nan")  # torch.argmax treats NaN as the maximum
+    assert torch.equal(torch.argmax(xn, dim=1).byte(), ops.argmax_mask(xn.to(D), mode=_lib.PS_MASK_PLAIN).cpu())
+    # infer_revise_masks.py:137-143
+    label = torch.tensor([[1, 1, 0, 1, 1], [1, 0, 1, 1, 0], [1, 1, 1, 1, 1]], dtype=torch.float32)
+    ref = torch.argmax((x * label.view(3, 5, 1, 1))[:, 1:], dim=1)
+    got = ops.argmax_mask(x.to(D), mode=_lib.PS_MASK_MUL, first_ch=1, label=label.to(D)).cpu()
+    assert torch.equal(ref.to(torch.uint8), got)
+    # infer_pseudo_masks.py:69-87 against the reference's own goldens
+    gm = np.load(os.path.join(golden_dir, "mask_reduce.npz"))
+    for i in range(5):
+        logit = torch.from_numpy(gm[f"c{i}.logit"])[None]
+        lab = torch.from_numpy(gm[f"c{i}.label"]).float()[None]
+        tissue = torch.from_numpy((gm[f"c{i}.tissue"] != 0).astype(np.uint8))[None]
+        m, e = ops.argmax_mask(logit.to(D), mode=_lib.PS_MASK_FILL, label=lab.to(D), tissue=tissue.to(D), want_entropy=True)
+        assert np.array_equal(m.cpu().numpy()[0].astype(np.int64), gm[f"c{i}.mask"])
+        np.testing.assert_allclose(e.cpu().numpy()[0], gm[f"c{i}.entropy"], rtol=1e-4, atol=1e-6)
+
+
+def test_confusion_matches_golden(golden_dir):
+    from pistoseg_amd import _lib, ops
+
+    D = dev()
+    g = np.load(os.path.join(golden_dir, "miou.npz"))
+    logits = torch.from_numpy(g["logits"]).to(D)
+    pred = ops.argmax_mask(logits, mode=_lib.PS_MASK_PLAIN, softmax_first=True)
+    cm = torch.zeros(9, dtype=torch.int64, device=D)
+    ops.confusion_accum(pred, torch.from_numpy(g["gt"]).to(D), cm, 3)
+    ops.confusion_accum(pred, torch.from_numpy(g["gt"]).to(D), cm, 3)
+    assert np.array_equal(cm.cpu().numpy().reshape(3, 3), 2 * g["cm"].astype(np.int64))
+
+
+def test_optimizers_match_torch():
+    from pistoseg_amd import ops
+
+    D = dev()
+    g = torch.Generator().manual_seed(2)
+    n = 100_003
+    p0 = torch.randn(n, generator=g)
+    # AdamW (segmentation_module.py:86-90)
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pt], lr=1e-3, weight_decay=0.05)
+    p, m, v = p0.clone().to(D), torch.zeros(n, device=D), torch.zeros(n, device=D)
+    pb = torch.empty(n, device=D, dtype=torch.bfloat16)
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g)
+        pt.grad = gr.clone()
+        opt.step()
+        ops.adamw_step(p, gr.to(D), m, v, pb, 1e-3, (0.9, 0.999), 1e-8, 0.05, step)
+    assert rel_err(p.cpu(), pt.detach()) < 1e-6
+    assert torch.equal(pb.cpu(), p.cpu().bfloat16())
+    # SGD with momentum + L2 (utils.PolyOptimizer's effective update)
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([pt], lr=0.01, momentum=5e-4, weight_decay=5e-4)
+    p, buf = p0.clone().to(D), torch.zeros(n, device=D)
+    for step in range(3):
+        gr = torch.randn(n, generator=g)
+        pt.grad = gr.clone()
+        opt.step()
+        ops.sgd_step(p, gr.to(D), buf, None, 0.01, 5e-4, 5e-4, step == 0)
+    assert rel_err(p.cpu(), pt.detach()) < 1e-6
