@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""Headline benchmark: 224x224 tiles/s of the ResNet38-d segmentation hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1]): SegmentationModule-style training step -- ResNet38-d backbone + fc8 +
+bilinear upsample, per-pixel CE (ignore_index=3, mean over all pixels), backward, AdamW -- on bs=64
+synthetic 224x224x3 tiles per GPU, 3 classes, bf16 storage / f32 accumulate, random-init weights.
+A step is one full optimisation step over one batch; inputs are resident in HBM before the timed region.
+Tile batches shard across ranks (weak scaling); gradients are all-reduced over RCCL in buckets overlapped
+with the backward.  `value` = tiles/s of the whole job for TRAINING; inference tiles/s of the same model is
+reported beside it (`infer_value`).
+
+One JSON line is printed by rank 0; besides the driver contract it carries
+  roofline     : the dominant kernel's achieved TFLOP/s = algorithmic conv FLOPs per launch / HIP-event launch
+                 duration (measured live, one instrumented step after the timed region), vs the dense bf16
+                 MFMA peak of gfx950 (2.5 PFLOP/s).
+  cpu_baseline : the CPU oracle (torch fp32 restatement of the reference path) timed on the host cores on a
+                 bounded sample of the same step (rank 0, N == 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_FWD_PER_TILE = 199.93   # SURVEY.md 8(d) / BASELINE.md 2: conv FLOPs, 2*MACs, per 224x224 tile (RFM net)
+GFLOP_TRAIN_PER_TILE = 556.28  # fwd + dgrad + wgrad, frozen conv1a/b2* skipped
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # /opt/skills/guides/MI355X_MICROARCH.md, dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="tiles per GPU per step")
+    ap.add_argument("--tile", type=int, default=224)
+    ap.add_argument("--classes", type=int, default=3)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-infer", action="store_true")
+    ap.add_argument("--cpu-tiles", type=int, default=2)
+    return ap.parse_args()
+
+
+def timed(fn, steps, dist_on):
+    if dist_on:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if dist_on:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def roofline_leg(run_step, precision):
+    """One instrumented step: HIP events around every conv launch on the launch stream."""
+    from pistoseg_amd import ops
+
+    ops.PROFILE = []
+    run_step()
+    torch.cuda.synchronize()
+    prof, ops.PROFILE = ops.PROFILE, None
+    per = {}
+    for label, flops, e0, e1 in prof:
+        d = per.setdefault(label, {"launches": 0, "flops": 0.0, "ms": 0.0})
+        d["launches"] += 1
+        d["flops"] += flops
+        d["ms"] += e0.elapsed_time(e1)
+    dom = max(per.items(), key=lambda kv: kv[1]["ms"])
+    name, d = dom
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    peak = MFMA_PEAK_TFLOPS[precision]
+    kernels = {k: {"launches": v["launches"], "avg_us": round(1e3 * v["ms"] / v["launches"], 1),
+                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in per.items()}
+    return {
+        "bound": "mfma", "kernel": name, "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4), "traffic": None,
+        "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 1),
+        "flops_per_launch_avg": d["flops"] / d["launches"], "all_conv_kernels": kernels,
+    }
+
+
+def cpu_baseline(tiles, tile, classes):
+    """The CPU oracle's training step (fwd + CE + bwd + AdamW) on a bounded sample; oracle = checker, timed beside."""
+    from oracle import ref_cpu
+
+    threads = torch.get_num_threads()
+    sd = ref_cpu.make_state_dict(classes, False, seed=42)
+    tk = ref_cpu.trainable_keys(sd)
+    params = [sd[k].requires_grad_(True) for k in tk]
+    opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=0.05)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(tiles, 3, tile, tile, generator=g)
+    y = torch.randint(0, classes + 1, (tiles, tile, tile), generator=g)
+    t0 = time.perf_counter()
+    loss = ref_cpu.seg_ce_loss(ref_cpu.seg_forward(sd, x), y, 3)
+    loss.backward()
+    opt.step()
+    dt = time.perf_counter() - t0
+    with torch.no_grad():
+        t1 = time.perf_counter()
+        ref_cpu.seg_forward(sd, x)
+        dti = time.perf_counter() - t1
+    return {"value": round(tiles / dt, 4), "unit": "tiles/s", "cores": threads, "kind": "port",
+            "sample": f"1 un-warmed training step (fwd+CE+bwd+AdamW) on {tiles} synthetic {tile}x{tile} tiles, torch CPU fp32",
+            "infer_value": round(tiles / dti, 4)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if args.gpus != world and rank == 0 and dist_on:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__
+
+    if rank == 0:
+        __graft_entry__.build()
+    if dist_on:
+        torch.distributed.barrier()
+    from pistoseg_amd.seg_model import ResNet38dSeg
+    from pistoseg_amd.trainer import SegTrainer, init_weights_he
+
+    dev = torch.device("cuda", local_rank)
+    model = ResNet38dSeg(classes=args.classes, precision=args.precision)
+    init_weights_he(model, seed=42)
+    model = model.to(dev)
+    trainer = SegTrainer(model, lr=1e-3, weight_decay=0.05, ignore_index=3,
+                         process_group=torch.distributed.group.WORLD if dist_on else None)
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    x = torch.randn(args.batch, 3, args.tile, args.tile, generator=g).to(dev)
+    y = torch.randint(0, args.classes + 1, (args.batch, args.tile, args.tile), generator=g).to(dev)
+
+    def train_step():
+        trainer.train_step(x, y)
+
+    for _ in range(args.warmup):
+        train_step()
+    dt = timed(train_step, args.steps, dist_on)
+    tiles = world * args.batch * args.steps
+    value = tiles / dt
+    ms = 1e3 * dt / args.steps
+
+    out = {
+        "metric": "224x224 tiles/sec (train fwd+bwd+opt)", "value": round(value, 2), "unit": "tiles/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: segmentation_train.py step, ResNet38-d seg model, 3-class CE(ignore=3), AdamW, random-init",
+                   "per_gpu_batch": args.batch, "global_batch": args.batch * world, "tile": args.tile, "parallelism": f"dp{world}"},
+        "train_conv_tflops_per_gpu": round(value / world * GFLOP_TRAIN_PER_TILE * (args.tile / 224.0) ** 2 / 1e3, 1),
+    }
+
+    if not args.no_infer:
+        model.eval()
+
+        def infer_step():
+            with torch.no_grad():
+                model(x)
+
+        for _ in range(max(1, args.warmup)):
+            infer_step()
+        dti = timed(infer_step, args.steps, dist_on)
+        out["infer_value"] = round(tiles / dti, 2)
+        out["infer_ms_per_step"] = round(1e3 * dti / args.steps, 3)
+        model.train()
+
+    if rank == 0:
+        out["roofline"] = roofline_leg(train_step, args.precision)
+    else:
+        train_step()  # keep ranks in lockstep through the instrumented step (it contains collectives)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_tiles, args.tile, args.classes)
+    if dist_on:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -175,7 +175,7 @@ def _drop(x: Tensor, mask: Optional[Tensor]) -> Tensor:
     return x * mask.view(mask.shape[0], mask.shape[1], 1, 1)
 
 
-def _res_unit(sd, name, cin, cmid, cout, stride, fdil, dil, x):
+def _res_unit(sd, name, cin, cmid, cout, stride, fdil, dil, x, collect=None):
     """ResBlock.forward, resnet38d.py:26-48.  The 1x1 shortcut is applied to the *activated*
     input when the shape changes; otherwise the raw input is the identity shortcut."""
     a = _bn_relu(sd, f"{name}.bn_branch2a", x)
@@ -185,34 +185,39 @@ def _res_unit(sd, name, cin, cmid, cout, stride, fdil, dil, x):
         shortcut = F.conv2d(a, sd[f"{name}.conv_branch1.weight"], stride=stride)
     h = F.conv2d(a, sd[f"{name}.conv_branch2a.weight"], stride=stride, padding=fdil, dilation=fdil)
     h = _bn_relu(sd, f"{name}.bn_branch2b1", h)
+    if collect is not None:
+        collect[name] = (a, h)
     h = F.conv2d(h, sd[f"{name}.conv_branch2b1.weight"], padding=dil, dilation=dil)
     return shortcut + h, a
 
 
-def _bot_unit(sd, name, cin, cout, stride, dil, x, drop1, drop2):
+def _bot_unit(sd, name, cin, cout, stride, dil, x, drop1, drop2, collect=None):
     """ResBlock_bot.forward, resnet38d.py:73-98 (shortcut conv always present)."""
     a = _bn_relu(sd, f"{name}.bn_branch2a", x)
     shortcut = F.conv2d(a, sd[f"{name}.conv_branch1.weight"], stride=stride)
     h = F.conv2d(a, sd[f"{name}.conv_branch2a.weight"], stride=stride)
-    h = _drop(_bn_relu(sd, f"{name}.bn_branch2b1", h), drop1)
-    h = F.conv2d(h, sd[f"{name}.conv_branch2b1.weight"], padding=dil, dilation=dil)
-    h = _drop(_bn_relu(sd, f"{name}.bn_branch2b2", h), drop2)
-    h = F.conv2d(h, sd[f"{name}.conv_branch2b2.weight"])
+    h1 = _drop(_bn_relu(sd, f"{name}.bn_branch2b1", h), drop1)
+    h = F.conv2d(h1, sd[f"{name}.conv_branch2b1.weight"], padding=dil, dilation=dil)
+    h2 = _drop(_bn_relu(sd, f"{name}.bn_branch2b2", h), drop2)
+    if collect is not None:
+        collect[name] = (a, h1, h2)
+    h = F.conv2d(h2, sd[f"{name}.conv_branch2b2.weight"])
     return shortcut + h, a
 
 
-def forward_as_dict(sd: Dict[str, Tensor], x: Tensor, drop: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
+def forward_as_dict(sd: Dict[str, Tensor], x: Tensor, drop: Optional[Dict[str, Tensor]] = None, collect=None) -> Dict[str, Tensor]:
     """Net.forward_as_dict, resnet38d.py:159-188.  `drop` maps
-    {'b6.dropout_2b1','b6.dropout_2b2','b7.dropout_2b1','b7.dropout_2b2'} -> [N, C] multipliers."""
+    {'b6.dropout_2b1','b6.dropout_2b2','b7.dropout_2b1','b7.dropout_2b2'} -> [N, C] multipliers.
+    `collect` (optional dict) receives every unit's post-ReLU activations (for ReLU-pattern checks in tests)."""
     drop = drop or {}
     out: Dict[str, Tensor] = {}
     x = F.conv2d(x, sd["conv1a.weight"], padding=1)
     for name, kind, cin, cmid, cout, stride, fdil, dil, _p in BLOCKS:
         if kind == "res":
-            x, a = _res_unit(sd, name, cin, cmid, cout, stride, fdil, dil, x)
+            x, a = _res_unit(sd, name, cin, cmid, cout, stride, fdil, dil, x, collect)
         else:
             x, a = _bot_unit(
-                sd, name, cin, cout, stride, dil, x, drop.get(f"{name}.dropout_2b1"), drop.get(f"{name}.dropout_2b2")
+                sd, name, cin, cout, stride, dil, x, drop.get(f"{name}.dropout_2b1"), drop.get(f"{name}.dropout_2b2"), collect
             )
         if name in TAPS:
             out[TAPS[name]] = a
@@ -224,13 +229,15 @@ def bilinear(x: Tensor, size: Tuple[int, int], align_corners: bool) -> Tensor:
     return F.interpolate(x, size, mode="bilinear", align_corners=align_corners)
 
 
-def seg_forward(sd: Dict[str, Tensor], x: Tensor, drop: Optional[Dict[str, Tensor]] = None) -> Tensor:
+def seg_forward(sd: Dict[str, Tensor], x: Tensor, drop: Optional[Dict[str, Tensor]] = None, collect=None) -> Tensor:
     """The build's "ResNet38-d segmentation model" (SURVEY 0.2): the `cam` branch of
     revise_net.Net.forward -- fc8 1x1 conv on dropout7(conv6), bilinear align_corners=True
     upsample to the input size (revise_net.py:50,86).  Equals outputs[0] of revise_forward."""
     drop = drop or {}
     H, W = x.shape[-2:]
-    conv6 = forward_as_dict(sd, x, drop)["conv6"]
+    conv6 = forward_as_dict(sd, x, drop, collect)["conv6"]
+    if collect is not None:
+        collect["conv6"] = (conv6,)
     cam = F.conv2d(_drop(conv6, drop.get("dropout7")), sd["fc8.weight"])
     return bilinear(cam, (H, W), True)
 

@@ -9,6 +9,11 @@ import ctypes as C
 import os
 from typing import Optional
 
+# torch bundles its own HIP runtime (torch/lib/libamdhip64.so).  It must be in the process BEFORE our library
+# is dlopen'ed, so that both resolve to ONE runtime (streams and device pointers are shared between them);
+# loading ours first would pull in /opt/rocm's copy and every launch would fail with hipErrorNoDevice.
+import torch  # noqa: F401  (side effect: loads the HIP runtime torch uses)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpistoseg_hip.so")
 

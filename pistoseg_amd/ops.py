@@ -18,6 +18,32 @@ from ._lib import PS_BF16, PS_EPI_BNRELU, PS_EPI_NONE, PS_EPI_RELUBWD, PS_F32, C
 Tensor = torch.Tensor
 
 
+# Optional per-launch timing of the conv kernels (bench.py's roofline leg): when PROFILE is a list, every conv
+# launch is bracketed by HIP events on the current stream and appended as (kernel label, flops, start, end).
+PROFILE = None
+
+
+def _conv_label(kind: str, dtype: int, m: int, cd: int) -> str:
+    """Mirrors dispatch_bn() in csrc/conv_igemm.hip: which instantiation serves this launch."""
+    dt = "bf16" if dtype == PS_BF16 else "f32"
+    if kind == "wgrad":
+        return f"conv_wgrad_kernel<{dt}>"
+    ntm = (m + 127) // 128
+    bn = 128 if (cd % 128 == 0 and ntm * (cd // 128) >= 512) else 64
+    return f"conv_igemm_kernel<{dt},BN={bn}>"
+
+
+def _launch(label: str, flops: float, fn):
+    if PROFILE is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    PROFILE.append((label, flops, e0, e1))
+    return r
+
+
 def _dt(t_or_dtype) -> int:
     d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
     if d == torch.float32:
@@ -95,7 +121,10 @@ def conv2d_fwd(spec: ConvSpec, x: Tensor, w_fwd: Tensor, *, add0=None, out_raw=N
     g = _geom(spec, _dt(x), n, h, w, _ldc(x), _ldc(ref))
     e = _epilogue(mode, add0=add0, out_raw=out_raw, scale=bn_scale, shift=bn_shift, drop=drop, out=out_act)
     lib = _lib.load()
-    _lib.check(lib.ps_conv2d_fwd(C.byref(g), x.data_ptr(), w_fwd.data_ptr(), C.byref(e), _stream()), "ps_conv2d_fwd")
+    ho, wo = spec.out_hw(h, w)
+    m = n * ho * wo
+    _launch(_conv_label("fwd", g.dtype, m, spec.cout), 2.0 * m * spec.cout * spec.cin * spec.ksize**2,
+            lambda: _lib.check(lib.ps_conv2d_fwd(C.byref(g), x.data_ptr(), w_fwd.data_ptr(), C.byref(e), _stream()), "ps_conv2d_fwd"))
 
 
 def conv2d_dgrad(spec: ConvSpec, dy: Tensor, w_dgrad: Tensor, x_hw, *, add0=None, out_raw=None, mask_src=None, bn_scale=None,
@@ -110,7 +139,9 @@ def conv2d_dgrad(spec: ConvSpec, dy: Tensor, w_dgrad: Tensor, x_hw, *, add0=None
     g = _geom(spec, _dt(dy), n, h, w, _ldc(ref), _ldc(dy))
     e = _epilogue(mode, add0=add0, out_raw=out_raw, scale=bn_scale, drop=drop, mask_src=mask_src, add1=add1, out=out)
     lib = _lib.load()
-    _lib.check(lib.ps_conv2d_dgrad(C.byref(g), dy.data_ptr(), w_dgrad.data_ptr(), C.byref(e), _stream()), "ps_conv2d_dgrad")
+    mo = n * dy.shape[1] * dy.shape[2]
+    _launch(_conv_label("dgrad", g.dtype, n * h * w, spec.cin), 2.0 * mo * spec.cout * spec.cin * spec.ksize**2,
+            lambda: _lib.check(lib.ps_conv2d_dgrad(C.byref(g), dy.data_ptr(), w_dgrad.data_ptr(), C.byref(e), _stream()), "ps_conv2d_dgrad"))
 
 
 def conv2d_wgrad(spec: ConvSpec, x: Tensor, dy: Tensor, dw: Tensor) -> None:
@@ -121,7 +152,9 @@ def conv2d_wgrad(spec: ConvSpec, x: Tensor, dy: Tensor, dw: Tensor) -> None:
     assert dw.numel() == spec.cout * spec.cin * spec.ksize**2
     g = _geom(spec, _dt(x), n, h, w, _ldc(x), _ldc(dy))
     lib = _lib.load()
-    _lib.check(lib.ps_conv2d_wgrad(C.byref(g), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _stream()), "ps_conv2d_wgrad")
+    mo = n * dy.shape[1] * dy.shape[2]
+    _launch(_conv_label("wgrad", g.dtype, mo, spec.cout), 2.0 * mo * spec.cout * spec.cin * spec.ksize**2,
+            lambda: _lib.check(lib.ps_conv2d_wgrad(C.byref(g), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _stream()), "ps_conv2d_wgrad"))
 
 
 def weight_transpose(src: Tensor, dst: Tensor, cout: int, taps: int, cin: int) -> None:

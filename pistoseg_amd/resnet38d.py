@@ -1,0 +1,404 @@
+"""ResNet38-d backbone on MI355X -- host-side mirror of the reference's `models/resnet38d.py`.
+
+Same module tree / state-dict keys (`b{2..7}[_k].{bn_branch2a,conv_branch2a,bn_branch2b1,conv_branch2b1,
+[bn_branch2b2,conv_branch2b2],[conv_branch1]}.*`, `conv1a.weight`, `bn7.*`), same `forward` /
+`forward_as_dict` / `train()` behaviour (reference: models/resnet38d.py:119-213), but the nn.Conv2d /
+nn.BatchNorm2d children are *parameter holders only*: the arithmetic runs as a fixed plan of fused HIP
+launches (pistoseg_amd/ops.py -> libpistoseg_hip.so):
+
+  * activations are channels-last [N,H,W,C] in the compute dtype (bf16, or f32 for the parity path);
+  * every conv writes, from its epilogue, the NEXT BatchNorm+ReLU(+Dropout2d) already applied, plus the raw
+    residual stream only where an identity shortcut will read it (pre-activation net: BN/ReLU are
+    frozen per-channel affines, resnet38d.py:206-211);
+  * backward is an explicit reverse plan (dgrad with the ReLU/BN mask fused, wgrad into f32) -- see
+    `backward_backbone`.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import ops
+from .ops import ConvSpec
+
+Tensor = torch.Tensor
+BN_EPS = 1e-5
+
+# name, kind, cin, cmid, cout, stride, first_dilation, dilation, dropout  (models/resnet38d.py:125-146)
+UNITS = [
+    ("b2", "res", 64, 128, 128, 2, 1, 1, 0.0),
+    ("b2_1", "res", 128, 128, 128, 1, 1, 1, 0.0),
+    ("b2_2", "res", 128, 128, 128, 1, 1, 1, 0.0),
+    ("b3", "res", 128, 256, 256, 2, 1, 1, 0.0),
+    ("b3_1", "res", 256, 256, 256, 1, 1, 1, 0.0),
+    ("b3_2", "res", 256, 256, 256, 1, 1, 1, 0.0),
+    ("b4", "res", 256, 512, 512, 2, 1, 1, 0.0),
+    ("b4_1", "res", 512, 512, 512, 1, 1, 1, 0.0),
+    ("b4_2", "res", 512, 512, 512, 1, 1, 1, 0.0),
+    ("b4_3", "res", 512, 512, 512, 1, 1, 1, 0.0),
+    ("b4_4", "res", 512, 512, 512, 1, 1, 1, 0.0),
+    ("b4_5", "res", 512, 512, 512, 1, 1, 1, 0.0),
+    ("b5", "res", 512, 512, 1024, 1, 1, 2, 0.0),
+    ("b5_1", "res", 1024, 512, 1024, 1, 2, 2, 0.0),
+    ("b5_2", "res", 1024, 512, 1024, 1, 2, 2, 0.0),
+    ("b6", "bot", 1024, 512, 2048, 1, 4, 4, 0.3),
+    ("b7", "bot", 2048, 1024, 4096, 1, 4, 4, 0.5),
+]
+TAP_OF_UNIT = {"b4": "conv3", "b5": "conv4", "b6": "conv5"}  # x_bn_relu taps, resnet38d.py:172,180,184
+
+
+def _channels_last_(conv: nn.Conv2d) -> None:
+    """Store an OIHW weight as [cout][kh][kw][cin] (torch.channels_last) -- the kernels' W_fwd layout."""
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+
+
+class ResBlock(nn.Module):
+    """Parameter holder for models/resnet38d.py:6-51."""
+
+    def __init__(self, cin, cmid, cout, stride=1, first_dilation=None, dilation=1):
+        super().__init__()
+        self.same_shape = cin == cout and stride == 1
+        first_dilation = dilation if first_dilation is None else first_dilation
+        self.bn_branch2a = nn.BatchNorm2d(cin)
+        self.conv_branch2a = nn.Conv2d(cin, cmid, 3, stride, padding=first_dilation, dilation=first_dilation, bias=False)
+        self.bn_branch2b1 = nn.BatchNorm2d(cmid)
+        self.conv_branch2b1 = nn.Conv2d(cmid, cout, 3, padding=dilation, dilation=dilation, bias=False)
+        if not self.same_shape:
+            self.conv_branch1 = nn.Conv2d(cin, cout, 1, stride, bias=False)
+
+
+class ResBlock_bot(nn.Module):
+    """Parameter holder for models/resnet38d.py:53-101."""
+
+    def __init__(self, cin, cout, stride=1, dilation=1, dropout=0.0):
+        super().__init__()
+        self.same_shape = cin == cout and stride == 1
+        self.bn_branch2a = nn.BatchNorm2d(cin)
+        self.conv_branch2a = nn.Conv2d(cin, cout // 4, 1, stride, bias=False)
+        self.bn_branch2b1 = nn.BatchNorm2d(cout // 4)
+        self.dropout_2b1 = nn.Dropout2d(dropout)
+        self.conv_branch2b1 = nn.Conv2d(cout // 4, cout // 2, 3, padding=dilation, dilation=dilation, bias=False)
+        self.bn_branch2b2 = nn.BatchNorm2d(cout // 2)
+        self.dropout_2b2 = nn.Dropout2d(dropout)
+        self.conv_branch2b2 = nn.Conv2d(cout // 2, cout, 1, bias=False)
+        self.conv_branch1 = nn.Conv2d(cin, cout, 1, stride, bias=False)
+
+
+class _Saved:
+    """Activations kept by a training forward for `backward_backbone` (channels-last, compute dtype)."""
+
+    def __init__(self):
+        self.unit_in: Dict[str, Tensor] = {}   # activated input a of each unit
+        self.mid: Dict[str, Tuple[Tensor, ...]] = {}  # a2 (, a3)
+        self.drop: Dict[str, Optional[Tensor]] = {}
+        self.hw: Dict[str, Tuple[int, int]] = {}  # input spatial size of each unit
+        self.conv6: Optional[Tensor] = None
+        self.n = 0
+
+
+class Net(nn.Module):
+    """Drop-in for the reference's `models.resnet38d.Net` (same constructor, keys and methods)."""
+
+    def __init__(self, precision: str = "bf16"):
+        super().__init__()
+        assert precision in ("bf16", "fp32")
+        self.precision = precision
+        self.conv1a = nn.Conv2d(3, 64, 3, padding=1, bias=False)
+        for name, kind, cin, cmid, cout, stride, fdil, dil, p in UNITS:
+            if kind == "res":
+                unit = ResBlock(cin, cmid, cout, stride=stride, first_dilation=fdil, dilation=dil)
+            else:
+                unit = ResBlock_bot(cin, cout, stride=stride, dilation=dil, dropout=p)
+            self.add_module(name, unit)
+        self.bn7 = nn.BatchNorm2d(4096)
+        self.not_training = [self.conv1a]
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d) and m is not self.conv1a:
+                _channels_last_(m)
+        self._cache: Dict[str, Tuple] = {}
+        self._weights_epoch = 0           # bumped by code that rewrites parameter memory behind torch's back
+        self._bf16_shadow: Dict[str, Tensor] = {}  # param name -> bf16 W_fwd view kept fresh by the fused optimiser
+        self.train(True)  # apply the freezing rules from the start (the reference's scripts always call train())
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, x):
+        return self.forward_as_dict(x)["conv6"]
+
+    def forward_as_dict(self, x):
+        """NCHW f32 feature dict {conv3, conv4, conv5, conv6} (resnet38d.py:159-188)."""
+        feats, _ = self.run_backbone(x, save=False, drop=self.sample_dropout(x.shape[0], x.device) if self.training else None)
+        return {k: v.permute(0, 3, 1, 2).float() for k, v in feats.items()}
+
+    def train(self, mode=True):
+        """Quirk kept from resnet38d.py:191-213: freezes `not_training` layers and every BatchNorm (which
+        always runs in eval mode), and returns None."""
+        super().train(mode)
+        for layer in self.not_training:
+            if isinstance(layer, nn.Conv2d):
+                layer.weight.requires_grad = False
+            elif isinstance(layer, nn.Module):
+                for c in layer.children():
+                    if getattr(c, "weight", None) is not None:
+                        c.weight.requires_grad = False
+                    if getattr(c, "bias", None) is not None:
+                        c.bias.requires_grad = False
+        for layer in self.modules():
+            if isinstance(layer, nn.BatchNorm2d):
+                layer.eval()
+                layer.bias.requires_grad = False
+                layer.weight.requires_grad = False
+        return
+
+    # ------------------------------------------------------------------ device-side views of the parameters
+    @property
+    def compute_dtype(self):
+        return torch.bfloat16 if self.precision == "bf16" else torch.float32
+
+    def _cached(self, key: str, deps: Tuple[Tensor, ...], make):
+        sig = tuple((t.data_ptr(), t._version) for t in deps) + (self.precision, self._weights_epoch)
+        hit = self._cache.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        val = make()
+        self._cache[key] = (sig, val)
+        return val
+
+    def w_fwd(self, conv: nn.Conv2d, key: str) -> Tensor:
+        """[cout][kh][kw][cin] in the compute dtype (the f32 parameter storage itself on the fp32 path)."""
+        w = conv.weight
+        if not w.is_contiguous(memory_format=torch.channels_last) and w.shape[2] > 1:
+            _channels_last_(conv)
+            w = conv.weight
+        flat = w.detach().permute(0, 2, 3, 1)
+        assert flat.is_contiguous()
+        if self.precision == "fp32":
+            return flat
+        shadow = self._bf16_shadow.get(key + ".weight")
+        if shadow is not None:
+            return shadow
+
+        def make():
+            out = torch.empty(flat.shape, device=w.device, dtype=torch.bfloat16)
+            ops.cast_f32_bf16(flat, out)
+            return out
+
+        return self._cached("wf:" + key, (w,), make)
+
+    def w_dgrad(self, conv: nn.Conv2d, key: str) -> Tensor:
+        """[cin][kh][kw][cout] in the compute dtype."""
+        w = conv.weight
+        cout, cin, k, _ = w.shape
+
+        def make():
+            src = self.w_fwd(conv, key)
+            out = torch.empty((cin, k, k, cout), device=w.device, dtype=self.compute_dtype)
+            ops.weight_transpose(src, out, cout, k * k, cin)
+            return out
+
+        return self._cached("wd:" + key, (w,), make)
+
+    def bn_affine(self, bn: nn.BatchNorm2d, key: str) -> Tuple[Tensor, Tensor]:
+        """Eval-mode BN as y = x*scale + shift (f32 per-channel vectors; BN is frozen on this path)."""
+
+        def make():
+            with torch.no_grad():
+                scale = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
+                shift = bn.bias.float() - bn.running_mean.float() * scale
+            return scale.contiguous(), shift.contiguous()
+
+        return self._cached("bn:" + key, (bn.weight, bn.bias, bn.running_mean, bn.running_var), make)
+
+    def sample_dropout(self, n: int, device) -> Dict[str, Tensor]:
+        """Per-(sample, channel) Dropout2d multipliers for a training forward (resnet38d.py:63,67,85,90)."""
+        out = {}
+        for name, kind, cin, cmid, cout, stride, fdil, dil, p in UNITS:
+            if kind != "bot":
+                continue
+            for tag, c in (("dropout_2b1", cout // 4), ("dropout_2b2", cout // 2)):
+                if p > 0:
+                    keep = torch.rand((n, c), device=device) >= p
+                    out[f"{name}.{tag}"] = keep.to(torch.float32) / (1.0 - p)
+        return out
+
+    def unit_specs(self, name, kind, cin, cmid, cout, stride, fdil, dil):
+        if kind == "res":
+            return {
+                "conv_branch2a": ConvSpec(cin, cmid, 3, stride, fdil),
+                "conv_branch2b1": ConvSpec(cmid, cout, 3, 1, dil),
+                "conv_branch1": ConvSpec(cin, cout, 1, stride, 1),
+            }
+        return {
+            "conv_branch2a": ConvSpec(cin, cout // 4, 1, stride, 1),
+            "conv_branch2b1": ConvSpec(cout // 4, cout // 2, 3, 1, dil),
+            "conv_branch2b2": ConvSpec(cout // 2, cout, 1, 1, 1),
+            "conv_branch1": ConvSpec(cin, cout, 1, stride, 1),
+        }
+
+    # ------------------------------------------------------------------ forward plan
+    def run_backbone(self, x: Tensor, save: bool, drop: Optional[Dict[str, Tensor]] = None):
+        """x: NCHW f32 on the GPU.  Returns ({conv3,conv4,conv5,conv6} channels-last, _Saved or None)."""
+        if not x.is_cuda:
+            raise RuntimeError("pistoseg_amd.resnet38d.Net runs on the GPU only (no CPU fallback); move the module and input to cuda")
+        x = x.contiguous().float()
+        n, _, h, w = x.shape
+        dt, dev = self.compute_dtype, x.device
+        drop = drop or {}
+        saved = _Saved() if save else None
+        feats: Dict[str, Tensor] = {}
+
+        def new(hh, ww, c):
+            return torch.empty((n, hh, ww, c), device=dev, dtype=dt)
+
+        first = getattr(self, UNITS[0][0])
+        sc0, sh0 = self.bn_affine(first.bn_branch2a, UNITS[0][0] + ".bn_branch2a")
+        a = new(h, w, 64)
+        ops.conv1a_fwd(x, self.conv1a.weight.detach().contiguous(), sc0, sh0, a)
+        xraw = None
+        for i, (name, kind, cin, cmid, cout, stride, fdil, dil, _p) in enumerate(UNITS):
+            unit = getattr(self, name)
+            specs = self.unit_specs(name, kind, cin, cmid, cout, stride, fdil, dil)
+            if i + 1 < len(UNITS):
+                nxt_name, nxt = UNITS[i + 1][0], getattr(self, UNITS[i + 1][0])
+                nscale, nshift = self.bn_affine(nxt.bn_branch2a, nxt_name + ".bn_branch2a")
+                need_raw = UNITS[i + 1][1] == "res" and nxt.same_shape
+            else:
+                nscale, nshift = self.bn_affine(self.bn7, "bn7")
+                need_raw = False
+            if name in TAP_OF_UNIT:
+                feats[TAP_OF_UNIT[name]] = a
+            ho, wo = specs["conv_branch2a"].out_hw(h, w)
+            if saved is not None:
+                saved.unit_in[name] = a
+                saved.hw[name] = (h, w)
+            same = kind == "res" and unit.same_shape
+            if same:
+                shortcut = xraw
+            else:
+                shortcut = new(ho, wo, cout)
+                ops.conv2d_fwd(specs["conv_branch1"], a, self.w_fwd(unit.conv_branch1, name + ".conv_branch1"), out_raw=shortcut)
+            a_next = new(ho, wo, cout)
+            xraw_next = new(ho, wo, cout) if need_raw else None
+            if kind == "res":
+                s1, b1 = self.bn_affine(unit.bn_branch2b1, name + ".bn_branch2b1")
+                a2 = new(ho, wo, cmid)
+                ops.conv2d_fwd(specs["conv_branch2a"], a, self.w_fwd(unit.conv_branch2a, name + ".conv_branch2a"), bn_scale=s1, bn_shift=b1, out_act=a2)
+                ops.conv2d_fwd(specs["conv_branch2b1"], a2, self.w_fwd(unit.conv_branch2b1, name + ".conv_branch2b1"), add0=shortcut,
+                               out_raw=xraw_next, bn_scale=nscale, bn_shift=nshift, out_act=a_next)
+                if saved is not None:
+                    saved.mid[name] = (a2,)
+            else:
+                d1, d2 = drop.get(f"{name}.dropout_2b1"), drop.get(f"{name}.dropout_2b2")
+                s1, b1 = self.bn_affine(unit.bn_branch2b1, name + ".bn_branch2b1")
+                s2, b2 = self.bn_affine(unit.bn_branch2b2, name + ".bn_branch2b2")
+                a2 = new(ho, wo, cout // 4)
+                ops.conv2d_fwd(specs["conv_branch2a"], a, self.w_fwd(unit.conv_branch2a, name + ".conv_branch2a"), bn_scale=s1, bn_shift=b1, drop=d1, out_act=a2)
+                a3 = new(ho, wo, cout // 2)
+                ops.conv2d_fwd(specs["conv_branch2b1"], a2, self.w_fwd(unit.conv_branch2b1, name + ".conv_branch2b1"), bn_scale=s2, bn_shift=b2, drop=d2, out_act=a3)
+                ops.conv2d_fwd(specs["conv_branch2b2"], a3, self.w_fwd(unit.conv_branch2b2, name + ".conv_branch2b2"), add0=shortcut,
+                               out_raw=xraw_next, bn_scale=nscale, bn_shift=nshift, out_act=a_next)
+                if saved is not None:
+                    saved.mid[name] = (a2, a3)
+                    saved.drop[name + ".dropout_2b1"], saved.drop[name + ".dropout_2b2"] = d1, d2
+            a, xraw, h, w = a_next, xraw_next, ho, wo
+        feats["conv6"] = a
+        if saved is not None:
+            saved.conv6 = a
+            saved.n = n
+        return feats, saved
+
+    # ------------------------------------------------------------------ backward plan
+    def first_trainable_unit(self) -> int:
+        for i, u in enumerate(UNITS):
+            unit = getattr(self, u[0])
+            if any(p.requires_grad for p in unit.parameters()):
+                return i
+        return len(UNITS)
+
+    def backward_backbone(self, saved: _Saved, g_x7: Tensor, grads: Dict[str, Tensor], g_taps: Optional[Dict[str, Tensor]] = None,
+                          after_unit=None) -> None:
+        """Reverse plan.  g_x7: gradient w.r.t. b7's raw output (the ReLU(bn7) mask already applied),
+        channels-last compute dtype.  grads: parameter name -> f32 buffer [cout][kh][kw][cin] that wgrad
+        ACCUMULATES into (caller zeroes).  g_taps: gradients w.r.t. the conv4 / conv5 taps.
+        after_unit(name): optional callback after a unit's weight gradients are complete (DDP buckets)."""
+        g_taps = g_taps or {}
+        first = self.first_trainable_unit()
+        G = g_x7
+        dt, dev, n = G.dtype, G.device, saved.n
+        for i in range(len(UNITS) - 1, -1, -1):
+            name, kind, cin, cmid, cout, stride, fdil, dil, _p = UNITS[i]
+            if i < first:
+                break
+            unit = getattr(self, name)
+            specs = self.unit_specs(name, kind, cin, cmid, cout, stride, fdil, dil)
+            a = saved.unit_in[name]
+            h, w = saved.hw[name]
+            ho, wo = specs["conv_branch2a"].out_hw(h, w)
+            need_dx = i > first
+            tap = g_taps.get(TAP_OF_UNIT.get(name, ""))
+            s_in, _ = self.bn_affine(unit.bn_branch2a, name + ".bn_branch2a")
+            same = kind == "res" and unit.same_shape
+
+            def wgrad(cname, x_act, dy):
+                p = getattr(unit, cname).weight
+                if p.requires_grad:
+                    ops.conv2d_wgrad(specs[cname], x_act, dy, grads[f"{name}.{cname}.weight"])
+
+            def new(hh, ww, c):
+                return torch.empty((n, hh, ww, c), device=dev, dtype=dt)
+
+            if kind == "res":
+                (a2,) = saved.mid[name]
+                s1, _ = self.bn_affine(unit.bn_branch2b1, name + ".bn_branch2b1")
+                wgrad("conv_branch2b1", a2, G)
+                gh = new(ho, wo, cmid)
+                ops.conv2d_dgrad(specs["conv_branch2b1"], G, self.w_dgrad(unit.conv_branch2b1, name + ".conv_branch2b1"), (ho, wo),
+                                 mask_src=a2, bn_scale=s1, out=gh)
+                wgrad("conv_branch2a", a, gh)
+                if not same:
+                    wgrad("conv_branch1", a, G)
+                if need_dx:
+                    Gp = new(h, w, cin)
+                    if same:
+                        assert tap is None
+                        ops.conv2d_dgrad(specs["conv_branch2a"], gh, self.w_dgrad(unit.conv_branch2a, name + ".conv_branch2a"), (h, w),
+                                         mask_src=a, bn_scale=s_in, add1=G, out=Gp)
+                    else:
+                        t = new(h, w, cin)
+                        ops.conv2d_dgrad(specs["conv_branch1"], G, self.w_dgrad(unit.conv_branch1, name + ".conv_branch1"), (h, w), add0=tap, out_raw=t)
+                        ops.conv2d_dgrad(specs["conv_branch2a"], gh, self.w_dgrad(unit.conv_branch2a, name + ".conv_branch2a"), (h, w),
+                                         add0=t, mask_src=a, bn_scale=s_in, out=Gp)
+                    G = Gp
+            else:
+                a2, a3 = saved.mid[name]
+                d1, d2 = saved.drop[name + ".dropout_2b1"], saved.drop[name + ".dropout_2b2"]
+                s1, _ = self.bn_affine(unit.bn_branch2b1, name + ".bn_branch2b1")
+                s2, _ = self.bn_affine(unit.bn_branch2b2, name + ".bn_branch2b2")
+                wgrad("conv_branch2b2", a3, G)
+                g3 = new(ho, wo, cout // 2)
+                ops.conv2d_dgrad(specs["conv_branch2b2"], G, self.w_dgrad(unit.conv_branch2b2, name + ".conv_branch2b2"), (ho, wo),
+                                 mask_src=a3, bn_scale=s2, drop=d2, out=g3)
+                wgrad("conv_branch2b1", a2, g3)
+                g2 = new(ho, wo, cout // 4)
+                ops.conv2d_dgrad(specs["conv_branch2b1"], g3, self.w_dgrad(unit.conv_branch2b1, name + ".conv_branch2b1"), (ho, wo),
+                                 mask_src=a2, bn_scale=s1, drop=d1, out=g2)
+                wgrad("conv_branch2a", a, g2)
+                wgrad("conv_branch1", a, G)
+                if need_dx:
+                    t = new(h, w, cin)
+                    ops.conv2d_dgrad(specs["conv_branch1"], G, self.w_dgrad(unit.conv_branch1, name + ".conv_branch1"), (h, w), add0=tap, out_raw=t)
+                    Gp = new(h, w, cin)
+                    ops.conv2d_dgrad(specs["conv_branch2a"], g2, self.w_dgrad(unit.conv_branch2a, name + ".conv_branch2a"), (h, w),
+                                     add0=t, mask_src=a, bn_scale=s_in, out=Gp)
+                    G = Gp
+            if after_unit is not None:
+                after_unit(name)
+
+    def invalidate_weight_cache(self) -> None:
+        """Call after parameter memory was rewritten by a raw-pointer kernel (fused optimiser step)."""
+        self._weights_epoch += 1
+
+    def trainable_conv_params(self) -> List[Tuple[str, nn.Parameter]]:
+        """(name, parameter) of every conv weight that currently requires grad, in state-dict order."""
+        return [(k, p) for k, p in self.named_parameters() if p.dim() == 4 and p.requires_grad]

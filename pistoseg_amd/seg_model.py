@@ -1,0 +1,111 @@
+"""The ResNet38-d segmentation model: backbone -> fc8 (4096 -> classes, 1x1) -> bilinear upsample
+(align_corners=True) to the input size.
+
+This is the `cam` branch of the reference's `revise_net.Net.forward` (models/revise_net.py:50,86), the only
+reference-defined "ResNet38-d -> per-pixel class logits" head; it plugs into
+`SegmentationModule` / `MosaicModule` at the `smp.create_model(args.model, ...)` call site
+(models/segmentation_module.py:72-81) through `create_model('ResNet38d', ...)`.  State-dict keys are the
+backbone's plus `fc8.weight`, i.e. a subset of the RFM checkpoint (revise_pseudo_labels.py:214).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from . import ops, resnet38d
+
+Tensor = torch.Tensor
+
+
+class ResNet38dSeg(resnet38d.Net):
+    def __init__(self, classes: int = 3, precision: str = "bf16"):
+        super().__init__(precision=precision)
+        self.dropout7 = nn.Dropout2d(0.5)
+        self.fc8 = nn.Conv2d(4096, classes, 1, bias=False)
+        nn.init.xavier_uniform_(self.fc8.weight)
+        self.from_scratch_layers = [self.fc8]
+        self.not_training = [self.conv1a, self.b2, self.b2_1, self.b2_2]  # revise_net.py:27
+        self.classes = classes
+        self.train(True)
+
+    def sample_dropout(self, n: int, device) -> Dict[str, Tensor]:
+        out = super().sample_dropout(n, device)
+        keep = torch.rand((n, 4096), device=device) >= 0.5
+        out["dropout7"] = keep.to(torch.float32) * 2.0
+        return out
+
+    # ------------------------------------------------------------------ head
+    def head_forward(self, conv6: Tensor, drop7: Optional[Tensor], out_hw) -> (Tensor, Tensor):
+        n, g1, g2, _ = conv6.shape
+        cam = torch.empty((n, g1, g2, self.classes), device=conv6.device, dtype=torch.float32)
+        ops.fc8_fwd(conv6, self.fc8.weight.detach().reshape(self.classes, 4096), drop7, cam)
+        logits = torch.empty((n, self.classes, out_hw[0], out_hw[1]), device=conv6.device, dtype=torch.float32)
+        ops.bilinear_fwd(cam, "nhwc", logits, "nchw", True)
+        return logits, cam
+
+    def head_backward(self, conv6: Tensor, drop7: Optional[Tensor], dlogits: Tensor, dw8: Tensor) -> Tensor:
+        """Returns the gradient w.r.t. b7's raw output; accumulates fc8's weight gradient into dw8 [C,4096]."""
+        n, g1, g2, _ = conv6.shape
+        dcam = torch.empty((n, g1, g2, self.classes), device=conv6.device, dtype=torch.float32)
+        ops.bilinear_bwd(dlogits.contiguous(), "nchw", dcam, "nhwc", True)
+        scale7, _ = self.bn_affine(self.bn7, "bn7")
+        g_x7 = torch.empty_like(conv6)
+        ops.fc8_bwd(conv6, self.fc8.weight.detach().reshape(self.classes, 4096), drop7, scale7, dcam, g_x7, dw8)
+        return g_x7
+
+    # ------------------------------------------------------------------ reference-style call
+    def forward(self, x: Tensor) -> Tensor:
+        """x: [N,3,H,W] f32 -> logits [N,classes,H,W] f32."""
+        params = [p for _, p in self.trainable_conv_params()]
+        if torch.is_grad_enabled() and params:
+            return _SegFunction.apply(self, x, *params)
+        drop = self.sample_dropout(x.shape[0], x.device) if self.training else {}
+        feats, _ = self.run_backbone(x, save=False, drop=drop)
+        logits, _ = self.head_forward(feats["conv6"], drop.get("dropout7"), x.shape[-2:])
+        return logits
+
+    def new_grad_buffers(self, device) -> Dict[str, Tensor]:
+        """Zeroed f32 gradient buffers in the kernels' [cout][kh][kw][cin] layout, one per trainable conv."""
+        out = {}
+        for name, p in self.trainable_conv_params():
+            cout, cin, kh, kw = p.shape
+            out[name] = torch.zeros((cout, kh, kw, cin), device=device, dtype=torch.float32)
+        return out
+
+
+class _SegFunction(torch.autograd.Function):
+    """Whole-model autograd node: forward = the fused forward plan, backward = the explicit reverse plan."""
+
+    @staticmethod
+    def forward(ctx, model: ResNet38dSeg, x: Tensor, *params: Tensor):
+        drop = model.sample_dropout(x.shape[0], x.device) if model.training else {}
+        feats, saved = model.run_backbone(x, save=True, drop=drop)
+        logits, _ = model.head_forward(feats["conv6"], drop.get("dropout7"), x.shape[-2:])
+        ctx.model, ctx.saved_acts, ctx.drop7 = model, saved, drop.get("dropout7")
+        if getattr(model, "debug_keep_saved", False):
+            model._last_saved = saved  # tests compare ReLU patterns with the oracle
+        ctx.names = [n for n, _ in model.trainable_conv_params()]
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits: Tensor):
+        model, saved = ctx.model, ctx.saved_acts
+        grads = model.new_grad_buffers(dlogits.device)
+        dw8 = grads["fc8.weight"].view(model.classes, 4096) if "fc8.weight" in grads else torch.zeros(
+            (model.classes, 4096), device=dlogits.device)
+        g_x7 = model.head_backward(saved.conv6, ctx.drop7, dlogits, dw8)
+        model.backward_backbone(saved, g_x7, grads)
+        ctx.saved_acts = None
+        return (None, None) + tuple(grads[n].permute(0, 3, 1, 2) for n in ctx.names)
+
+
+def create_model(arch: str, encoder_name: Optional[str] = None, in_channels: int = 3, classes: int = 3, precision: str = "bf16", **_):
+    """Plug point mirroring `smp.create_model(args.model, encoder_name=args.encoder, in_channels=3,
+    classes=args.num_classes, ...)` (models/segmentation_module.py:72-81).  Only the in-tree ResNet38-d is
+    provided; smp architectures (UnetPlusPlus/efficientnet) are third-party and out of scope."""
+    if arch.lower() in ("resnet38d", "resnet38-d", "resnet38d_seg"):
+        assert in_channels == 3
+        return ResNet38dSeg(classes=classes, precision=precision)
+    raise ValueError(f"pistoseg_amd provides --model ResNet38d only (got {arch!r}); smp models are not part of the hot path")

@@ -1,0 +1,171 @@
+"""Native training step for the ResNet38-d segmentation model (stage 5, `segmentation_train.py`).
+
+What `pl.Trainer.fit` does per batch in the reference -- `SegmentationModule.training_step`
+(models/segmentation_module.py:96-111: forward, per-pixel CE, mean over all pixels, mIoU bookkeeping), then
+Lightning's backward and `AdamW.step` (:86-90) -- is one call here, with no autograd graph:
+
+  forward plan -> fused CE fwd+bwd -> reverse plan (wgrad straight into a flat f32 gradient arena)
+  -> [N > 1: bucketed RCCL all-reduce of arena slices on a side stream, overlapped with the rest of the
+     backward] -> one fused AdamW launch over the flat parameter arena (also refreshes the bf16 weights).
+
+Parameters stay `nn.Parameter`s with the reference's names and OIHW shapes (checkpoint layout); their
+storage is re-pointed at slices of the arena (channels-last strides = the kernels' W_fwd layout).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib, ops
+from .resnet38d import UNITS
+from .seg_model import ResNet38dSeg
+
+Tensor = torch.Tensor
+
+
+def init_weights_he(model: torch.nn.Module, seed: int = 42) -> None:
+    """Random-init weights of the architecture (no checkpoint is available offline): He-normal convs with a
+    damped last conv per residual branch, mildly randomised BatchNorm statistics."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() == 4:
+                fan_in = p.shape[1] * p.shape[2] * p.shape[3]
+                std = math.sqrt(2.0 / fan_in)
+                if name.endswith(("conv_branch2b1.weight", "conv_branch2b2.weight")) and not (
+                    name.startswith(("b6", "b7")) and "2b1" in name):
+                    std *= 0.5
+                if name.startswith("fc8"):
+                    std = math.sqrt(1.0 / fan_in)
+                p.copy_(torch.randn(p.shape, generator=g) * std)
+            elif name.endswith("weight"):
+                p.copy_(torch.rand(p.shape, generator=g) * 0.8 + 0.6)
+            elif name.endswith("bias"):
+                p.copy_(torch.rand(p.shape, generator=g) * 0.4 - 0.2)
+        for name, b in model.named_buffers():
+            if name.endswith("running_mean"):
+                b.copy_(torch.rand(b.shape, generator=g) * 0.6 - 0.3)
+            elif name.endswith("running_var"):
+                b.copy_(torch.rand(b.shape, generator=g) + 0.6)
+
+
+def arena_order(model: ResNet38dSeg) -> List[Tuple[str, torch.nn.Parameter]]:
+    """Trainable conv weights in the order their gradients become final during the reverse plan
+    (fc8, b7, b6, ... ) so that all-reduce buckets are contiguous arena slices."""
+    named = dict(model.trainable_conv_params())
+    out: List[Tuple[str, torch.nn.Parameter]] = []
+    for k in list(named):
+        if k.split(".")[0] not in {u[0] for u in UNITS}:
+            out.append((k, named.pop(k)))  # heads (fc8, ...) finish first
+    for u in reversed(UNITS):
+        for k in list(named):
+            if k.split(".")[0] == u[0]:
+                out.append((k, named.pop(k)))
+    assert not named
+    return out
+
+
+class SegTrainer:
+    def __init__(self, model: ResNet38dSeg, lr: float = 1e-3, weight_decay: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8,
+                 ignore_index: Optional[int] = 3, process_group=None, bucket_mb: float = 48.0, track_iou: bool = True):
+        assert next(model.parameters()).is_cuda, "move the model to the GPU first"
+        self.model = model
+        self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
+        self.ignore_index = ignore_index
+        self.step_count = 0
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.track_iou = track_iou
+        dev = next(model.parameters()).device
+        self.device = dev
+        model.train()
+        self.entries = arena_order(model)
+        total = sum(p.numel() for _, p in self.entries)
+        self.p_flat = torch.empty(total, device=dev, dtype=torch.float32)
+        self.g_flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.m_flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.v_flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.pb_flat = torch.empty(total, device=dev, dtype=torch.bfloat16) if model.precision == "bf16" else None
+        self.grads: Dict[str, Tensor] = {}
+        self.offsets: Dict[str, Tuple[int, int]] = {}
+        off = 0
+        for name, p in self.entries:
+            cout, cin, kh, kw = p.shape
+            n = p.numel()
+            view = self.p_flat[off:off + n].view(cout, kh, kw, cin)
+            view.copy_(p.detach().permute(0, 2, 3, 1))
+            p.data = view.permute(0, 3, 1, 2)  # OIHW shape, channels-last strides, arena storage
+            self.grads[name] = self.g_flat[off:off + n].view(cout, kh, kw, cin)
+            if self.pb_flat is not None:
+                model._bf16_shadow[name] = self.pb_flat[off:off + n].view(cout, kh, kw, cin)
+            self.offsets[name] = (off, n)
+            off += n
+        if self.pb_flat is not None:
+            ops.cast_f32_bf16(self.p_flat, self.pb_flat)
+        model.invalidate_weight_cache()
+        # all-reduce buckets: (unit name after which the bucket is final, start, end) over the arena
+        self.buckets: List[Tuple[str, int, int]] = []
+        if self.world > 1:
+            limit = int(bucket_mb * (1 << 20) / 4)
+            start, last_unit = 0, None
+            for name, _ in self.entries:
+                unit = name.split(".")[0]
+                o, n = self.offsets[name]
+                if last_unit is not None and unit != last_unit and o - start >= limit:
+                    self.buckets.append((last_unit, start, o))
+                    start = o
+                last_unit = unit
+            self.buckets.append((last_unit, start, total))
+            self.comm_stream = torch.cuda.Stream(device=dev)
+        self.cm = torch.zeros(model.classes * model.classes, device=dev, dtype=torch.int64)  # train_iou confusion
+
+    # ------------------------------------------------------------------
+    def train_step(self, image: Tensor, mask: Tensor) -> Tensor:
+        """One optimisation step on a batch {'image': [N,3,H,W] f32, 'mask': [N,H,W] int64}; returns the loss (1-element device tensor)."""
+        model = self.model
+        n = image.shape[0]
+        self.g_flat.zero_()
+        drop = model.sample_dropout(n, image.device)
+        feats, saved = model.run_backbone(image, save=True, drop=drop)
+        logits, _ = model.head_forward(feats["conv6"], drop.get("dropout7"), image.shape[-2:])
+        # mean over the GLOBAL batch: every rank scales its gradient by 1/world, the all-reduce sums
+        loss, dlogits = ops.softmax_ce(logits, mask, self.ignore_index, want_grad=True, grad_scale=1.0 / self.world)
+        if self.track_iou:  # self.train_iou(mask_pred, mask), segmentation_module.py:108 -- kept on the device
+            pred = ops.argmax_mask(logits, mode=_lib.PS_MASK_PLAIN, softmax_first=True)
+            ops.confusion_accum(pred, mask, self.cm, model.classes)
+        dw8 = self.grads["fc8.weight"].view(model.classes, 4096)
+        g_x7 = model.head_backward(saved.conv6, drop.get("dropout7"), dlogits, dw8)
+        pending = []
+        bucket_iter = iter(self.buckets)
+        nxt = next(bucket_iter, None)
+
+        def after_unit(name: str):
+            nonlocal nxt
+            while nxt is not None and nxt[0] == name:
+                pending.append(self._launch_allreduce(nxt[1], nxt[2]))
+                nxt = next(bucket_iter, None)
+
+        model.backward_backbone(saved, g_x7, self.grads, after_unit=after_unit if self.world > 1 else None)
+        if self.world > 1:
+            while nxt is not None:  # buckets whose closing unit is frozen / not visited
+                pending.append(self._launch_allreduce(nxt[1], nxt[2]))
+                nxt = next(bucket_iter, None)
+            for w in pending:
+                w.wait()
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.step_count += 1
+        ops.adamw_step(self.p_flat, self.g_flat, self.m_flat, self.v_flat, self.pb_flat, self.lr, self.betas, self.eps,
+                       self.weight_decay, self.step_count)
+        model.invalidate_weight_cache()
+        return loss
+
+    def _launch_allreduce(self, start: int, end: int):
+        self.comm_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm_stream):
+            return torch.distributed.all_reduce(self.g_flat[start:end], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def lr_scheduler_step(self, gamma: float = 0.9) -> None:
+        """ExponentialLR(gamma=0.9) once per epoch (segmentation_module.py:88)."""
+        self.lr *= gamma
