@@ -164,6 +164,64 @@ int ps_argmax_mask(const float* x, const float* label, const uint8_t* tissue, ui
 int ps_confusion_accum(const uint8_t* pred, const int64_t* gt, int64_t* cm, int64_t npix, int32_t num_class, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * RFM head (stage 3/4, models/revise_net.py) and the feature-consistency losses
+ * (revise_pseudo_labels.py:115-138,253-282).  f32 arithmetic.
+ * ---------------------------------------------------------------------------------------------- */
+/* Batched strided GEMM  C[b][m][n] = alpha * sum_k A[b][m*sam + k*sak] * B[b][k*sbk + n*sbn]  (element strides;
+ * operand dtypes f32 or bf16).  replaces: torch.matmul(q.transpose(1,2), k) (revise_net.py:72) and its autograd. */
+int ps_bgemm(int32_t a_dtype, int32_t b_dtype, int32_t c_dtype, const void* A, const void* B, void* C, int32_t batch, int32_t M,
+             int32_t N, int32_t K, int64_t sab, int64_t sam, int64_t sak, int64_t sbb, int64_t sbk, int64_t sbn, int64_t scb, int64_t scm,
+             int64_t scn, float alpha, void* stream);
+/* In-place softmax of `rows` contiguous rows of length `len`.  replaces: F.softmax(A, dim=1) (revise_net.py:73) -- the
+ * affinity is kept TRANSPOSED (P[n][j][i] = A[n][i][j]) so the reference's dim=1 softmax runs along rows. */
+int ps_softmax_rows(float* x, int64_t rows, int32_t len, void* stream);
+/* R[n,j,cc] = sum_i P[n][j][i] * V[n,i,cc]  (cc <= 24).  replaces: torch.matmul(cam, A) in Net.RFM (revise_net.py:93-94)
+ * for the three normalised maps at once (V = [cam_n | pmask_n | pcam_n], pixel-major). */
+int ps_rfm_apply(const float* P, const float* V, float* R, int32_t n, int32_t np, int32_t cc, void* stream);
+/* Backward of ps_rfm_apply + ps_softmax_rows w.r.t. the pre-softmax scores, in place over P:
+ * dS[n][j][i] = P[n][j][i] * (sum_c dR[n,j,c]*V[n,i,c] - sum_c dR[n,j,c]*R[n,j,c]).  (V is no-grad: revise_net.py:32.) */
+int ps_affinity_softmax_bwd(float* P_inout, const float* dR, const float* V, const float* R, int32_t n, int32_t np, int32_t cc,
+                            void* stream);
+/* CAM normalisation into an f32 destination with element strides (dn, dc, dp) over (sample, channel, pixel).
+ * mode 0: get_norm_cam_d (revise_net.py:29-41); mode 1: max_norm(src)*label with channel 0 rebuilt as 1 - max fg
+ * (revise_pseudo_labels.py:132-138,268-272; label [n,c] f32 or NULL).  2 <= C <= 8. */
+int ps_norm_cam(const ps_tensor4* src, float* dst, int64_t dn, int64_t dc, int64_t dp, const float* label, int32_t mode, void* stream);
+
+int64_t ps_loss_workspace_floats(void);
+/* loss_rfm (revise_pseudo_labels.py:263-265): loss_out[0] (+)= mean over [n,1..c-1,h,w] of |a*label - b*label|; if da/db
+ * are given they are ACCUMULATED with grad_scale * d loss.  a, b: NCHW f32; label: [n,c] f32. */
+int ps_l1_masked(const float* a, const float* b, const float* label, float* da, float* db, float* loss_out, int32_t accumulate,
+                 float grad_scale, int32_t n, int32_t c, int32_t h, int32_t w, float* partials, void* stream);
+/* out[n,c,p] = | max_onehot(ref)[n,c,p] - rv[n,c,p]*label[n,c] |  (revise_pseudo_labels.py:125-130,275-276). */
+int ps_ecr_tensor(const float* ref, const float* rv, const float* label, float* out, int32_t n, int32_t c, int32_t h, int32_t w,
+                  void* stream);
+/* d rv (+)= -sign(max_onehot(ref) - rv*label) * label * grad_scale on the elements selected by ps_topk_select
+ * (thr/take from it; tie_counter: zeroed int32[n] scratch). */
+int ps_ecr_bwd(const float* ref, const float* rv, const float* label, const float* t, const float* thr, const int32_t* take,
+               int32_t* tie_counter, float* drv, float grad_scale, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
+/* Per-row top-k by radix select (k largest if largest != 0 else k smallest).  replaces: torch.topk(...)[0] followed by
+ * mean/sum (revise_pseudo_labels.py:120-122,277-278).  thr[row] = k-th value, take[row] = number of elements equal to thr
+ * that belong to the selection, sums[row] = sum of the selected values (of relu(values) if relu != 0). */
+int ps_topk_select(const float* x, int32_t rows, int64_t row_len, int32_t k, int32_t largest, int32_t relu, float* thr, int32_t* take,
+                   float* sums, void* stream);
+/* out[0] (+)= scale * sum_i x[i]   (fixed-order reduction of per-row sums). */
+int ps_sum_scaled(const float* x, int32_t n, float scale, float* out, int32_t accumulate, void* stream);
+/* out[nc] = mean over hw of x[nc, hw]   (F.adaptive_avg_pool2d(cam, 1), revise_pseudo_labels.py:253). */
+int ps_gap(const float* x, float* out, int32_t nc, int64_t hw, void* stream);
+/* F.multilabel_soft_margin_loss(gap[:,1:], label[:,1:]) (revise_pseudo_labels.py:255): loss_out[0] (+)= loss,
+ * dgap[n,c] = grad_scale * d loss / d gap (channel 0 gets 0). */
+int ps_softmargin(const float* gap, const float* label, float* dgap, float* loss_out, int32_t accumulate, float grad_scale, int32_t n,
+                  int32_t c, void* stream);
+/* dx[nc, hw] += dgap[nc] / hw */
+int ps_gap_bwd(const float* dgap, float* dx, int32_t nc, int64_t hw, void* stream);
+/* m[n,p] = max over channels 1.. of x[n,c,p]*label[n,c], arg[n,p] = that channel (first max)
+ * (adaptive_min_pooling_loss((cam_rv*label)[:,1:]), revise_pseudo_labels.py:115-119,254). */
+int ps_chmax(const float* x, const float* label, float* m, uint8_t* arg, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
+/* dx[n,arg,p] += grad_scale*label[n,arg] for the k smallest m (per ps_topk_select) that are > 0. */
+int ps_minpool_bwd(const float* m, const uint8_t* arg, const float* label, const float* thr, const int32_t* take, int32_t* tie_counter,
+                   float* dx, float grad_scale, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Optimisers over a flat f32 arena.  replaces: torch.optim.AdamW (models/segmentation_module.py:86-90)
  * and utils.PolyOptimizer / torch.optim.SGD (utils.py:166-187).
  * ---------------------------------------------------------------------------------------------- */

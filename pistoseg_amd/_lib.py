@@ -80,6 +80,22 @@ PROTOTYPES = {
     "ps_adamw_step": (C.c_int, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
     "ps_sgd_step": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _I, _P]),
     "ps_debug_set_glds": (None, [C.c_int]),
+    "ps_bgemm": (C.c_int, [_I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P]),
+    "ps_softmax_rows": (C.c_int, [_P, _L, _I, _P]),
+    "ps_rfm_apply": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
+    "ps_affinity_softmax_bwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "ps_norm_cam": (C.c_int, [C.POINTER(Tensor4), _P, _L, _L, _L, _P, _I, _P]),
+    "ps_loss_workspace_floats": (C.c_int64, []),
+    "ps_l1_masked": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _I, _P, _P]),
+    "ps_ecr_tensor": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ps_ecr_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P]),
+    "ps_topk_select": (C.c_int, [_P, _I, _L, _I, _I, _I, _P, _P, _P, _P]),
+    "ps_sum_scaled": (C.c_int, [_P, _I, _F, _P, _I, _P]),
+    "ps_gap": (C.c_int, [_P, _P, _I, _L, _P]),
+    "ps_softmargin": (C.c_int, [_P, _P, _P, _P, _I, _F, _I, _I, _P]),
+    "ps_gap_bwd": (C.c_int, [_P, _P, _I, _L, _P]),
+    "ps_chmax": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ps_minpool_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -1,0 +1,567 @@
+// RFM head and feature-consistency losses (stage 3, revise_net.py / revise_pseudo_labels.py): affinity
+// attention (batched q^T k + column softmax), CAM normalisation, RFM application, and the cls / rfm / ecr
+// loss reductions with their gradients.  All f32 arithmetic; these are <0.2 % of the step's FLOPs and
+// HBM/L2-bound, so they are plain wave64 VALU kernels (LDS tiles, shuffles for the reductions).
+#include <math.h>
+
+#include "ps_internal.h"
+
+namespace {
+
+__device__ __forceinline__ float ld(const void* p, int dtype, long long i) {
+  return dtype == PS_BF16 ? ps_bf16_to_f32(reinterpret_cast<const uint16_t*>(p)[i]) : reinterpret_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void st(void* p, int dtype, long long i, float v) {
+  if (dtype == PS_BF16) reinterpret_cast<uint16_t*>(p)[i] = ps_f32_to_bf16(v);
+  else reinterpret_cast<float*>(p)[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched strided GEMM  C[b][m][n] = alpha * sum_k A[b][m*sam + k*sak] * B[b][k*sbk + n*sbn]
+// 64x64 tile, 16-deep K steps, 256 threads x (4x4) outputs.
+// ------------------------------------------------------------------------------------------------
+struct BgemmArgs {
+  const void* A; const void* B; void* C;
+  int adt, bdt, cdt;
+  int batch, M, N, K;
+  long long sab, sam, sak, sbb, sbk, sbn, scb, scm, scn;
+  float alpha;
+};
+__global__ __launch_bounds__(256) void bgemm_kernel(const BgemmArgs a) {
+  __shared__ float As[16][65], Bs[16][65];
+  const int b = blockIdx.z, m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const unsigned char* Ab = static_cast<const unsigned char*>(a.A);
+  const unsigned char* Bb = static_cast<const unsigned char*>(a.B);
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < a.K; k0 += 16) {
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+      // pick the index that is contiguous in memory as the fast one
+      int kk, mm;
+      if (a.sak == 1) { kk = e & 15; mm = e >> 4; } else { mm = e & 63; kk = e >> 6; }
+      const int m = m0 + mm, k = k0 + kk;
+      As[kk][mm] = (m < a.M && k < a.K) ? ld(Ab, a.adt, b * a.sab + m * a.sam + k * a.sak) : 0.f;
+      int kb, nn;
+      if (a.sbk == 1) { kb = e & 15; nn = e >> 4; } else { nn = e & 63; kb = e >> 6; }
+      const int n = n0 + nn, k2 = k0 + kb;
+      Bs[kb][nn] = (n < a.N && k2 < a.K) ? ld(Bb, a.bdt, b * a.sbb + k2 * a.sbk + n * a.sbn) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { av[i] = As[kk][ty * 4 + i]; bv[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+      if (m < a.M && n < a.N) st(a.C, a.cdt, b * a.scb + m * a.scm + n * a.scn, a.alpha * acc[i][j]);
+    }
+}
+
+// in-place softmax of rows of length len (one wave per row)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, long long rows, int len) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float* r = x + row * len;
+  float mx = -INFINITY;
+  for (int i = lane; i < len; i += 64) mx = fmaxf(mx, r[i]);
+  mx = ps_wave_max(mx);
+  float s = 0.f;
+  for (int i = lane; i < len; i += 64) s += expf(r[i] - mx);
+  s = ps_wave_sum(s);
+  const float inv = 1.f / s;
+  for (int i = lane; i < len; i += 64) r[i] = expf(r[i] - mx) * inv;
+}
+
+// R[n,j,cc] = sum_i P[n][j][i] * V[n,i,cc]     (one wave per (n,j); cc <= 24)
+constexpr int RFM_MAXCC = 24;
+__global__ __launch_bounds__(256) void rfm_apply_kernel(const float* __restrict__ P, const float* __restrict__ V, float* __restrict__ R,
+                                                        long long rows, int np, int cc) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const long long n = row / np;
+  const float* p = P + row * np;
+  const float* v = V + n * np * cc;
+  float acc[RFM_MAXCC];
+#pragma unroll
+  for (int c = 0; c < RFM_MAXCC; ++c) acc[c] = 0.f;
+  for (int i = lane; i < np; i += 64) {
+    const float pv = p[i];
+#pragma unroll
+    for (int c = 0; c < RFM_MAXCC; ++c)
+      if (c < cc) acc[c] = fmaf(pv, v[(long long)i * cc + c], acc[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < RFM_MAXCC; ++c)
+    if (c < cc) {
+      const float s = ps_wave_sum(acc[c]);
+      if (lane == 0) R[row * cc + c] = s;
+    }
+}
+
+// dS[n][j][i] = P[n][j][i] * (sum_c dR[n,j,c]*V[n,i,c] - sum_c dR[n,j,c]*R[n,j,c])   (in place over P)
+__global__ __launch_bounds__(256) void affinity_softmax_bwd_kernel(float* __restrict__ P, const float* __restrict__ dR,
+                                                                   const float* __restrict__ V, const float* __restrict__ R,
+                                                                   long long rows, int np, int cc) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const long long n = row / np;
+  float g[RFM_MAXCC];
+  float dot = 0.f;
+#pragma unroll
+  for (int c = 0; c < RFM_MAXCC; ++c) {
+    g[c] = c < cc ? dR[row * cc + c] : 0.f;
+    if (c < cc) dot = fmaf(g[c], R[row * cc + c], dot);
+  }
+  float* p = P + row * np;
+  const float* v = V + n * np * cc;
+  for (int i = lane; i < np; i += 64) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < RFM_MAXCC; ++c)
+      if (c < cc) s = fmaf(g[c], v[(long long)i * cc + c], s);
+    p[i] = p[i] * (s - dot);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CAM normalisation.  mode 0: get_norm_cam_d (revise_net.py:29-41); mode 1: max_norm(.)*label with the
+// background channel rebuilt as 1 - max fg (revise_pseudo_labels.py:268-272).  One block per sample.
+// src: strided (n,c,h,w) view; dst: f32 with strides (dn, dc, dp) over (n, c, pixel).
+// ------------------------------------------------------------------------------------------------
+struct NormArgs {
+  const void* src; int sdt; long long sn, sc, sh, sw;
+  float* dst; long long dn, dc, dp;
+  const float* label;  // [n, c] or null (mode 1)
+  int c, h, w, mode;
+};
+__global__ __launch_bounds__(256) void norm_cam_kernel(const NormArgs a) {
+  __shared__ float smin[8][4], smax[8][4], fmn[8], fmx[8];
+  const int n = blockIdx.x, hw = a.h * a.w, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = 0; c < a.c; ++c) {
+    float mn = INFINITY, mx = -INFINITY;
+    for (int p = threadIdx.x; p < hw; p += 256) {
+      const float v = ld(a.src, a.sdt, n * a.sn + c * a.sc + (p / a.w) * a.sh + (p % a.w) * a.sw);
+      mn = fminf(mn, v); mx = fmaxf(mx, v);
+    }
+    mn = ps_wave_min(mn); mx = ps_wave_max(mx);
+    if (lane == 0) { smin[c][wave] = mn; smax[c][wave] = mx; }
+  }
+  __syncthreads();
+  if (threadIdx.x < a.c) {
+    const int c = threadIdx.x;
+    fmn[c] = fminf(fminf(smin[c][0], smin[c][1]), fminf(smin[c][2], smin[c][3]));
+    fmx[c] = fmaxf(fmaxf(smax[c][0], smax[c][1]), fmaxf(smax[c][2], smax[c][3]));
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < hw; p += 256) {
+    float v[8];
+    float fgmax = -INFINITY;
+    for (int c = 0; c < a.c; ++c) {
+      const float x = ld(a.src, a.sdt, n * a.sn + c * a.sc + (p / a.w) * a.sh + (p % a.w) * a.sw);
+      if (a.mode == 0) v[c] = (x - fmn[c]) / ((fmx[c] + 1e-5f) - fmn[c]);
+      else v[c] = (x - fmn[c]) / (fmx[c] - fmn[c] + 1e-5f) * (a.label ? a.label[n * a.c + c] : 1.f);
+      if (c >= 1) fgmax = fmaxf(fgmax, v[c]);
+    }
+    v[0] = 1.f - fgmax;
+    if (a.mode == 0)
+      for (int c = 1; c < a.c; ++c)
+        if (v[c] < fgmax) v[c] = 0.f;
+    for (int c = 0; c < a.c; ++c) a.dst[n * a.dn + c * a.dc + p * a.dp] = v[c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Loss reductions.  All produce per-block partial sums (deterministic two-stage reduction).
+// ------------------------------------------------------------------------------------------------
+constexpr int LOSS_BLOCKS = 1024;
+__device__ __forceinline__ void block_partial(float local, float* partials) {
+  __shared__ float red[4];
+  local = ps_wave_sum(local);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void finish_sum_kernel(const float* __restrict__ partials, int nparts, float scale, float* __restrict__ out,
+                                                         int accumulate) {
+  __shared__ float red[4];
+  float v = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) v += partials[i];
+  v = ps_wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float r = ((red[0] + red[1]) + (red[2] + red[3])) * scale;
+    out[0] = accumulate ? out[0] + r : r;
+  }
+}
+
+// loss_rfm = mean over [n, 1.., h, w] of |a*label - b*label|;  da/db (+)= +-sign * label * gscale
+__global__ __launch_bounds__(256) void l1_masked_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ label,
+                                                        float* __restrict__ da, float* __restrict__ db, float* __restrict__ partials, int n,
+                                                        int c, long long hw, float gscale) {
+  const long long total = (long long)n * (c - 1) * hw;
+  float local = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long pix = i % hw;
+    const long long t = i / hw;
+    const int ch = (int)(t % (c - 1)) + 1, img = (int)(t / (c - 1));
+    const long long off = ((long long)img * c + ch) * hw + pix;
+    const float l = label[img * c + ch];
+    const float d = a[off] * l - b[off] * l;
+    local += fabsf(d);
+    if (da) {
+      const float s = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+      da[off] += s * l * gscale;
+      db[off] -= s * l * gscale;
+    }
+  }
+  block_partial(local, partials);
+}
+
+// tensor_ecr[n, c, p] = | max_onehot(ref)[n,c,p] - rv[n,c,p]*label[n,c] |   (revise_pseudo_labels.py:125-130,275-276)
+__global__ __launch_bounds__(256) void ecr_tensor_kernel(const float* __restrict__ ref, const float* __restrict__ rv, const float* __restrict__ label,
+                                                         float* __restrict__ out, int n, int c, long long hw) {
+  const long long total = (long long)n * hw;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long img = i / hw, pix = i - img * hw;
+    const float* rp = ref + img * c * hw + pix;
+    float fgmax = -INFINITY;
+    for (int k = 1; k < c; ++k) fgmax = fmaxf(fgmax, rp[k * hw]);
+    for (int k = 0; k < c; ++k) {
+      float oh = rp[k * hw];
+      if (k >= 1 && oh != fgmax) oh = 0.f;
+      const long long off = (img * c + k) * hw + pix;
+      out[off] = fabsf(oh - rv[off] * label[img * c + k]);
+    }
+  }
+}
+// d rv (+)= -sign(oh - rv*label) * label * gscale on the selected (top-k) elements
+__global__ __launch_bounds__(256) void ecr_bwd_kernel(const float* __restrict__ ref, const float* __restrict__ rv, const float* __restrict__ label,
+                                                      const float* __restrict__ t, const float* __restrict__ thr, const int* __restrict__ ties_take,
+                                                      int* __restrict__ tie_counter, float* __restrict__ drv, int n, int c, long long hw, float gscale) {
+  const long long total = (long long)n * hw;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long img = i / hw, pix = i - img * hw;
+    const float* rp = ref + img * c * hw + pix;
+    float fgmax = -INFINITY;
+    for (int k = 1; k < c; ++k) fgmax = fmaxf(fgmax, rp[k * hw]);
+    for (int k = 0; k < c; ++k) {
+      const long long off = (img * c + k) * hw + pix;
+      const float tv = t[off], th = thr[img];
+      bool sel = tv > th;
+      if (!sel && tv == th) sel = atomicAdd(&tie_counter[img], 1) < ties_take[img];
+      if (!sel) continue;
+      float oh = rp[k * hw];
+      if (k >= 1 && oh != fgmax) oh = 0.f;
+      const float l = label[img * c + k];
+      const float d = oh - rv[off] * l;
+      const float s = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+      drv[off] -= s * l * gscale;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// top-k by radix select: one block per row; keys are order-preserving uint32 images of the floats.
+// largest != 0: k largest; else k smallest.  Outputs thr[row] (the k-th value), take[row] = how many
+// elements EQUAL to thr belong to the selection, and sum[row] = sum of the selected values (optionally
+// of relu(values)), which does not depend on which ties are taken.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fkey(float f, int largest) {
+  uint32_t u = __float_as_uint(f);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending order
+  return largest ? ~u : u;                          // select the k SMALLEST keys
+}
+__device__ __forceinline__ float fkey_inv(uint32_t key, int largest) {
+  uint32_t u = largest ? ~key : key;
+  u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+  return __uint_as_float(u);
+}
+__global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restrict__ x, long long row_len, int k, int largest, int relu,
+                                                           float* __restrict__ thr, int* __restrict__ take, float* __restrict__ sums) {
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned int s_prefix, s_remaining;
+  __shared__ float red[16];
+  const float* r = x + (long long)blockIdx.x * row_len;
+  if (threadIdx.x == 0) { s_prefix = 0; s_remaining = (unsigned)k; }
+  __syncthreads();
+  for (int pass = 3; pass >= 0; --pass) {
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned prefix = s_prefix;
+    const unsigned hi_mask = pass == 3 ? 0u : (0xFFFFFFFFu << (8 * (pass + 1)));
+    for (long long i = threadIdx.x; i < row_len; i += blockDim.x) {
+      const uint32_t key = fkey(r[i], largest);
+      if ((key & hi_mask) == prefix) atomicAdd(&hist[(key >> (8 * pass)) & 255u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned rem = s_remaining, b = 0;
+      for (; b < 256; ++b) {
+        if (hist[b] >= rem) break;
+        rem -= hist[b];
+      }
+      s_prefix = prefix | (b << (8 * pass));
+      s_remaining = rem;
+    }
+    __syncthreads();
+  }
+  const uint32_t kth = s_prefix;  // key of the k-th element; s_remaining = how many equal keys are taken
+  const float t = fkey_inv(kth, largest);
+  float local = 0.f;
+  for (long long i = threadIdx.x; i < row_len; i += blockDim.x) {
+    const float v = r[i];
+    if (fkey(v, largest) < kth) local += relu ? fmaxf(v, 0.f) : v;
+  }
+  local = ps_wave_sum(local);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    const int nw = blockDim.x >> 6;
+    for (int w = 0; w < nw; ++w) s += red[w];
+    thr[blockIdx.x] = t;
+    take[blockIdx.x] = (int)s_remaining;
+    sums[blockIdx.x] = s + (relu ? fmaxf(t, 0.f) : t) * (float)s_remaining;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// classification pieces of loss_cls (revise_pseudo_labels.py:253-256)
+// ------------------------------------------------------------------------------------------------
+// per-(n,c) mean over pixels of an NCHW tensor (adaptive_avg_pool2d(cam, 1)): one block per (n,c)
+__global__ __launch_bounds__(256) void gap_kernel(const float* __restrict__ x, float* __restrict__ out, long long hw) {
+  __shared__ float red[4];
+  const float* p = x + (long long)blockIdx.x * hw;
+  float s = 0.f;
+  for (long long i = threadIdx.x; i < hw; i += 256) s += p[i];
+  s = ps_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)hw;
+}
+// multilabel_soft_margin_loss on gap[:,1:] vs label[:,1:] (mean over classes, mean over batch) and its gradient
+// w.r.t. gap; single block.  loss_out[0] (+)= loss.  dgap[n,c] = gscale * (sigmoid(x) - y) / ((c-1)*n), dgap[n,0] = 0.
+__global__ __launch_bounds__(256) void softmargin_kernel(const float* __restrict__ gap, const float* __restrict__ label, float* __restrict__ dgap,
+                                                         float* __restrict__ loss_out, int n, int c, float gscale, int accumulate) {
+  __shared__ float red[4];
+  float local = 0.f;
+  for (int i = threadIdx.x; i < n * c; i += 256) {
+    const int ch = i % c;
+    float g = 0.f;
+    if (ch >= 1) {
+      const float x = gap[i], y = label[i];
+      // -(y*logsigmoid(x) + (1-y)*logsigmoid(-x)); logsigmoid(x) = min(x,0) - log1p(exp(-|x|))
+      const float ls_pos = fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
+      const float ls_neg = fminf(-x, 0.f) - log1pf(expf(-fabsf(x)));
+      local += -(y * ls_pos + (1.f - y) * ls_neg);
+      const float sig = 1.f / (1.f + expf(-x));
+      g = (sig - y) * gscale / (float)((c - 1) * n);
+    }
+    if (dgap) dgap[i] = g;
+  }
+  local = ps_wave_sum(local);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float r = ((red[0] + red[1]) + (red[2] + red[3])) / (float)((c - 1) * n);
+    loss_out[0] = accumulate ? loss_out[0] + r : r;
+  }
+}
+// dx[n,c,p] (+)= dgap[n,c] / hw    (gradient of the global average pool, broadcast)
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ dgap, float* __restrict__ dx, long long total, long long hw) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) dx[i] += dgap[i / hw] / (float)hw;
+}
+// m[n,p] = max over fg channels of x[n,c,p]*label[n,c]; arg[n,p] = its channel (first max)
+__global__ __launch_bounds__(256) void chmax_kernel(const float* __restrict__ x, const float* __restrict__ label, float* __restrict__ m,
+                                                    uint8_t* __restrict__ arg, int n, int c, long long hw) {
+  const long long total = (long long)n * hw;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long img = i / hw, pix = i - img * hw;
+    float best = 0.f;
+    int bi = 1;
+    for (int k = 1; k < c; ++k) {
+      const float v = x[(img * c + k) * hw + pix] * label[img * c + k];
+      if (k == 1 || v > best) { best = v; bi = k; }
+    }
+    m[i] = best;
+    arg[i] = (uint8_t)bi;
+  }
+}
+// adaptive_min_pooling backward: the k smallest channel-max values with value > 0 route gscale*label to their argmax channel
+__global__ __launch_bounds__(256) void minpool_bwd_kernel(const float* __restrict__ m, const uint8_t* __restrict__ arg, const float* __restrict__ label,
+                                                          const float* __restrict__ thr, const int* __restrict__ take, int* __restrict__ tie_counter,
+                                                          float* __restrict__ dx, int n, int c, long long hw, float gscale) {
+  const long long total = (long long)n * hw;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long img = i / hw, pix = i - img * hw;
+    const float v = m[i], th = thr[img];
+    bool sel = v < th;
+    if (!sel && v == th) sel = atomicAdd(&tie_counter[img], 1) < take[img];
+    if (!sel || !(v > 0.f)) continue;
+    const int k = arg[i];
+    dx[(img * c + k) * hw + pix] += gscale * label[img * c + k];
+  }
+}
+
+static inline int grid_for(long long items, int per_block, int cap = 2048) {
+  long long b = (items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int ps_bgemm(int32_t adt, int32_t bdt, int32_t cdt, const void* A, const void* B, void* C, int32_t batch, int32_t M, int32_t N,
+                        int32_t K, int64_t sab, int64_t sam, int64_t sak, int64_t sbb, int64_t sbk, int64_t sbn, int64_t scb, int64_t scm,
+                        int64_t scn, float alpha, void* stream) {
+  PS_REQUIRE(A && B && C && batch > 0 && M > 0 && N > 0 && K > 0, "bgemm: bad argument");
+  PS_REQUIRE(batch <= 65535, "bgemm: batch %d too large", batch);
+  BgemmArgs a{A, B, C, adt, bdt, cdt, batch, M, N, K, sab, sam, sak, sbb, sbk, sbn, scb, scm, scn, alpha};
+  hipLaunchKernelGGL(bgemm_kernel, dim3((N + 63) / 64, (M + 63) / 64, batch), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  PS_CHECK_LAUNCH("bgemm");
+  return PS_OK;
+}
+
+extern "C" int ps_softmax_rows(float* x, int64_t rows, int32_t len, void* stream) {
+  PS_REQUIRE(x && rows > 0 && len > 0, "softmax_rows: bad argument");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, (long long)rows, len);
+  PS_CHECK_LAUNCH("softmax_rows");
+  return PS_OK;
+}
+
+extern "C" int ps_rfm_apply(const float* P, const float* V, float* R, int32_t n, int32_t np, int32_t cc, void* stream) {
+  PS_REQUIRE(P && V && R && n > 0 && np > 0 && cc > 0 && cc <= RFM_MAXCC, "rfm_apply: bad argument (cc <= %d)", RFM_MAXCC);
+  const long long rows = (long long)n * np;
+  hipLaunchKernelGGL(rfm_apply_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), P, V, R, rows, np, cc);
+  PS_CHECK_LAUNCH("rfm_apply");
+  return PS_OK;
+}
+
+extern "C" int ps_affinity_softmax_bwd(float* P_inout, const float* dR, const float* V, const float* R, int32_t n, int32_t np, int32_t cc,
+                                       void* stream) {
+  PS_REQUIRE(P_inout && dR && V && R && n > 0 && np > 0 && cc > 0 && cc <= RFM_MAXCC, "affinity_softmax_bwd: bad argument");
+  const long long rows = (long long)n * np;
+  hipLaunchKernelGGL(affinity_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), P_inout, dR,
+                     V, R, rows, np, cc);
+  PS_CHECK_LAUNCH("affinity_softmax_bwd");
+  return PS_OK;
+}
+
+extern "C" int ps_norm_cam(const ps_tensor4* src, float* dst, int64_t dn, int64_t dc, int64_t dp, const float* label, int32_t mode, void* stream) {
+  PS_REQUIRE(src && src->ptr && dst, "norm_cam: null argument");
+  PS_REQUIRE(src->c >= 2 && src->c <= 8 && (mode == 0 || mode == 1), "norm_cam: C=%d unsupported (2..8) or bad mode", src->c);
+  NormArgs a{src->ptr, src->dtype, src->sn, src->sc, src->sh, src->sw, dst, dn, dc, dp, label, src->c, src->h, src->w, mode};
+  hipLaunchKernelGGL(norm_cam_kernel, dim3(src->n), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  PS_CHECK_LAUNCH("norm_cam");
+  return PS_OK;
+}
+
+extern "C" int64_t ps_loss_workspace_floats(void) { return LOSS_BLOCKS; }
+
+extern "C" int ps_l1_masked(const float* a, const float* b, const float* label, float* da, float* db, float* loss_out, int32_t accumulate,
+                            float grad_scale, int32_t n, int32_t c, int32_t h, int32_t w, float* partials, void* stream) {
+  PS_REQUIRE(a && b && label && loss_out && partials && n > 0 && c >= 2 && (!da == !db), "l1_masked: bad argument");
+  const long long hw = (long long)h * w, total = (long long)n * (c - 1) * hw;
+  const int grid = grid_for(total, 256, LOSS_BLOCKS);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(l1_masked_kernel, dim3(grid), dim3(256), 0, s, a, b, label, da, db, partials, n, c, hw, grad_scale / (float)total);
+  PS_CHECK_LAUNCH("l1_masked");
+  hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, s, partials, grid, 1.f / (float)total, loss_out, accumulate);
+  PS_CHECK_LAUNCH("l1_masked_finish");
+  return PS_OK;
+}
+
+extern "C" int ps_ecr_tensor(const float* ref, const float* rv, const float* label, float* out, int32_t n, int32_t c, int32_t h, int32_t w,
+                             void* stream) {
+  PS_REQUIRE(ref && rv && label && out && n > 0 && c >= 2, "ecr_tensor: bad argument");
+  const long long hw = (long long)h * w;
+  hipLaunchKernelGGL(ecr_tensor_kernel, dim3(grid_for((long long)n * hw, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), ref, rv, label, out,
+                     n, c, hw);
+  PS_CHECK_LAUNCH("ecr_tensor");
+  return PS_OK;
+}
+
+extern "C" int ps_ecr_bwd(const float* ref, const float* rv, const float* label, const float* t, const float* thr, const int32_t* take,
+                          int32_t* tie_counter, float* drv, float grad_scale, int32_t n, int32_t c, int32_t h, int32_t w, void* stream) {
+  PS_REQUIRE(ref && rv && label && t && thr && take && tie_counter && drv && n > 0, "ecr_bwd: bad argument");
+  const long long hw = (long long)h * w;
+  hipLaunchKernelGGL(ecr_bwd_kernel, dim3(grid_for((long long)n * hw, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), ref, rv, label, t, thr,
+                     take, tie_counter, drv, n, c, hw, grad_scale);
+  PS_CHECK_LAUNCH("ecr_bwd");
+  return PS_OK;
+}
+
+extern "C" int ps_topk_select(const float* x, int32_t rows, int64_t row_len, int32_t k, int32_t largest, int32_t relu, float* thr, int32_t* take,
+                              float* sums, void* stream) {
+  PS_REQUIRE(x && thr && take && sums && rows > 0 && row_len > 0 && k >= 1 && k <= row_len, "topk_select: bad argument (k=%d, len=%lld)", k,
+             (long long)row_len);
+  hipLaunchKernelGGL(topk_select_kernel, dim3(rows), dim3(1024), 0, static_cast<hipStream_t>(stream), x, (long long)row_len, k, largest, relu, thr,
+                     take, sums);
+  PS_CHECK_LAUNCH("topk_select");
+  return PS_OK;
+}
+
+extern "C" int ps_sum_scaled(const float* x, int32_t n, float scale, float* out, int32_t accumulate, void* stream) {
+  PS_REQUIRE(x && out && n > 0, "sum_scaled: bad argument");
+  hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), x, n, scale, out, accumulate);
+  PS_CHECK_LAUNCH("sum_scaled");
+  return PS_OK;
+}
+
+extern "C" int ps_gap(const float* x, float* out, int32_t nc, int64_t hw, void* stream) {
+  PS_REQUIRE(x && out && nc > 0 && hw > 0, "gap: bad argument");
+  hipLaunchKernelGGL(gap_kernel, dim3(nc), dim3(256), 0, static_cast<hipStream_t>(stream), x, out, (long long)hw);
+  PS_CHECK_LAUNCH("gap");
+  return PS_OK;
+}
+
+extern "C" int ps_softmargin(const float* gap, const float* label, float* dgap, float* loss_out, int32_t accumulate, float grad_scale, int32_t n,
+                             int32_t c, void* stream) {
+  PS_REQUIRE(gap && label && loss_out && n > 0 && c >= 2, "softmargin: bad argument");
+  hipLaunchKernelGGL(softmargin_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), gap, label, dgap, loss_out, n, c, grad_scale,
+                     accumulate);
+  PS_CHECK_LAUNCH("softmargin");
+  return PS_OK;
+}
+
+extern "C" int ps_gap_bwd(const float* dgap, float* dx, int32_t nc, int64_t hw, void* stream) {
+  PS_REQUIRE(dgap && dx && nc > 0 && hw > 0, "gap_bwd: bad argument");
+  const long long total = (long long)nc * hw;
+  hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), dgap, dx, total, (long long)hw);
+  PS_CHECK_LAUNCH("gap_bwd");
+  return PS_OK;
+}
+
+extern "C" int ps_chmax(const float* x, const float* label, float* m, uint8_t* arg, int32_t n, int32_t c, int32_t h, int32_t w, void* stream) {
+  PS_REQUIRE(x && label && m && arg && n > 0 && c >= 2, "chmax: bad argument");
+  const long long hw = (long long)h * w;
+  hipLaunchKernelGGL(chmax_kernel, dim3(grid_for((long long)n * hw, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, label, m, arg, n, c, hw);
+  PS_CHECK_LAUNCH("chmax");
+  return PS_OK;
+}
+
+extern "C" int ps_minpool_bwd(const float* m, const uint8_t* arg, const float* label, const float* thr, const int32_t* take, int32_t* tie_counter,
+                              float* dx, float grad_scale, int32_t n, int32_t c, int32_t h, int32_t w, void* stream) {
+  PS_REQUIRE(m && arg && label && thr && take && tie_counter && dx && n > 0, "minpool_bwd: bad argument");
+  const long long hw = (long long)h * w;
+  hipLaunchKernelGGL(minpool_bwd_kernel, dim3(grid_for((long long)n * hw, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), m, arg, label, thr,
+                     take, tie_counter, dx, n, c, hw, grad_scale);
+  PS_CHECK_LAUNCH("minpool_bwd");
+  return PS_OK;
+}

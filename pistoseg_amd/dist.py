@@ -1,0 +1,104 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm).
+
+The reference has no distributed code (its `nn.DataParallel` wrappers degenerate to one device);
+tile batches are independent (BN is frozen, resnet38d.py:206-211), so
+  * training = batch-dim data parallel with ONE exchange per step: a SUM all-reduce of the flat f32 gradient
+    arena, cut into buckets that are contiguous in the order the reverse plan finalises them and launched on
+    a side stream as soon as their last unit is done (overlap with the remaining dgrad/wgrad);
+  * inference = contiguous index ranges per rank, no collective on the data path, optional gather of uint8
+    masks / all-reduce of the confusion matrix.
+Everything here is device-agnostic so the N > 1 logic is covered by world_size-2 gloo tests on CPU.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+Tensor = torch.Tensor
+
+
+def plan_buckets(entries: Sequence[Tuple[str, int]], limit_elems: int) -> List[Tuple[str, int, int]]:
+    """entries: (parameter name 'unit.conv.weight', numel) in arena order.  Returns (closing unit, start, end)
+    slices that tile the arena exactly; a bucket closes at a unit boundary once it holds >= limit_elems."""
+    buckets: List[Tuple[str, int, int]] = []
+    start, off, last_unit = 0, 0, None
+    for name, n in entries:
+        unit = name.split(".")[0]
+        if last_unit is not None and unit != last_unit and off - start >= limit_elems:
+            buckets.append((last_unit, start, off))
+            start = off
+        last_unit = unit
+        off += n
+    if off > start:
+        buckets.append((last_unit, start, off))
+    return buckets
+
+
+class BucketedAllReduce:
+    """SUM all-reduce of a flat gradient arena in buckets, driven by 'unit finished' notifications."""
+
+    def __init__(self, flat: Tensor, buckets: List[Tuple[str, int, int]], group=None):
+        self.flat, self.buckets, self.group = flat, buckets, group
+        self.comm_stream = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None
+        self._next = 0
+        self._pending = []
+
+    def begin_step(self) -> None:
+        self._next, self._pending = 0, []
+
+    def _launch(self, start: int, end: int) -> None:
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                w = dist.all_reduce(self.flat[start:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            w = dist.all_reduce(self.flat[start:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._pending.append(w)
+
+    def on_unit_done(self, unit: str) -> None:
+        while self._next < len(self.buckets) and self.buckets[self._next][0] == unit:
+            _, s, e = self.buckets[self._next]
+            self._launch(s, e)
+            self._next += 1
+
+    def finish(self) -> None:
+        """Flush buckets whose closing unit was never reported (frozen units), then wait for everything."""
+        while self._next < len(self.buckets):
+            _, s, e = self.buckets[self._next]
+            self._launch(s, e)
+            self._next += 1
+        for w in self._pending:
+            w.wait()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self._pending = []
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous index range of this rank: [rank*ceil(n/p), min(n, (rank+1)*ceil(n/p)))  (SURVEY.md 8e)."""
+    per = (n_items + world - 1) // world
+    lo = min(n_items, rank * per)
+    return lo, min(n_items, lo + per)
+
+
+def gather_masks(local: Tensor, n_items: int, group=None) -> Optional[Tensor]:
+    """Gather per-rank uint8 masks [n_local, H, W] to rank 0 in shard order (C2 of SURVEY 2.1)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    per = (n_items + world - 1) // world
+    padded = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    out = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
+    dist.gather(padded, out, dst=0, group=group)
+    if rank != 0:
+        return None
+    return torch.cat(out, dim=0)[:n_items]
+
+
+def allreduce_confusion(cm: Tensor, group=None) -> Tensor:
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(cm, op=dist.ReduceOp.SUM, group=group)
+    return cm

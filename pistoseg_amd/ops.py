@@ -296,3 +296,131 @@ def sgd_step(p: Tensor, g: Tensor, buf: Optional[Tensor], p_bf16: Optional[Tenso
         lib.ps_sgd_step(p.data_ptr(), g.data_ptr(), _ptr(buf), _ptr(p_bf16), p.numel(), lr, momentum, weight_decay, int(first_step), _stream()),
         "ps_sgd_step",
     )
+
+
+# ---------------------------------------------------------------------------------------------------
+# RFM head + feature-consistency losses (csrc/rfm_ops.hip)
+# ---------------------------------------------------------------------------------------------------
+def bgemm(A: Tensor, B: Tensor, Cm: Tensor, batch: int, M: int, N: int, K: int, sa, sb, sc, alpha: float = 1.0) -> None:
+    """C[b][m][n] = alpha * sum_k A[b][m*sam + k*sak] * B[b][k*sbk + n*sbn]; sa=(sab,sam,sak), sb=(sbb,sbk,sbn), sc=(scb,scm,scn)."""
+    _require_gpu(A, B, Cm)
+    lib = _lib.load()
+    _lib.check(lib.ps_bgemm(_dt(A), _dt(B), _dt(Cm), A.data_ptr(), B.data_ptr(), Cm.data_ptr(), batch, M, N, K, *sa, *sb, *sc, alpha, _stream()), "ps_bgemm")
+
+
+def softmax_rows_(x: Tensor, rows: int, length: int) -> None:
+    _require_gpu(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    lib = _lib.load()
+    _lib.check(lib.ps_softmax_rows(x.data_ptr(), rows, length, _stream()), "ps_softmax_rows")
+
+
+def rfm_apply(P: Tensor, V: Tensor, R: Tensor) -> None:
+    """R[n,j,:] = sum_i P[n,j,i] * V[n,i,:]."""
+    _require_gpu(P, V, R)
+    n, np_, _ = P.shape
+    cc = V.shape[2]
+    assert P.is_contiguous() and V.is_contiguous() and R.is_contiguous() and P.dtype == V.dtype == R.dtype == torch.float32
+    lib = _lib.load()
+    _lib.check(lib.ps_rfm_apply(P.data_ptr(), V.data_ptr(), R.data_ptr(), n, np_, cc, _stream()), "ps_rfm_apply")
+
+
+def affinity_softmax_bwd_(P: Tensor, dR: Tensor, V: Tensor, R: Tensor) -> None:
+    _require_gpu(P, dR, V, R)
+    n, np_, _ = P.shape
+    assert all(t.is_contiguous() and t.dtype == torch.float32 for t in (P, dR, V, R))
+    lib = _lib.load()
+    _lib.check(lib.ps_affinity_softmax_bwd(P.data_ptr(), dR.data_ptr(), V.data_ptr(), R.data_ptr(), n, np_, V.shape[2], _stream()), "ps_affinity_softmax_bwd")
+
+
+def norm_cam(src: Tensor, src_layout: str, dst: Tensor, dst_strides, mode: int, label: Optional[Tensor] = None) -> None:
+    """dst (f32) <- normalised CAM; dst_strides = element strides over (sample, channel, pixel)."""
+    _require_gpu(src, dst)
+    a = _t4(src, src_layout)
+    assert dst.dtype == torch.float32
+    lib = _lib.load()
+    _lib.check(lib.ps_norm_cam(C.byref(a), dst.data_ptr(), *dst_strides, _ptr(label), mode, _stream()), "ps_norm_cam")
+
+
+def _loss_ws(dev) -> Tensor:
+    return torch.empty(int(_lib.load().ps_loss_workspace_floats()), device=dev, dtype=torch.float32)
+
+
+def l1_masked(a: Tensor, b: Tensor, label: Tensor, loss: Tensor, accumulate: bool, da=None, db=None, grad_scale: float = 1.0) -> None:
+    _require_gpu(a, b, label, loss)
+    n, c, h, w = a.shape
+    lib = _lib.load()
+    _lib.check(lib.ps_l1_masked(a.data_ptr(), b.data_ptr(), label.data_ptr(), _ptr(da), _ptr(db), loss.data_ptr(), int(accumulate), grad_scale,
+                                n, c, h, w, _loss_ws(a.device).data_ptr(), _stream()), "ps_l1_masked")
+
+
+def ecr_tensor(ref: Tensor, rv: Tensor, label: Tensor, out: Tensor) -> None:
+    _require_gpu(ref, rv, label, out)
+    n, c, h, w = rv.shape
+    lib = _lib.load()
+    _lib.check(lib.ps_ecr_tensor(ref.data_ptr(), rv.data_ptr(), label.data_ptr(), out.data_ptr(), n, c, h, w, _stream()), "ps_ecr_tensor")
+
+
+def ecr_bwd(ref, rv, label, t, thr, take, drv, grad_scale: float) -> None:
+    n, c, h, w = rv.shape
+    counter = torch.zeros(n, device=rv.device, dtype=torch.int32)
+    lib = _lib.load()
+    _lib.check(lib.ps_ecr_bwd(ref.data_ptr(), rv.data_ptr(), label.data_ptr(), t.data_ptr(), thr.data_ptr(), take.data_ptr(), counter.data_ptr(),
+                              drv.data_ptr(), grad_scale, n, c, h, w, _stream()), "ps_ecr_bwd")
+
+
+def topk_select(x: Tensor, k: int, largest: bool, relu: bool = False):
+    """x: [rows, len] f32 contiguous -> (thr[rows] f32, take[rows] i32, sums[rows] f32)."""
+    _require_gpu(x)
+    rows, length = x.shape
+    assert x.is_contiguous() and x.dtype == torch.float32
+    thr = torch.empty(rows, device=x.device, dtype=torch.float32)
+    take = torch.empty(rows, device=x.device, dtype=torch.int32)
+    sums = torch.empty(rows, device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.ps_topk_select(x.data_ptr(), rows, length, k, int(largest), int(relu), thr.data_ptr(), take.data_ptr(), sums.data_ptr(), _stream()), "ps_topk_select")
+    return thr, take, sums
+
+
+def sum_scaled(x: Tensor, scale: float, out: Tensor, accumulate: bool) -> None:
+    lib = _lib.load()
+    _lib.check(lib.ps_sum_scaled(x.data_ptr(), x.numel(), scale, out.data_ptr(), int(accumulate), _stream()), "ps_sum_scaled")
+
+
+def gap(x: Tensor) -> Tensor:
+    n, c, h, w = x.shape
+    out = torch.empty((n, c), device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.ps_gap(x.data_ptr(), out.data_ptr(), n * c, h * w, _stream()), "ps_gap")
+    return out
+
+
+def softmargin(gap_: Tensor, label: Tensor, loss: Tensor, accumulate: bool, want_grad: bool, grad_scale: float = 1.0):
+    n, c = gap_.shape
+    dgap = torch.empty_like(gap_) if want_grad else None
+    lib = _lib.load()
+    _lib.check(lib.ps_softmargin(gap_.data_ptr(), label.data_ptr(), _ptr(dgap), loss.data_ptr(), int(accumulate), grad_scale, n, c, _stream()), "ps_softmargin")
+    return dgap
+
+
+def gap_bwd(dgap: Tensor, dx: Tensor) -> None:
+    n, c, h, w = dx.shape
+    lib = _lib.load()
+    _lib.check(lib.ps_gap_bwd(dgap.data_ptr(), dx.data_ptr(), n * c, h * w, _stream()), "ps_gap_bwd")
+
+
+def chmax(x: Tensor, label: Tensor):
+    n, c, h, w = x.shape
+    m = torch.empty((n, h * w), device=x.device, dtype=torch.float32)
+    arg = torch.empty((n, h * w), device=x.device, dtype=torch.uint8)
+    lib = _lib.load()
+    _lib.check(lib.ps_chmax(x.data_ptr(), label.data_ptr(), m.data_ptr(), arg.data_ptr(), n, c, h, w, _stream()), "ps_chmax")
+    return m, arg
+
+
+def minpool_bwd(m, arg, label, thr, take, dx, grad_scale: float) -> None:
+    n, c, h, w = dx.shape
+    counter = torch.zeros(n, device=dx.device, dtype=torch.int32)
+    lib = _lib.load()
+    _lib.check(lib.ps_minpool_bwd(m.data_ptr(), arg.data_ptr(), label.data_ptr(), thr.data_ptr(), take.data_ptr(), counter.data_ptr(), dx.data_ptr(),
+                                  grad_scale, n, c, h, w, _stream()), "ps_minpool_bwd")

@@ -19,6 +19,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _lib, ops
+from .dist import BucketedAllReduce, plan_buckets
 from .resnet38d import UNITS
 from .seg_model import ResNet38dSeg
 
@@ -105,20 +106,11 @@ class SegTrainer:
         if self.pb_flat is not None:
             ops.cast_f32_bf16(self.p_flat, self.pb_flat)
         model.invalidate_weight_cache()
-        # all-reduce buckets: (unit name after which the bucket is final, start, end) over the arena
-        self.buckets: List[Tuple[str, int, int]] = []
+        # all-reduce buckets: (unit after which the bucket is final, start, end) over the arena
+        self.reducer: Optional[BucketedAllReduce] = None
         if self.world > 1:
-            limit = int(bucket_mb * (1 << 20) / 4)
-            start, last_unit = 0, None
-            for name, _ in self.entries:
-                unit = name.split(".")[0]
-                o, n = self.offsets[name]
-                if last_unit is not None and unit != last_unit and o - start >= limit:
-                    self.buckets.append((last_unit, start, o))
-                    start = o
-                last_unit = unit
-            self.buckets.append((last_unit, start, total))
-            self.comm_stream = torch.cuda.Stream(device=dev)
+            buckets = plan_buckets([(name, p.numel()) for name, p in self.entries], int(bucket_mb * (1 << 20) / 4))
+            self.reducer = BucketedAllReduce(self.g_flat, buckets, process_group)
         self.cm = torch.zeros(model.classes * model.classes, device=dev, dtype=torch.int64)  # train_iou confusion
 
     # ------------------------------------------------------------------
@@ -137,34 +129,17 @@ class SegTrainer:
             ops.confusion_accum(pred, mask, self.cm, model.classes)
         dw8 = self.grads["fc8.weight"].view(model.classes, 4096)
         g_x7 = model.head_backward(saved.conv6, drop.get("dropout7"), dlogits, dw8)
-        pending = []
-        bucket_iter = iter(self.buckets)
-        nxt = next(bucket_iter, None)
-
-        def after_unit(name: str):
-            nonlocal nxt
-            while nxt is not None and nxt[0] == name:
-                pending.append(self._launch_allreduce(nxt[1], nxt[2]))
-                nxt = next(bucket_iter, None)
-
-        model.backward_backbone(saved, g_x7, self.grads, after_unit=after_unit if self.world > 1 else None)
-        if self.world > 1:
-            while nxt is not None:  # buckets whose closing unit is frozen / not visited
-                pending.append(self._launch_allreduce(nxt[1], nxt[2]))
-                nxt = next(bucket_iter, None)
-            for w in pending:
-                w.wait()
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if self.reducer is not None:
+            self.reducer.begin_step()
+            self.reducer.on_unit_done("fc8")
+        model.backward_backbone(saved, g_x7, self.grads, after_unit=self.reducer.on_unit_done if self.reducer is not None else None)
+        if self.reducer is not None:
+            self.reducer.finish()
         self.step_count += 1
         ops.adamw_step(self.p_flat, self.g_flat, self.m_flat, self.v_flat, self.pb_flat, self.lr, self.betas, self.eps,
                        self.weight_decay, self.step_count)
         model.invalidate_weight_cache()
         return loss
-
-    def _launch_allreduce(self, start: int, end: int):
-        self.comm_stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.comm_stream):
-            return torch.distributed.all_reduce(self.g_flat[start:end], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True)
 
     def lr_scheduler_step(self, gamma: float = 0.9) -> None:
         """ExponentialLR(gamma=0.9) once per epoch (segmentation_module.py:88)."""
