@@ -147,6 +147,15 @@ int64_t ps_ce_workspace_floats(void);
 int ps_softmax_ce(const float* logits, const int64_t* target, float* loss_out, float* dlogits, float grad_scale,
                   int32_t n, int32_t c, int32_t h, int32_t w, int32_t ignore_index, float* partials, void* stream);
 
+/* Multiclass Dice loss over NCHW f32 logits (softmax inside), smp.losses.DiceLoss(mode='multiclass'[, ignore_index])
+ * as called by models/mosaic_module.py:65-68,108.  THIRD-PARTY arithmetic (segmentation-models-pytorch 0.3.0,
+ * not vendored): restated from its public definition, parity unpinned.  Per class over batch+space of the kept
+ * pixels: 1 - 2*sum(p*t)/max(sum(p+t), 1e-7), zeroed for classes absent from the target, mean over classes.
+ * workspace: >= ps_dice_workspace_floats() floats.  dlogits (optional) = grad_scale * d loss / d logits. */
+int64_t ps_dice_workspace_floats(void);
+int ps_dice_loss(const float* logits, const int64_t* target, float* loss_out, float* dlogits, float grad_scale, int32_t n,
+                 int32_t c, int32_t h, int32_t w, int32_t ignore_index, float* workspace, void* stream);
+
 /* CAM/logit -> mask reduction.  replaces: infer_revise_masks.py:137-143 (mode PS_MASK_MUL: argmax over
  * channels first_ch.. of x*label), infer_pseudo_masks.py:76-85 (mode PS_MASK_FILL: channels with label 0
  * are filled with -1e10, softmax, entropy = -sum p*log(p+1e-10), argmax of p; single-label tiles get the

@@ -75,6 +75,8 @@ PROTOTYPES = {
     "ps_bilinear_bwd": (C.c_int, [C.POINTER(Tensor4), C.POINTER(Tensor4), _I, _P]),
     "ps_ce_workspace_floats": (C.c_int64, []),
     "ps_softmax_ce": (C.c_int, [_P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P, _P]),
+    "ps_dice_workspace_floats": (C.c_int64, []),
+    "ps_dice_loss": (C.c_int, [_P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P, _P]),
     "ps_argmax_mask": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ps_confusion_accum": (C.c_int, [_P, _P, _P, _L, _I, _P]),
     "ps_adamw_step": (C.c_int, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),

@@ -162,6 +162,99 @@ __global__ __launch_bounds__(256) void ce_finish_kernel(const float* __restrict_
   if (threadIdx.x == 0) out[0] = ((red[0] + red[1]) + (red[2] + red[3])) * inv_total;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// multiclass Dice loss (smp.losses.DiceLoss(mode='multiclass', from_logits=True, smooth=0, eps=1e-7,
+// dims=(0,2)) as used by models/mosaic_module.py:65-68,108 -- third-party arithmetic, PARITY UNPINNED).
+// sums[0..C) = sum p*t, sums[C..2C) = sum (p + t), sums[2C..3C) = sum t   over kept pixels
+// ------------------------------------------------------------------------------------------------
+constexpr int DICE_BLOCKS = 512, DICE_MAXC = 8;
+__global__ __launch_bounds__(256) void dice_sums_kernel(const float* __restrict__ z, const long long* __restrict__ tgt, float* __restrict__ partials,
+                                                        int n, int c, long long hw, int ignore) {
+  __shared__ float red[4][3 * DICE_MAXC];
+  float acc[3 * DICE_MAXC];
+#pragma unroll
+  for (int i = 0; i < 3 * DICE_MAXC; ++i) acc[i] = 0.f;
+  const long long total = (long long)n * hw;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long img = i / hw, pix = i - img * hw;
+    const long long t = tgt[i];
+    if (t == ignore) continue;
+    const float* zp = z + img * c * hw + pix;
+    float mx = -INFINITY;
+    for (int k = 0; k < c; ++k) mx = fmaxf(mx, zp[k * hw]);
+    float se = 0.f;
+    for (int k = 0; k < c; ++k) se += expf(zp[k * hw] - mx);
+    const float lse = mx + logf(se);
+#pragma unroll
+    for (int k = 0; k < DICE_MAXC; ++k) {
+      if (k < c) {
+        const float p = expf(zp[k * hw] - lse), tt = (k == t) ? 1.f : 0.f;
+        acc[k] += p * tt;
+        acc[DICE_MAXC + k] += p + tt;
+        acc[2 * DICE_MAXC + k] += tt;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3 * DICE_MAXC; ++i) {
+    const float v = ps_wave_sum(acc[i]);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 * DICE_MAXC)
+    partials[blockIdx.x * 3 * DICE_MAXC + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(64) void dice_finish_kernel(const float* __restrict__ partials, int nparts, int c, float* __restrict__ sums,
+                                                         float* __restrict__ loss) {
+  __shared__ float s[3 * DICE_MAXC];
+  if (threadIdx.x < 3 * DICE_MAXC) {
+    float v = 0.f;
+    for (int b = 0; b < nparts; ++b) v += partials[b * 3 * DICE_MAXC + threadIdx.x];
+    s[threadIdx.x] = v;
+    sums[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float l = 0.f;
+    for (int k = 0; k < c; ++k) {
+      const float score = 2.f * s[k] / fmaxf(s[DICE_MAXC + k], 1e-7f);
+      l += (s[2 * DICE_MAXC + k] > 0.f) ? (1.f - score) : 0.f;
+    }
+    loss[0] = l / (float)c;
+  }
+}
+__global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__ z, const long long* __restrict__ tgt, const float* __restrict__ sums,
+                                                       float* __restrict__ dz, float gscale, int n, int c, long long hw, int ignore) {
+  const long long total = (long long)n * hw;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long img = i / hw, pix = i - img * hw;
+    const long long t = tgt[i];
+    const float* zp = z + img * c * hw + pix;
+    float* dp = dz + img * c * hw + pix;
+    if (t == ignore) {
+      for (int k = 0; k < c; ++k) dp[k * hw] = 0.f;
+      continue;
+    }
+    float mx = -INFINITY;
+    for (int k = 0; k < c; ++k) mx = fmaxf(mx, zp[k * hw]);
+    float se = 0.f;
+    for (int k = 0; k < c; ++k) se += expf(zp[k * hw] - mx);
+    const float lse = mx + logf(se);
+    float p[DICE_MAXC], g[DICE_MAXC];
+    float dot = 0.f;
+    for (int k = 0; k < c; ++k) {
+      p[k] = expf(zp[k * hw] - lse);
+      const float I = sums[k], S = sums[DICE_MAXC + k], T = sums[2 * DICE_MAXC + k];
+      float gk = 0.f;
+      if (T > 0.f && S > 1e-7f) gk = (-2.f * ((k == t) ? 1.f : 0.f) / S + 2.f * I / (S * S)) / (float)c;
+      g[k] = gk;
+      dot += p[k] * gk;
+    }
+    for (int k = 0; k < c; ++k) dp[k * hw] = gscale * p[k] * (g[k] - dot);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // CAM / logit -> mask
 // ------------------------------------------------------------------------------------------------
@@ -291,6 +384,29 @@ extern "C" int ps_softmax_ce(const float* logits, const int64_t* target, float* 
   PS_CHECK_LAUNCH("softmax_ce");
   hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, s, partials, grid, 1.f / (float)total, loss_out);
   PS_CHECK_LAUNCH("softmax_ce_finish");
+  return PS_OK;
+}
+
+extern "C" int64_t ps_dice_workspace_floats(void) { return DICE_BLOCKS * 3 * DICE_MAXC + 3 * DICE_MAXC; }
+
+extern "C" int ps_dice_loss(const float* logits, const int64_t* target, float* loss_out, float* dlogits, float grad_scale, int32_t n,
+                            int32_t c, int32_t h, int32_t w, int32_t ignore_index, float* workspace, void* stream) {
+  PS_REQUIRE(logits && target && loss_out && workspace, "dice_loss: null argument");
+  PS_REQUIRE(n > 0 && c > 0 && c <= DICE_MAXC && h > 0 && w > 0, "dice_loss: bad shape (C <= %d)", DICE_MAXC);
+  const long long hw = (long long)h * w, total = (long long)n * hw;
+  const int grid = grid_for(total, 256 * 4, DICE_BLOCKS);
+  float* sums = workspace + (long long)DICE_BLOCKS * 3 * DICE_MAXC;
+  const int ign = ignore_index < 0 ? -1 : ignore_index;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(dice_sums_kernel, dim3(grid), dim3(256), 0, s, logits, (const long long*)target, workspace, n, c, hw, ign);
+  PS_CHECK_LAUNCH("dice_sums");
+  hipLaunchKernelGGL(dice_finish_kernel, dim3(1), dim3(64), 0, s, workspace, grid, c, sums, loss_out);
+  PS_CHECK_LAUNCH("dice_finish");
+  if (dlogits) {
+    hipLaunchKernelGGL(dice_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, logits, (const long long*)target, sums, dlogits, grad_scale, n, c,
+                       hw, ign);
+    PS_CHECK_LAUNCH("dice_bwd");
+  }
   return PS_OK;
 }
 

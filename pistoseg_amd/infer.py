@@ -1,0 +1,61 @@
+"""Inference reductions of stages 2 and 4 (CAM / logit -> mask), sharded over ranks by contiguous tile ranges.
+
+stage 2 (infer_pseudo_masks.py:116-154): logits -> bilinear(align_corners=False) to 32x32 (`logits_32x32/*.pt`) and
+`get_mask_pred_and_entropy` (absent classes filled with -1e10, softmax, entropy, argmax, tissue==0 -> index C).
+stage 4 (infer_revise_masks.py:115-143): (X_rv * label)[:, 1:] -> argmax for pmask_rv, pcam_rv, cam_rv.
+PNG / palette / resize post-processing stays host-side I/O (out of scope).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib, ops
+from .dist import shard_range
+
+Tensor = torch.Tensor
+
+
+def interpolate_tensor(logits: Tensor, target_shape=(32, 32)) -> Tensor:
+    """Batched form of infer_pseudo_masks.py:89-90: [N,C,H,W] f32 -> [N,C,h,w] f32, bilinear align_corners=False."""
+    n, c = logits.shape[:2]
+    out = torch.empty((n, c) + tuple(target_shape), device=logits.device, dtype=torch.float32)
+    ops.bilinear_fwd(logits.contiguous(), "nchw", out, "nchw", False)
+    return out
+
+
+def get_mask_pred_and_entropy(logits: Tensor, tissue: Optional[Tensor], patch_label: Tensor):
+    """Batched form of infer_pseudo_masks.py:69-87.  logits [N,C,H,W] f32, tissue uint8 [N,H,W] (0 = background),
+    patch_label [N,C] in {0,1}.  Returns (mask uint8 [N,H,W], entropy f32 [N,H,W])."""
+    return ops.argmax_mask(logits.contiguous(), mode=_lib.PS_MASK_FILL, label=patch_label, tissue=tissue, want_entropy=True)
+
+
+@torch.no_grad()
+def infer_pseudo_masks(model, images: Tensor, patch_label: Tensor, tissue: Optional[Tensor] = None, batch_size: int = 64,
+                       rank: int = 0, world: int = 1):
+    """Stage 2 over this rank's contiguous shard of `images` ([T,3,H,W], host or device).  Returns
+    (lo, hi, logits_32x32 [t,C,32,32], mask uint8 [t,H,W], entropy [t,H,W])."""
+    dev = next(model.parameters()).device
+    lo, hi = shard_range(images.shape[0], rank, world)
+    small, masks, ents = [], [], []
+    model.eval()
+    for s in range(lo, hi, batch_size):
+        e = min(hi, s + batch_size)
+        x = images[s:e].to(dev, non_blocking=True)
+        logits = model(x)
+        small.append(interpolate_tensor(logits))
+        m, en = get_mask_pred_and_entropy(logits, None if tissue is None else tissue[s:e].to(dev), patch_label[s:e].to(dev))
+        masks.append(m)
+        ents.append(en)
+    cat = lambda xs: torch.cat(xs, 0) if xs else None
+    return lo, hi, cat(small), cat(masks), cat(ents)
+
+
+@torch.no_grad()
+def infer_revise_masks(model, x: Tensor, pmask: Tensor, pcam: Tensor, label: Tensor):
+    """Stage 4 for one batch.  label: [N, C] with the background score prepended.  Returns uint8 masks
+    (pmask_rv_mask, pcam_rv_mask, cam_rv_mask), each [N,H,W] with values in 0..C-2."""
+    _, cam_rv, pmask_rv, pcam_rv = model(x, pmask, pcam)
+    lab = label.reshape(x.shape[0], -1).to(cam_rv.device)
+    return tuple(ops.argmax_mask(t, mode=_lib.PS_MASK_MUL, first_ch=1, label=lab) for t in (pmask_rv, pcam_rv, cam_rv))

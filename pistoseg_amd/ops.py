@@ -252,6 +252,23 @@ def softmax_ce(logits: Tensor, target: Tensor, ignore_index: Optional[int], want
     return loss, dlogits
 
 
+def dice_loss(logits: Tensor, target: Tensor, ignore_index: Optional[int], want_grad: bool, grad_scale: float = 1.0):
+    """smp-style multiclass Dice (MosaicModule.training_step).  Returns (loss[1] f32, dlogits or None)."""
+    _require_gpu(logits, target)
+    n, c, h, w = logits.shape
+    assert logits.is_contiguous() and logits.dtype == torch.float32 and target.dtype == torch.int64 and target.is_contiguous()
+    lib = _lib.load()
+    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    ws = torch.empty(int(lib.ps_dice_workspace_floats()), device=logits.device, dtype=torch.float32)
+    dlogits = torch.empty_like(logits) if want_grad else None
+    _lib.check(
+        lib.ps_dice_loss(logits.data_ptr(), target.data_ptr(), loss.data_ptr(), _ptr(dlogits), float(grad_scale), n, c, h, w,
+                         -1 if ignore_index is None else int(ignore_index), ws.data_ptr(), _stream()),
+        "ps_dice_loss",
+    )
+    return loss, dlogits
+
+
 def argmax_mask(x: Tensor, *, mode: int = _lib.PS_MASK_PLAIN, softmax_first: bool = False, first_ch: int = 0, label: Optional[Tensor] = None,
                 tissue: Optional[Tensor] = None, want_entropy: bool = False):
     """NCHW f32 scores -> uint8 mask [N,H,W] (+ optional f32 entropy)."""

@@ -1,0 +1,103 @@
+"""`SegmentationModule` / `MosaicModule` -- mirrors of the reference's Lightning shells
+(models/segmentation_module.py:53-127, models/mosaic_module.py:59-141) around the MI355X ResNet38-d model.
+
+Same constructor (`args` Namespace with `patch_size, num_classes, dataset, model, encoder, lr, weight_decay, tta, ...`),
+`forward`, `training_step(batch, idx) -> loss`, `configure_optimizers() -> ([AdamW], [ExponentialLR(0.9)])`,
+`load_from_checkpoint`, and checkpoint layout (`state_dict` keys `model.*`, `hyper_parameters['args']`).  The model
+plug point is `create_model(args.model, encoder_name=args.encoder, in_channels=3, classes=args.num_classes)`
+(the `smp.create_model` call site, segmentation_module.py:72-81) with `--model ResNet38d`.
+Losses run as fused HIP kernels attached to autograd by a one-node Function, so Lightning's `loss.backward()` works.
+"""
+from __future__ import annotations
+
+import torch
+from torch.optim import AdamW
+from torch.optim.lr_scheduler import ExponentialLR
+
+from . import ops
+from .lightning_shim import LightningModule
+from .metrics import mIoUMask
+from .seg_model import create_model
+
+
+class _PixelLoss(torch.autograd.Function):
+    """loss = kernel(logits, target); the fused kernel already produced d loss / d logits."""
+
+    @staticmethod
+    def forward(ctx, logits, target, kind, ignore_index):
+        fn = ops.softmax_ce if kind == "ce" else ops.dice_loss
+        loss, dlogits = fn(logits.contiguous().float(), target.contiguous(), ignore_index, want_grad=True)
+        ctx.save_for_backward(dlogits)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * g, None, None, None
+
+
+def pixel_ce_mean(logits, target, ignore_index):
+    """torch.mean(nn.CrossEntropyLoss(reduction='none'[, ignore_index])(logits, target)) -- segmentation_module.py:63-66,101-102."""
+    return _PixelLoss.apply(logits, target, "ce", ignore_index)
+
+
+def dice_multiclass(logits, target, ignore_index):
+    """smp DiceLoss(mode='multiclass'[, ignore_index]) -- mosaic_module.py:65-68 (third-party definition, parity unpinned)."""
+    return _PixelLoss.apply(logits, target, "dice", ignore_index)
+
+
+class _Shell(LightningModule):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.patch_size = getattr(args, "patch_size", 224)
+        self.train_iou = mIoUMask(num_classes=args.num_classes)
+        self.valid_iou = mIoUMask(num_classes=args.num_classes)
+        self.test_iou = mIoUMask(num_classes=args.num_classes)
+        self.model = create_model(args.model, encoder_name=getattr(args, "encoder", None), in_channels=3, classes=args.num_classes,
+                                  precision=getattr(args, "precision", "bf16"))
+        self.save_hyperparameters()
+
+    def configure_optimizers(self):
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        optimizer = AdamW(params, self.args.lr, weight_decay=self.args.weight_decay)
+        scheduler = ExponentialLR(optimizer, gamma=0.9)
+        return [optimizer], [scheduler]
+
+    def forward(self, x):
+        return self.model(x)
+
+    def training_epoch_end(self, training_step_outputs=None):
+        self.log("train_miou_epoch", self.train_iou.Mean_Intersection_over_Union())
+        self.log("train_fwiou_epoch", self.train_iou.Frequency_Weighted_Intersection_over_Union())
+        self.train_iou.reset()
+
+
+class SegmentationModule(_Shell):
+    def __init__(self, args):
+        super().__init__(args)
+        self.retrain_iteration = 0
+        self.ignore_index = 3 if args.dataset == "wsss4luad" else None  # segmentation_module.py:63-66
+
+    def training_step(self, batch, batch_idx):
+        mask_pred = self.model(batch["image"])
+        loss = pixel_ce_mean(mask_pred, batch["mask"], self.ignore_index)
+        self.log("train_loss", loss, prog_bar=True)
+        self.train_iou(mask_pred, batch["mask"])
+        self.log("train_miou", self.train_iou.Mean_Intersection_over_Union(), prog_bar=True)
+        return loss
+
+
+class MosaicModule(_Shell):
+    def __init__(self, args):
+        super().__init__(args)
+        self.ignore_index = args.num_classes if args.dataset == "wsss4luad" else None  # mosaic_module.py:65-68
+        self.parameter = None
+
+    def training_step(self, batch, batch_idx):
+        mask_pred = self(batch["image"])
+        loss = dice_multiclass(mask_pred, batch["mask"], self.ignore_index)
+        self.log("train_loss", loss, prog_bar=True)
+        self.train_iou(mask_pred, batch["mask"])
+        self.log("train_miou_epoch", self.train_iou.Mean_Intersection_over_Union(), prog_bar=True)
+        return loss

@@ -1,0 +1,150 @@
+"""Module shells, checkpoint layout, optimisers and inference reductions on the GPU."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_cpu
+from oracle.make_golden import make_inputs, with_bg
+
+pytestmark = pytest.mark.gpu
+D = torch.device("cuda:0")
+
+
+def make_args(**kw):
+    base = dict(patch_size=64, num_classes=3, dataset="wsss4luad", model="ResNet38d", encoder="resnet38d", lr=1e-3, weight_decay=0.05,
+                tta=False, log_path="/tmp", precision="fp32")
+    base.update(kw)
+    return argparse.Namespace(**base)
+
+
+def test_segmentation_module_training_step_and_checkpoint(tmp_path):
+    from pistoseg_amd.segmentation_module import SegmentationModule
+
+    args = make_args()
+    mod = SegmentationModule(args).to(D)
+    sd = ref_cpu.make_state_dict(3, False, seed=42)
+    mod.model.load_state_dict(sd, strict=True)
+    mod.model.eval()  # deterministic (dropout off) for the oracle comparison
+    x, *_ = make_inputs(2, 64, 4, 108)
+    target = torch.randint(0, 4, (2, 64, 64), generator=torch.Generator().manual_seed(1))
+    loss = mod.training_step({"image": x.to(D), "mask": target.to(D), "label": None}, 0)
+    ref = ref_cpu.seg_ce_loss(ref_cpu.seg_forward(sd, x), target, 3)
+    assert abs(float(loss) - float(ref)) < 1e-4 * abs(float(ref))
+    loss.backward()  # what Lightning does
+    assert mod.model.fc8.weight.grad is not None and float(mod.model.fc8.weight.grad.abs().sum()) > 0
+    (opt,), (sched,) = mod.configure_optimizers()
+    assert isinstance(opt, torch.optim.AdamW) and sched.gamma == 0.9
+    opt.step()
+    # train_iou confusion matrix equals the oracle's (loss.py:16-26 semantics)
+    pred = ref_cpu.logits_to_mask(ref_cpu.seg_forward(sd, x)).numpy()
+    cm = ref_cpu.confusion_matrix(pred, target.numpy().astype(np.uint8), 3)
+    assert np.array_equal(mod.train_iou.confusion_matrix, cm)
+    # Lightning checkpoint layout: 'epoch=' in the file name, state_dict under model.*, hyper_parameters['args']
+    path = mod.save_checkpoint(str(tmp_path), epoch=3, metric=0.5)
+    assert "epoch=" in os.path.basename(path)
+    ckpt = torch.load(path, weights_only=False)
+    assert all(k.startswith("model.") for k in ckpt["state_dict"]) and ckpt["hyper_parameters"]["args"].num_classes == 3
+    again = SegmentationModule.load_from_checkpoint(path).to(D)
+    for (k1, v1), (k2, v2) in zip(mod.state_dict().items(), again.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1.cpu(), v2.cpu())
+
+
+def test_mosaic_module_dice_matches_oracle_definition():
+    from pistoseg_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    logits = (torch.randn(2, 3, 40, 36, generator=g) * 2).requires_grad_(True)
+    target = torch.randint(0, 4, (2, 40, 36), generator=g)
+    target[target == 1] = 0  # a class absent from the target
+    ref = ref_cpu.dice_loss_multiclass(logits, target, ignore_index=3)
+    ref.backward()
+    loss, dl = ops.dice_loss(logits.detach().to(D), target.to(D), 3, want_grad=True)
+    assert abs(float(loss) - float(ref)) < 1e-5
+    assert float((dl.cpu() - logits.grad).abs().max()) < 1e-6 + 1e-4 * float(logits.grad.abs().max())
+
+
+def test_poly_optimizer_matches_reference_golden(golden_dir):
+    from pistoseg_amd.optim import PolyOptimizer
+
+    g = np.load(os.path.join(golden_dir, "poly_optimizer.npz"))
+    p0 = torch.nn.Parameter(torch.from_numpy(g["p0_init"].copy()).to(D))
+    p1 = torch.nn.Parameter(torch.from_numpy(g["p1_init"].copy()).to(D))
+    opt = PolyOptimizer([{"params": [p0], "lr": 0.01, "weight_decay": 5e-4}, {"params": [p1], "lr": 0.1, "weight_decay": 0}],
+                        lr=0.01, weight_decay=5e-4, max_step=4)
+    assert [opt.param_groups[0]["momentum"], opt.param_groups[0]["weight_decay"]] == g["group0"].tolist()
+    for step in range(6):
+        p0.grad = torch.from_numpy(g[f"g0_step{step}"].copy()).to(D)
+        p1.grad = torch.from_numpy(g[f"g1_step{step}"].copy()).to(D)
+        opt.step()
+        np.testing.assert_allclose(p0.detach().cpu().numpy(), g[f"p0_step{step}"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(p1.detach().cpu().numpy(), g[f"p1_step{step}"], rtol=1e-6, atol=1e-7)
+
+
+def test_stage2_and_stage4_inference_reductions(golden_dir):
+    from pistoseg_amd import infer
+    from pistoseg_amd.revise_net import Net
+
+    g = np.load(os.path.join(golden_dir, "helpers.npz"))
+    for s in (224, 256):  # K9: logits -> 32x32, align_corners=False
+        out = infer.interpolate_tensor(torch.from_numpy(g[f"interp_in_{s}"])[None].to(D))
+        np.testing.assert_allclose(out.cpu().numpy()[0], g[f"interp_out_{s}"], rtol=1e-6, atol=1e-6)
+    # stage 4 through the model, against the reference golden masks
+    gm = np.load(os.path.join(golden_dir, "revise_s64_c4.npz"))
+    sd = ref_cpu.make_state_dict(4, True, seed=42)
+    model = Net(4, "fp32")
+    model.load_state_dict(sd)
+    model = model.to(D)
+    model.eval()
+    x, pmask, pcam, lab = make_inputs(2, 64, 4, 101)
+    pm, pc, label = with_bg(pmask, pcam, lab)
+    masks = infer.infer_revise_masks(model, x.to(D), pm.to(D), pc.to(D), label)
+    for name, m in zip(("pmask_rv_mask", "pcam_rv_mask", "cam_rv_mask"), masks):
+        agree = float((m.cpu().numpy() == gm[name]).mean())
+        assert agree > 0.9995, (name, agree)  # bit-exact up to f32 ties (checked strictly in test_rfm_gpu)
+
+
+def test_seg_trainer_step_matches_autograd_path_and_torch_adamw():
+    """The native step (flat arenas, fused AdamW) equals autograd path + torch.optim.AdamW after 2 steps."""
+    from pistoseg_amd import ops
+    from pistoseg_amd.seg_model import ResNet38dSeg
+    from pistoseg_amd.trainer import SegTrainer
+
+    sd = ref_cpu.make_state_dict(3, False, seed=42)
+    x, *_ = make_inputs(2, 64, 4, 109)
+    target = torch.randint(0, 4, (2, 64, 64), generator=torch.Generator().manual_seed(2))
+    drops = None
+    results = []
+    for native in (True, False):
+        model = ResNet38dSeg(3, "fp32")
+        model.load_state_dict(sd)
+        model = model.to(D)
+        model.train()
+        if drops is None:
+            drops = [model.sample_dropout(2, D) for _ in range(2)]
+        it = iter(drops)
+        model.sample_dropout = lambda n_, dev_: next(it)
+        if native:
+            tr = SegTrainer(model, lr=1e-3, weight_decay=0.05, ignore_index=3)
+            losses = [float(tr.train_step(x.to(D), target.to(D))) for _ in range(2)]
+        else:
+            opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3, weight_decay=0.05)
+            losses = []
+            for _ in range(2):
+                opt.zero_grad()
+                logits = model(x.to(D))
+                loss, dl = ops.softmax_ce(logits.detach(), target.to(D), 3, want_grad=True)
+                logits.backward(dl)
+                opt.step()
+                losses.append(float(loss))
+        results.append((losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}))
+    (l1, s1), (l2, s2) = results
+    assert abs(l1[0] - l2[0]) < 1e-6 and abs(l1[1] - l2[1]) < 2e-4 * abs(l2[1])
+    for k in s1:
+        if s1[k].is_floating_point():
+            # Adam's first steps move every weight by ~lr*sign(g): elements with |g| at the f32 noise floor (atomic
+            # summation order) may differ by a fraction of one update; bound = 10% of the two updates
+            assert float((s1[k] - s2[k]).abs().max()) <= 0.1 * 2 * 1e-3, k
