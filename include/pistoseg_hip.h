@@ -245,9 +245,15 @@ int ps_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, in
 int ps_sgd_step(float* p, const float* g, float* buf, void* p_bf16, int64_t n, float lr, float momentum,
                 float weight_decay, int32_t first_step, void* stream);
 
-/* Testing hook: 1 (default) stages conv operands with LDS-DMA (global_load_lds), 0 through registers.
- * Both variants compute identical results; the tests run the parity suite over both. */
+/* Testing hook: how conv operands are staged into LDS: 2 (default) LDS-DMA through buffer descriptors
+ * (buffer_load ... lds; padding rows are out-of-range lanes, which the DMA zero-fills), 1 LDS-DMA with flat
+ * addresses (global_load_lds; padding rows read a zero page), 0 through registers.  All variants compute identical
+ * results; the tests run the parity suite over all of them. */
 void ps_debug_set_glds(int on);
+/* Testing hook: 1 lets large problems use the experimental 256x128 three-stage kernel; 0 (default) uses the 128-pixel kernels. */
+void ps_debug_set_3stage(int on);
+/* Testing hook: 64 / 128 force the cout-tile width of the 2-stage conv kernel, 0 (default) picks by problem size. */
+void ps_debug_set_bn(int bn);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,8 @@ struct IgemmArgs {
   long long wrow_bytes;       // taps*Cs*esize
   int ntn;                    // number of cout tiles
   int Cd;                     // produced channels
+  unsigned src_bytes;         // extent of the gathered tensor / of the weights (buffer descriptors' num_records)
+  unsigned wgt_bytes;
   ps_epilogue epi;
 };
 
@@ -64,147 +66,19 @@ __device__ __forceinline__ void store16(T* p, const float* v) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),               \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-template <typename Tr, int BN, bool GLDS>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
-  typedef typename Tr::elem T;
-  constexpr int BM = 128;
-  constexpr int WM = (BN == 128) ? 64 : 32;  // pixels per wave
-  constexpr int MI = WM / 16;                // pixel fragments per wave
-  constexpr int BROWS = BN / 32;             // weight rows staged per lane
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// LDS-DMA through a buffer descriptor: 32-bit per-lane offset + scalar offset; an out-of-range lane (padding row,
+// offset 0x80000000) makes the DMA write ZEROS into LDS (checked on gfx950: tools/probe_oob.hip).
+#define BLDS16(rsrc, lptr, voff, soff)                                                                  \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(lptr), 16, (int)(voff), (int)(soff), 0, 0)
+constexpr unsigned PAD_ROW = 0x80000000u;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bid = ps_xcd_remap(blockIdx.x, gridDim.x);
-  const int tn = bid % a.ntn, tm = bid / a.ntn;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int wm = (BN == 128) ? (wave >> 1) : wave;
-  const int wn = (BN == 128) ? (wave & 1) : 0;
-
-  // ---------------- staging state ----------------
-  // pixel rows: LDS row R = wave*32 + j*8 + (lane>>3); the lane moves source chunk (lane&7)^(R&7) to position lane&7
-  const int srow = lane >> 3;
-  const int chunk_off = ((lane & 7) ^ srow) << 4;
-  int py[4], px[4], nb[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = m0 + wave * 32 + j * 8 + srow;
-    if (m < a.M) {
-      const int hw = a.Ho * a.Wo;
-      const int n = m / hw, rem = m - n * hw;
-      const int p = rem / a.Wo, q = rem - p * a.Wo;
-      py[j] = p * a.mul;
-      px[j] = q * a.mul;
-      nb[j] = n * a.Hs * a.Ws;
-    } else {
-      py[j] = -(1 << 20);  // never valid
-      px[j] = 0;
-      nb[j] = 0;
-    }
-  }
-  // weight rows: LDS row Rb = wave*(BN/4) + j*8 + (lane>>3) holds cout n0 + 64*(Rb>>6) + perm(Rb&63), where
-  // perm(16*i + rho) = 16*(rho>>2) + 4*i + (rho&3)  (so that accumulator register r of fragment i, lane
-  // group g is cout 16*g + 4*i + r: 16 contiguous couts per lane)
-  const unsigned char* wptr[BROWS];
-#pragma unroll
-  for (int j = 0; j < BROWS; ++j) {
-    const int rb = wave * (BN / 4) + j * 8 + srow;
-    const int within = rb & 63, fi = within >> 4, rho = within & 15;
-    const int cout = n0 + (rb & ~63) + 16 * (rho >> 2) + 4 * fi + (rho & 3);
-    wptr[j] = a.wgt + (long long)cout * a.wrow_bytes + chunk_off;
-  }
-  const unsigned char* aptr[4];
-  int tap = 0, kl = 0;
-  long long wk = 0;  // running K byte offset in a weight row
-
-  auto tap_pointers = [&](int t) {
-    const int ty = (a.taps == 1) ? a.ctr : t / 3, tx = (a.taps == 1) ? a.ctr : t - (t / 3) * 3;
-    const int dy = (ty - a.ctr) * a.dstep, dx = (tx - a.ctr) * a.dstep;
-    const int dmask = (1 << a.div_shift) - 1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int yn = py[j] + dy, xn = px[j] + dx;
-      const int y = yn >> a.div_shift, x = xn >> a.div_shift;
-      const bool ok = (yn >= 0) && (xn >= 0) && (((yn | xn) & dmask) == 0) && (y < a.Hs) && (x < a.Ws);
-      aptr[j] = ok ? a.src + (long long)(nb[j] + y * a.Ws + x) * a.pix_bytes + chunk_off : nullptr;
-    }
-  };
-  tap_pointers(0);
-
-  u32x4 ra[4], rb_[BROWS];  // register staging (GLDS == false)
-  auto stage_issue = [&](int buf) {
-    unsigned char* sa = smem + buf * STAGE + (wave * 32) * 128 + lane * 16;
-    unsigned char* sb = smem + buf * STAGE + A_BYTES + (wave * (BN / 4)) * 128 + lane * 16;
-    const long long ko = (long long)kl * 128;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned char* g = aptr[j] ? aptr[j] + ko : g_zero_line + (lane & 7) * 16;
-      if constexpr (GLDS) GLDS16(g, sa + j * 1024 - lane * 16);
-      else ra[j] = *reinterpret_cast<const u32x4*>(g);
-    }
-#pragma unroll
-    for (int j = 0; j < BROWS; ++j) {
-      const unsigned char* g = wptr[j] + wk;
-      if constexpr (GLDS) GLDS16(g, sb + j * 1024 - lane * 16);
-      else rb_[j] = *reinterpret_cast<const u32x4*>(g);
-    }
-    wk += 128;
-    if (++kl == a.klines) {
-      kl = 0;
-      if (++tap < a.taps) tap_pointers(tap);
-    }
-  };
-  auto stage_commit = [&](int buf) {  // register staging only: registers -> LDS
-    if constexpr (!GLDS) {
-      unsigned char* sa = smem + buf * STAGE + (wave * 32) * 128 + lane * 16;
-      unsigned char* sb = smem + buf * STAGE + A_BYTES + (wave * (BN / 4)) * 128 + lane * 16;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(sa + j * 1024) = ra[j];
-#pragma unroll
-      for (int j = 0; j < BROWS; ++j) *reinterpret_cast<u32x4*>(sb + j * 1024) = rb_[j];
-    }
-  };
-
-  // ---------------- accumulate ----------------
-  f32x4 acc[MI][4];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[mi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
+// Epilogue shared by the conv kernels: lane (frow = lane&15, g = lane>>4) owns pixels mbase + mi*16 + frow and the 16
+// contiguous produced channels cbase + 16*g .. +15 (acc[mi][i][r] = channel 4*i + r of that group).
+template <typename T, int MI>
+__device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[MI][4], int mbase, int cbase, int lane) {
   const int frow = lane & 15, g = lane >> 4;
-  const int nsteps = a.taps * a.klines;
-  // fragment byte offsets inside a stage (row&7 == lane&7 for both operands)
-  const int xoff = (wm * WM + frow) * 128, woff = A_BYTES + (wn * 64 + frow) * 128;
-  const int sw = lane & 7;
-
-  stage_issue(0);
-  stage_commit(0);
-  __syncthreads();
-  for (int s = 0; s < nsteps; ++s) {
-    const int cur = s & 1;
-    if (s + 1 < nsteps) stage_issue(cur ^ 1);
-    const unsigned char* st = smem + cur * STAGE;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int coff = ((g + 4 * kk) ^ sw) << 4;
-      u32x4 wf[4], xf[MI];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const u32x4*>(st + woff + i * 2048 + coff);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) xf[mi] = *reinterpret_cast<const u32x4*>(st + xoff + mi * 2048 + coff);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Tr::mma(wf[i], xf[mi], acc[mi][i]);
-    }
-    if (s + 1 < nsteps) stage_commit(cur ^ 1);
-    __syncthreads();
-  }
-
-  // ---------------- epilogue ----------------
   const ps_epilogue& e = a.epi;
-  const int cb = n0 + wn * 64 + 16 * g;  // this lane's 16 contiguous produced channels
+  const int cb = cbase + 16 * g;
   float sc[16], sh[16];
   if (e.mode != PS_EPI_NONE) {
 #pragma unroll
@@ -215,7 +89,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
   }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
-    const int m = m0 + wm * WM + mi * 16 + frow;
+    const int m = mbase + mi * 16 + frow;
     if (m >= a.M) continue;
     float v[16];
 #pragma unroll
@@ -259,16 +133,300 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
   }
 }
 
-static int g_use_glds = 1;
+template <typename Tr, int BN, int STG>  // STG: 0 registers, 1 global_load_lds, 2 buffer_load...lds (default)
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
+  typedef typename Tr::elem T;
+  constexpr int BM = 128;
+  constexpr int WM = (BN == 128) ? 64 : 32;  // pixels per wave
+  constexpr int MI = WM / 16;                // pixel fragments per wave
+  constexpr int BROWS = BN / 32;             // weight rows staged per lane
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bid = ps_xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = bid % a.ntn, tm = bid / a.ntn;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int wm = (BN == 128) ? (wave >> 1) : wave;
+  const int wn = (BN == 128) ? (wave & 1) : 0;
+
+  // ---------------- staging state ----------------
+  // pixel rows: LDS row R = wave*32 + j*8 + (lane>>3); the lane moves source chunk (lane&7)^(R&7) to position lane&7
+  const int srow = lane >> 3;
+  const int chunk_off = ((lane & 7) ^ srow) << 4;
+  int py[4], px[4], nb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + wave * 32 + j * 8 + srow;
+    if (m < a.M) {
+      const int hw = a.Ho * a.Wo;
+      const int n = m / hw, rem = m - n * hw;
+      const int p = rem / a.Wo, q = rem - p * a.Wo;
+      py[j] = p * a.mul;
+      px[j] = q * a.mul;
+      nb[j] = n * a.Hs * a.Ws;
+    } else {
+      py[j] = -(1 << 20);  // never valid
+      px[j] = 0;
+      nb[j] = 0;
+    }
+  }
+  // weight rows: LDS row Rb = wave*(BN/4) + j*8 + (lane>>3) holds cout n0 + 64*(Rb>>6) + perm(Rb&63), where
+  // perm(16*i + rho) = 16*(rho>>2) + 4*i + (rho&3)  (so that accumulator register r of fragment i, lane
+  // group g is cout 16*g + 4*i + r: 16 contiguous couts per lane)
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, (int)a.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, 0, (int)a.wgt_bytes, 0x00020000);
+  unsigned woff[BROWS];
+#pragma unroll
+  for (int j = 0; j < BROWS; ++j) {
+    const int rb = wave * (BN / 4) + j * 8 + srow;
+    const int within = rb & 63, fi = within >> 4, rho = within & 15;
+    const int cout = n0 + (rb & ~63) + 16 * (rho >> 2) + 4 * fi + (rho & 3);
+    woff[j] = (unsigned)(cout * a.wrow_bytes) + chunk_off;
+  }
+  unsigned aoff[4];  // byte offset of each pixel row for the current tap, PAD_ROW if the tap falls outside
+  int tap = 0, kl = 0;
+  int wk = 0;  // running K byte offset in a weight row
+
+  auto tap_offsets = [&](int t) {
+    const int ty = (a.taps == 1) ? a.ctr : t / 3, tx = (a.taps == 1) ? a.ctr : t - (t / 3) * 3;
+    const int dy = (ty - a.ctr) * a.dstep, dx = (tx - a.ctr) * a.dstep;
+    const int dmask = (1 << a.div_shift) - 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int yn = py[j] + dy, xn = px[j] + dx;
+      const int y = yn >> a.div_shift, x = xn >> a.div_shift;
+      const bool ok = (yn >= 0) && (xn >= 0) && (((yn | xn) & dmask) == 0) && (y < a.Hs) && (x < a.Ws);
+      aoff[j] = ok ? (unsigned)((nb[j] + y * a.Ws + x) * (int)a.pix_bytes) + chunk_off : PAD_ROW;
+    }
+  };
+  tap_offsets(0);
+
+  u32x4 ra[4], rb_[BROWS];  // register staging (STG == 0)
+  auto stage_issue = [&](int buf) {
+    unsigned char* sa = smem + buf * STAGE + (wave * 32) * 128;
+    unsigned char* sb = smem + buf * STAGE + A_BYTES + (wave * (BN / 4)) * 128;
+    const int ko = kl * 128;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (STG == 2) BLDS16(rsA, sa + j * 1024, aoff[j], ko);
+      else {
+        const unsigned char* g = aoff[j] != PAD_ROW ? a.src + aoff[j] + ko : g_zero_line + (lane & 7) * 16;
+        if constexpr (STG == 1) GLDS16(g, sa + j * 1024);
+        else ra[j] = *reinterpret_cast<const u32x4*>(g);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < BROWS; ++j) {
+      if constexpr (STG == 2) BLDS16(rsB, sb + j * 1024, woff[j], wk);
+      else {
+        const unsigned char* g = a.wgt + woff[j] + wk;
+        if constexpr (STG == 1) GLDS16(g, sb + j * 1024);
+        else rb_[j] = *reinterpret_cast<const u32x4*>(g);
+      }
+    }
+    wk += 128;
+    if (++kl == a.klines) {
+      kl = 0;
+      if (++tap < a.taps) tap_offsets(tap);
+    }
+  };
+  auto stage_commit = [&](int buf) {  // register staging only: registers -> LDS
+    if constexpr (STG == 0) {
+      unsigned char* sa = smem + buf * STAGE + (wave * 32) * 128 + lane * 16;
+      unsigned char* sb = smem + buf * STAGE + A_BYTES + (wave * (BN / 4)) * 128 + lane * 16;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(sa + j * 1024) = ra[j];
+#pragma unroll
+      for (int j = 0; j < BROWS; ++j) *reinterpret_cast<u32x4*>(sb + j * 1024) = rb_[j];
+    }
+  };
+
+  // ---------------- accumulate ----------------
+  f32x4 acc[MI][4];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[mi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, g = lane >> 4;
+  const int nsteps = a.taps * a.klines;
+  // fragment byte offsets inside a stage (row&7 == lane&7 for both operands)
+  const int xfrag = (wm * WM + frow) * 128, wfrag = A_BYTES + (wn * 64 + frow) * 128;
+  const int sw = lane & 7;
+
+  stage_issue(0);
+  stage_commit(0);
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < nsteps) stage_issue(cur ^ 1);
+    const unsigned char* st = smem + cur * STAGE;
+    u32x4 wf[2][4], xf[2][MI];  // all fragments of the K-line first: the reads overlap the MFMAs of the first half
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int coff = ((g + 4 * kk) ^ sw) << 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wf[kk][i] = *reinterpret_cast<const u32x4*>(st + wfrag + i * 2048 + coff);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) xf[kk][mi] = *reinterpret_cast<const u32x4*>(st + xfrag + mi * 2048 + coff);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Tr::mma(wf[kk][i], xf[kk][mi], acc[mi][i]);
+    if (s + 1 < nsteps) stage_commit(cur ^ 1);
+    __syncthreads();
+  }
+
+  conv_epilogue<T, MI>(a, acc, m0 + wm * WM, n0 + wn * 64, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 256-pixel x 128-cout tile, 8 waves (4 x 2 of 64x64), THREE LDS stages of 48 KiB: the LDS-DMA of K-step s+2 is
+// issued before the MFMAs of step s and stays in flight across the (raw) barrier; a counted `s_waitcnt vmcnt(6)`
+// retires only step s+1's six loads.  Same operand images, fragment reads and epilogue as the 2-stage kernel.
+// ------------------------------------------------------------------------------------------------
+template <typename Tr>
+__global__ __launch_bounds__(512) void conv_igemm3_kernel(const IgemmArgs a) {
+  typedef typename Tr::elem T;
+  constexpr int BM = 256, BN = 128, WM = 64, MI = 4;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bid = ps_xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = bid % a.ntn, tm = bid / a.ntn;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int srow = lane >> 3;
+  const int chunk_off = ((lane & 7) ^ srow) << 4;
+  int py[4], px[4], nb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + wave * 32 + j * 8 + srow;
+    if (m < a.M) {
+      const int hw = a.Ho * a.Wo;
+      const int n = m / hw, rem = m - n * hw;
+      const int p = rem / a.Wo, q = rem - p * a.Wo;
+      py[j] = p * a.mul;
+      px[j] = q * a.mul;
+      nb[j] = n * a.Hs * a.Ws;
+    } else {
+      py[j] = -(1 << 20);
+      px[j] = 0;
+      nb[j] = 0;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, (int)a.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, 0, (int)a.wgt_bytes, 0x00020000);
+  unsigned woff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int rb = wave * 16 + j * 8 + srow;
+    const int within = rb & 63, fi = within >> 4, rho = within & 15;
+    const int cout = n0 + (rb & ~63) + 16 * (rho >> 2) + 4 * fi + (rho & 3);
+    woff[j] = (unsigned)(cout * a.wrow_bytes) + chunk_off;
+  }
+  unsigned aoff[4];
+  int tap = 0, kl = 0;
+  int wk = 0;
+
+  auto tap_offsets = [&](int t) {
+    const int ty = (a.taps == 1) ? a.ctr : t / 3, tx = (a.taps == 1) ? a.ctr : t - (t / 3) * 3;
+    const int dy = (ty - a.ctr) * a.dstep, dx = (tx - a.ctr) * a.dstep;
+    const int dmask = (1 << a.div_shift) - 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int yn = py[j] + dy, xn = px[j] + dx;
+      const int y = yn >> a.div_shift, x = xn >> a.div_shift;
+      const bool ok = (yn >= 0) && (xn >= 0) && (((yn | xn) & dmask) == 0) && (y < a.Hs) && (x < a.Ws);
+      aoff[j] = ok ? (unsigned)((nb[j] + y * a.Ws + x) * (int)a.pix_bytes) + chunk_off : PAD_ROW;
+    }
+  };
+  tap_offsets(0);
+
+  auto stage_issue = [&](int buf) {
+    unsigned char* sa = smem + buf * STAGE + (wave * 32) * 128;
+    unsigned char* sb = smem + buf * STAGE + A_BYTES + (wave * 16) * 128;
+    const int ko = kl * 128;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) BLDS16(rsA, sa + j * 1024, aoff[j], ko);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) BLDS16(rsB, sb + j * 1024, woff[j], wk);
+    wk += 128;
+    if (++kl == a.klines) {
+      kl = 0;
+      if (++tap < a.taps) tap_offsets(tap);
+    }
+  };
+
+  f32x4 acc[MI][4];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[mi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, g = lane >> 4;
+  const int nsteps = a.taps * a.klines;
+  const int xfrag = (wm * WM + frow) * 128, wfrag = A_BYTES + (wn * 64 + frow) * 128;
+  const int sw = lane & 7;
+
+  stage_issue(0);
+  if (nsteps > 1) {
+    stage_issue(1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  int cur = 0, nxt2 = 2;  // buffer of step s, buffer for step s+2
+  for (int s = 0; s < nsteps; ++s) {
+    if (s + 2 < nsteps) stage_issue(nxt2);
+    const unsigned char* st = smem + cur * STAGE;
+    u32x4 wf[2][4], xf[2][MI];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int coff = ((g + 4 * kk) ^ sw) << 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wf[kk][i] = *reinterpret_cast<const u32x4*>(st + wfrag + i * 2048 + coff);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) xf[kk][mi] = *reinterpret_cast<const u32x4*>(st + xfrag + mi * 2048 + coff);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Tr::mma(wf[kk][i], xf[kk][mi], acc[mi][i]);
+    // step s+1 must have landed (its loads are older than step s+2's six) before anyone reads it
+    if (s + 2 < nsteps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    cur = (cur == 2) ? 0 : cur + 1;
+    nxt2 = (nxt2 == 2) ? 0 : nxt2 + 1;
+  }
+  conv_epilogue<T, MI>(a, acc, m0 + wm * WM, n0 + wn * 64, lane);
+}
+
+static int g_use_glds = 2;  // staging mode: 0 registers, 1 global_load_lds, 2 buffer_load ... lds
+static int g_use_3stage = 0;  // experimental 256x128 three-stage kernel: correct but slower than two 128x128 blocks per CU (r01 measurements)
+static int g_force_bn = 0;  // testing: 64 or 128 forces the 2-stage tile width
 
 template <typename Tr, int BN>
 int launch_igemm(const IgemmArgs& a, int ntm, hipStream_t stream) {
   const int grid = ntm * a.ntn;
   const size_t lds = 2 * (128 * 128 + BN * 128);
-  if (g_use_glds) {
-    hipLaunchKernelGGL((conv_igemm_kernel<Tr, BN, true>), dim3(grid), dim3(256), lds, stream, a);
+  if (g_use_glds == 2) {
+    hipLaunchKernelGGL((conv_igemm_kernel<Tr, BN, 2>), dim3(grid), dim3(256), lds, stream, a);
+  } else if (g_use_glds == 1) {
+    hipLaunchKernelGGL((conv_igemm_kernel<Tr, BN, 1>), dim3(grid), dim3(256), lds, stream, a);
   } else {
-    hipLaunchKernelGGL((conv_igemm_kernel<Tr, BN, false>), dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<Tr, BN, 0>), dim3(grid), dim3(256), lds, stream, a);
   }
   PS_CHECK_LAUNCH("conv_igemm");
   return PS_OK;
@@ -309,11 +467,28 @@ int check_epilogue(const ps_epilogue* e, int dtype, const char* who) {
   return PS_OK;
 }
 
+int set_extents(IgemmArgs& a, long long src_bytes, long long wgt_bytes) {
+  // 32-bit buffer offsets; bit 31 marks padding rows
+  PS_REQUIRE(src_bytes < (1LL << 31) && wgt_bytes < (1LL << 31), "conv: tensor larger than 2 GiB (%lld / %lld bytes)", src_bytes, wgt_bytes);
+  a.src_bytes = (unsigned)src_bytes;
+  a.wgt_bytes = (unsigned)wgt_bytes;
+  return PS_OK;
+}
+
 template <typename Tr>
 int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
+  // big problems: 256 x 128 tile, 3-stage LDS-DMA ring (1 block of 8 waves per CU)
+  if (g_use_3stage && g_use_glds == 2 && a.Cd % 128 == 0 && (long long)((a.M + 255) / 256) * (a.Cd / 128) >= 256) {
+    IgemmArgs b = a;
+    b.ntn = a.Cd / 128;
+    const int grid = ((a.M + 255) / 256) * b.ntn;
+    hipLaunchKernelGGL((conv_igemm3_kernel<Tr>), dim3(grid), dim3(512), 3 * (256 * 128 + 128 * 128), s, b);
+    PS_CHECK_LAUNCH("conv_igemm3");
+    return PS_OK;
+  }
   const int ntm = (a.M + 127) / 128;
   // BN = 128 whenever it divides Cd and there are enough tiles to fill 256 CUs twice over; else 64.
-  if (a.Cd % 128 == 0 && (long long)ntm * (a.Cd / 128) >= 512) {
+  if (g_force_bn != 64 && a.Cd % 128 == 0 && ((long long)ntm * (a.Cd / 128) >= 512 || g_force_bn == 128)) {
     IgemmArgs b = a;
     b.ntn = a.Cd / 128;
     return launch_igemm<Tr, 128>(b, ntm, s);
@@ -325,7 +500,9 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" void ps_debug_set_glds(int on) { g_use_glds = on; }
+extern "C" void ps_debug_set_glds(int on) { g_use_glds = on; }  // 0 | 1 | 2
+extern "C" void ps_debug_set_3stage(int on) { g_use_3stage = on; }
+extern "C" void ps_debug_set_bn(int bn) { g_force_bn = bn; }
 
 extern "C" int ps_conv_supported(const ps_conv_geom* g) { return check_geom(g) == PS_OK ? 1 : 0; }
 
@@ -347,6 +524,7 @@ extern "C" int ps_conv2d_fwd(const ps_conv_geom* g, const void* x, const void* w
   a.wrow_bytes = (long long)a.taps * g->cin * es;
   a.Cd = g->cout;
   a.epi = *epi;
+  if (int rc = set_extents(a, (long long)g->n * g->h * g->w * a.pix_bytes, (long long)g->cout * a.wrow_bytes)) return rc;
   return g->dtype == PS_BF16 ? dispatch_bn<TraitsBF16>(a, static_cast<hipStream_t>(stream))
                              : dispatch_bn<TraitsF32>(a, static_cast<hipStream_t>(stream));
 }
@@ -369,6 +547,7 @@ extern "C" int ps_conv2d_dgrad(const ps_conv_geom* g, const void* dy, const void
   a.wrow_bytes = (long long)a.taps * g->cout * es;
   a.Cd = g->cin;
   a.epi = *epi;
+  if (int rc = set_extents(a, (long long)g->n * a.Hs * a.Ws * a.pix_bytes, (long long)g->cin * a.wrow_bytes)) return rc;
   return g->dtype == PS_BF16 ? dispatch_bn<TraitsBF16>(a, static_cast<hipStream_t>(stream))
                              : dispatch_bn<TraitsF32>(a, static_cast<hipStream_t>(stream));
 }

@@ -14,7 +14,6 @@
 
 namespace {
 
-__device__ __attribute__((aligned(256))) unsigned char g_zero_row[512];
 
 struct FastDiv {
   uint32_t magic, shift, d;
@@ -42,6 +41,8 @@ struct WgradArgs {
   long long x_pix_bytes, dy_pix_bytes;
   int tiles_co, tiles_ci, splits, ksteps;  // ksteps = ceil(M / KP)
   FastDiv div_hw, div_w;
+  unsigned x_bytes, dy_bytes;  // buffer extents (num_records)
+  int dq, dp, dn;              // how (q, p, n) of a pixel advance when its index grows by KP
 };
 
 struct WTraitsBF16 {
@@ -59,9 +60,11 @@ __device__ __forceinline__ int row_swz(int R) {
   else return (((R >> 1) & 1) << 1) | (((R >> 3) & 1) << 2);
 }
 
-#define GLDS16(gptr, lptr)                                                                              \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),               \
-                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+// LDS-DMA through a buffer descriptor (32-bit lane offset + scalar offset); out-of-range lanes (padding pixels,
+// the tail beyond the last pixel) are ZERO-filled by the DMA (tools/probe_oob.hip).
+#define BLDS16(rsrc, lptr, voff, soff)                                                                  \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(lptr), 16, (int)(voff), (int)(soff), 0, 0)
+constexpr unsigned PAD_ROW = 0x80000000u;
 
 template <typename Tr, int BCO, int BCI>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
@@ -89,39 +92,53 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 
   const int wr = wave >> 1, wc = wave & 1;
 
-  // staging lanes
+  // ---- staging.  dY rows are linear in the pixel index: constant lane offset + a scalar offset per K-step; rows past
+  // the last pixel fall outside the descriptor and arrive as zeros.  X rows follow the tap shift: the lane tracks
+  // (n, p, q) of its NIX pixels incrementally (no division in the loop).
+  const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)a.dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
   const int g_rowin = lane / (RBG / 16), g_pos = lane % (RBG / 16);
   const int x_rowin = lane / (RBX / 16), x_pos = lane % (RBX / 16);
+  unsigned goff[NIG];
+#pragma unroll
+  for (int j = 0; j < NIG; ++j) {
+    const int R = (wave * NIG + j) * RPG + g_rowin;
+    goff[j] = (unsigned)(R * (int)a.dy_pix_bytes + co0 * ES + ((g_pos ^ row_swz<ES, RBG>(R)) << 4));
+  }
+  int xn[NIX], xp[NIX], xq[NIX];
+  unsigned xchunk[NIX];
+#pragma unroll
+  for (int j = 0; j < NIX; ++j) {
+    const int R = (wave * NIX + j) * RPX + x_rowin;
+    const uint32_t m = (uint32_t)(ks0 * KP + R);
+    const uint32_t n = fdiv(m, a.div_hw);
+    const uint32_t rem = m - n * a.div_hw.d;
+    const uint32_t p = fdiv(rem, a.div_w);
+    xn[j] = (int)n; xp[j] = (int)p; xq[j] = (int)(rem - p * a.div_w.d);
+    xchunk[j] = (unsigned)(ci0 * ES + ((x_pos ^ row_swz<ES, RBX>(R)) << 4));
+  }
+  const int n_img = a.M / (a.Ho * a.Wo);
 
   auto stage = [&](int buf, int ks) {
-    const int mbase = ks * KP;
     unsigned char* sg = smem + buf * STAGE;
     unsigned char* sx = sg + G_BYTES;
+    const int gso = ks * KP * (int)a.dy_pix_bytes;
 #pragma unroll
-    for (int j = 0; j < NIG; ++j) {
-      const int R = (wave * NIG + j) * RPG + g_rowin;
-      const int m = mbase + R;
-      const int chunk = g_pos ^ row_swz<ES, RBG>(R);
-      const unsigned char* src = (m < a.M) ? a.dy + (long long)m * a.dy_pix_bytes + (long long)co0 * ES + chunk * 16
-                                           : g_zero_row + (chunk & 15) * 16;
-      GLDS16(src, sg + (wave * NIG + j) * 1024);
-    }
+    for (int j = 0; j < NIG; ++j) BLDS16(rsG, sg + (wave * NIG + j) * 1024, goff[j], gso);
 #pragma unroll
     for (int j = 0; j < NIX; ++j) {
-      const int R = (wave * NIX + j) * RPX + x_rowin;
-      const int m = mbase + R;
-      const int chunk = x_pos ^ row_swz<ES, RBX>(R);
-      const unsigned char* src = g_zero_row + (chunk & 15) * 16;
-      if (m < a.M) {
-        const uint32_t n = fdiv(m, a.div_hw);
-        const uint32_t rem = m - n * a.div_hw.d;
-        const uint32_t p = fdiv(rem, a.div_w);
-        const uint32_t q = rem - p * a.div_w.d;
-        const int y = (int)p * a.stride + dy_off, xx = (int)q * a.stride + dx_off;
-        if (y >= 0 && y < a.H && xx >= 0 && xx < a.W)
-          src = a.x + ((long long)(n * a.H + y) * a.W + xx) * a.x_pix_bytes + (long long)ci0 * ES + chunk * 16;
-      }
-      GLDS16(src, sx + (wave * NIX + j) * 1024);
+      const int y = xp[j] * a.stride + dy_off, xx = xq[j] * a.stride + dx_off;
+      const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)xx < (unsigned)a.W && xn[j] < n_img;
+      const unsigned off = ok ? (unsigned)(((xn[j] * a.H + y) * a.W + xx) * (int)a.x_pix_bytes) + xchunk[j] : PAD_ROW;
+      BLDS16(rsX, sx + (wave * NIX + j) * 1024, off, 0);
+      // advance this lane's pixel by KP
+      int q = xq[j] + a.dq;
+      const int c1 = q >= a.Wo;
+      q -= c1 ? a.Wo : 0;
+      int p = xp[j] + a.dp + c1;
+      const int c2 = p >= a.Ho;
+      p -= c2 ? a.Ho : 0;
+      xq[j] = q; xp[j] = p; xn[j] += a.dn + c2;
     }
   };
 
@@ -216,6 +233,9 @@ int launch_wgrad(WgradArgs a, hipStream_t s) {
   a.tiles_co = a.cout / BCO;
   a.tiles_ci = a.cin / BCI;
   a.ksteps = (a.M + Tr::KP - 1) / Tr::KP;
+  a.dq = Tr::KP % a.Wo;
+  a.dp = (Tr::KP / a.Wo) % a.Ho;
+  a.dn = Tr::KP / (a.Wo * a.Ho);
   const long long tiles = (long long)a.tiles_co * a.tiles_ci * a.taps;
   long long splits = (1536 + tiles - 1) / tiles;           // aim for >= ~1.5k blocks (256 CUs x 2-3 resident)
   const long long max_splits = (a.ksteps + 7) / 8;          // at least 8 K-steps per block
@@ -258,6 +278,10 @@ extern "C" int ps_conv2d_wgrad(const ps_conv_geom* g, const void* x, const void*
   a.dy_pix_bytes = (long long)g->ldc_y * es;
   a.div_hw = make_fastdiv((uint32_t)(a.Ho * a.Wo));
   a.div_w = make_fastdiv((uint32_t)a.Wo);
+  const long long xb = (long long)g->n * g->h * g->w * a.x_pix_bytes, gb = (long long)a.M * a.dy_pix_bytes;
+  PS_REQUIRE(xb < (1LL << 31) && gb < (1LL << 31), "conv2d_wgrad: tensor larger than 2 GiB");
+  a.x_bytes = (unsigned)xb;
+  a.dy_bytes = (unsigned)gb;
   return g->dtype == PS_BF16 ? dispatch_wgrad<WTraitsBF16>(a, static_cast<hipStream_t>(stream))
                              : dispatch_wgrad<WTraitsF32>(a, static_cast<hipStream_t>(stream));
 }

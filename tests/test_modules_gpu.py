@@ -145,6 +145,8 @@ def test_seg_trainer_step_matches_autograd_path_and_torch_adamw():
     assert abs(l1[0] - l2[0]) < 1e-6 and abs(l1[1] - l2[1]) < 2e-4 * abs(l2[1])
     for k in s1:
         if s1[k].is_floating_point():
-            # Adam's first steps move every weight by ~lr*sign(g): elements with |g| at the f32 noise floor (atomic
-            # summation order) may differ by a fraction of one update; bound = 10% of the two updates
-            assert float((s1[k] - s2[k]).abs().max()) <= 0.1 * 2 * 1e-3, k
+            # Adam's first steps move every weight by ~lr*sign(g): an element whose gradient sits at the f32 noise
+            # floor (atomic summation order) can take a different sign, i.e. differ by up to 2*lr per step -- so bound
+            # the maximum by that and require the MEAN difference to be negligible against one update
+            d = (s1[k] - s2[k]).abs()
+            assert float(d.max()) <= 2 * 2 * 1e-3 * 1.1 and float(d.mean()) < 1e-6, (k, float(d.max()), float(d.mean()))

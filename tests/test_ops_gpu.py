@@ -43,7 +43,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("glds", [1, 0])
+@pytest.mark.parametrize("glds", [2, 1, 0])  # operand staging: buffer LDS-DMA (default), flat LDS-DMA, registers
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd_dgrad_wgrad(case, dtype, glds):
@@ -53,8 +53,8 @@ def test_conv_fwd_dgrad_wgrad(case, dtype, glds):
     lib.ps_debug_set_glds(glds)
     try:
         cin, cout, k, s, d = case
-        if glds == 0 and cin > 256:
-            pytest.skip("register-staging variant is covered on the small cases")
+        if glds != 2 and cin > 256:
+            pytest.skip("the alternative staging variants are covered on the small cases")
         n, h, w = 2, 13, 10  # odd/even sizes, M not a multiple of 128
         g = torch.Generator().manual_seed(sum(case) * 7 + k)
         x = torch.randn(n, cin, h, w, generator=g)
@@ -95,7 +95,7 @@ def test_conv_fwd_dgrad_wgrad(case, dtype, glds):
         ops.conv2d_wgrad(spec, xd, gyd, dw)
         assert rel_err(dw.cpu(), w_fwd_layout(wt.grad)) < tol
     finally:
-        lib.ps_debug_set_glds(1)
+        lib.ps_debug_set_glds(2)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -325,3 +325,53 @@ def test_optimizers_match_torch():
         opt.step()
         ops.sgd_step(p, gr.to(D), buf, None, 0.01, 5e-4, 5e-4, step == 0)
     assert rel_err(p.cpu(), pt.detach()) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [
+    # (n, h, w, cin, cout, k, s, d): large enough for the 256x128 three-stage kernel (>= 256 tiles)
+    (4, 28, 28, 2048, 4096, 1, 1, 1), (16, 28, 28, 512, 1024, 3, 1, 4), (12, 56, 56, 256, 512, 3, 2, 1), (3, 112, 112, 128, 128, 3, 1, 1),
+])
+def test_conv_three_stage_kernel_is_bit_identical_to_two_stage(case, dtype):
+    """The 3-stage LDS-DMA ring changes the pipeline, not the arithmetic: every output element is the same MFMA
+    chain over the same K order, so fwd and dgrad must agree BITWISE with the 2-stage kernel (race screen: repeated),
+    and one image is checked against the CPU."""
+    from pistoseg_amd import _lib, ops
+
+    lib = _lib.load()
+    n, h, w, cin, cout, k, s, d = case
+    g = torch.Generator().manual_seed(n * 1000 + cin)
+    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    x = q(torch.randn(n, h, w, cin, generator=g))
+    wt = q(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5)
+    spec = ops.ConvSpec(cin, cout, k, s, d)
+    ho, wo = spec.out_hw(h, w)
+    D = dev()
+    xd, wf, wd = x.to(D, dtype), w_fwd_layout(wt).to(D, dtype), w_dgrad_layout(wt).to(D, dtype)
+    res = q(torch.randn(n, ho, wo, cout, generator=g)).to(D, dtype)
+    scale = (torch.rand(cout, generator=g) + 0.5).to(D)
+    shift = (torch.randn(cout, generator=g) * 0.1).to(D)
+    gy = q(torch.randn(n, ho, wo, cout, generator=g)).to(D, dtype)
+    mask = q(torch.randn(n, h, w, cin, generator=g)).to(D, dtype)
+
+    def run():
+        y_raw = torch.empty((n, ho, wo, cout), device=D, dtype=dtype)
+        y_act = torch.empty_like(y_raw)
+        ops.conv2d_fwd(spec, xd, wf, add0=res, out_raw=y_raw, bn_scale=scale, bn_shift=shift, out_act=y_act)
+        gx = torch.empty((n, h, w, cin), device=D, dtype=dtype)
+        ops.conv2d_dgrad(spec, gy, wd, (h, w), mask_src=mask, out=gx)
+        return y_raw, y_act, gx
+
+    try:
+        lib.ps_debug_set_3stage(0)
+        ref = run()
+        lib.ps_debug_set_3stage(1)
+        for _ in range(3):
+            got = run()
+            for a_, b_ in zip(got, ref):
+                assert torch.equal(a_, b_)
+    finally:
+        lib.ps_debug_set_3stage(0)
+    cpu = F.conv2d(x[:1].permute(0, 3, 1, 2), wt, stride=s, padding=d if k == 3 else 0, dilation=d) + res[:1].float().cpu().permute(0, 3, 1, 2)
+    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    assert rel_err(ref[0][:1].float().cpu(), nhwc(cpu)) < tol

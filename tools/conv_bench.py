@@ -1,0 +1,75 @@
+"""Per-layer conv micro-benchmark (optimisation harness): times fwd / dgrad / wgrad of the net's distinct layer
+shapes at a given batch, interleaving kernel variants in one process (HIP events), prints TFLOP/s."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pistoseg_amd import _lib, ops
+
+LAYERS = [  # name, cin, cout, k, s, d, H (input), count in net
+    ("b2.2b1 128->128 3x3 @112", 128, 128, 3, 1, 1, 112, 5),
+    ("b3.2b1 256->256 3x3 @56", 256, 256, 3, 1, 1, 56, 5),
+    ("b4.2a 256->512 3x3 s2", 256, 512, 3, 2, 1, 56, 1),
+    ("b4.2b1 512->512 3x3 @28", 512, 512, 3, 1, 1, 28, 12),
+    ("b5.2b1 512->1024 3x3 d2", 512, 1024, 3, 1, 2, 28, 3),
+    ("b5_1.2a 1024->512 3x3 d2", 1024, 512, 3, 1, 2, 28, 2),
+    ("b6.2b1 512->1024 3x3 d4", 512, 1024, 3, 1, 4, 28, 1),
+    ("b7.2b1 1024->2048 3x3 d4", 1024, 2048, 3, 1, 4, 28, 1),
+    ("b7.b1 2048->4096 1x1", 2048, 4096, 1, 1, 1, 28, 2),
+    ("b7.2a 2048->1024 1x1", 2048, 1024, 1, 1, 1, 28, 1),
+    ("b6.b1 1024->2048 1x1", 1024, 2048, 1, 1, 1, 28, 2),
+]
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--what", default="fwd,dgrad,wgrad")
+    ap.add_argument("--variants", default="3stage=0,3stage=1")
+    ap.add_argument("--layers", default="")
+    args = ap.parse_args()
+    lib = _lib.load()
+    D = torch.device("cuda:0")
+    dt = torch.bfloat16
+    variants = [v.split("=") for v in args.variants.split(",")]
+    sel = [int(i) for i in args.layers.split(",")] if args.layers else range(len(LAYERS))
+    for li in sel:
+        name, cin, cout, k, s, d, H, cnt = LAYERS[li]
+        n = args.batch
+        spec = ops.ConvSpec(cin, cout, k, s, d)
+        ho, wo = spec.out_hw(H, H)
+        x = torch.randn(n, H, H, cin, device=D).to(dt)
+        wf = (torch.randn(cout, k, k, cin, device=D) * 0.02).to(dt)
+        wd = (torch.randn(cin, k, k, cout, device=D) * 0.02).to(dt)
+        gy = torch.randn(n, ho, wo, cout, device=D).to(dt)
+        y = torch.empty(n, ho, wo, cout, device=D, dtype=dt)
+        gx = torch.empty(n, H, H, cin, device=D, dtype=dt)
+        dw = torch.zeros(cout, k, k, cin, device=D)
+        flops = 2.0 * n * ho * wo * cout * cin * k * k
+        fns = {"fwd": lambda: ops.conv2d_fwd(spec, x, wf, out_raw=y), "dgrad": lambda: ops.conv2d_dgrad(spec, gy, wd, (H, H), out_raw=gx),
+               "wgrad": lambda: ops.conv2d_wgrad(spec, x, gy, dw)}
+        line = f"{name:28s}"
+        for what in args.what.split(","):
+            res = {}
+            for r in range(3):  # interleaved rounds
+                for vn, vv in variants:
+                    lib.ps_debug_set_3stage(0)
+                    getattr(lib, "ps_debug_set_" + vn)(int(vv))
+                    fns[what]()
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(args.iters):
+                        fns[what]()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    res.setdefault((vn, vv), []).append(e0.elapsed_time(e1) / args.iters)
+            line += f" | {what}:"
+            for (vn, vv), ts in res.items():
+                t = min(ts)
+                line += f" {vn}={vv}: {t*1e3:7.1f}us {flops/t/1e9:6.0f}TF"
+        print(line, flush=True)
+    lib.ps_debug_set_3stage(0)
+    lib.ps_debug_set_bn(0)
+
+if __name__ == "__main__":
+    main()
