@@ -254,6 +254,14 @@ void ps_debug_set_glds(int on);
 void ps_debug_set_3stage(int on);
 /* Testing hook: 64 / 128 force the cout-tile width of the 2-stage conv kernel, 0 (default) picks by problem size. */
 void ps_debug_set_bn(int bn);
+/* Testing hook: 112 / 128 force the pixel-tile height of the 128-cout conv kernel, 0 (default) picks the better-balanced. */
+void ps_debug_set_bm(int bm);
+/* Timing experiments only (results become WRONG): 1 = the conv kernel stages its first two K-steps and then stops loading. */
+void ps_debug_set_ablate(int v);
+/* Testing hook: 1 = big problems use the experimental 8-wave ping-pong conv kernel, 0 (default) = never, 2 = always (cout % 128 == 0). */
+void ps_debug_set_pp(int v);
+/* Testing hook: 1 (default) = big problems use the wave-specialised (4 loader + 4 consumer waves) conv kernel, 0 = never, 2 = always. */
+void ps_debug_set_ws(int v);
 
 #ifdef __cplusplus
 }

@@ -31,6 +31,7 @@ struct IgemmArgs {
   int Cd;                     // produced channels
   unsigned src_bytes;         // extent of the gathered tensor / of the weights (buffer descriptors' num_records)
   unsigned wgt_bytes;
+  int ablate;                 // timing experiments only: 1 = stage the first two K-steps only (no further loads)
   ps_epilogue epi;
 };
 
@@ -72,93 +73,112 @@ __device__ __forceinline__ void store16(T* p, const float* v) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(lptr), 16, (int)(voff), (int)(soff), 0, 0)
 constexpr unsigned PAD_ROW = 0x80000000u;
 
-// Epilogue shared by the conv kernels: lane (frow = lane&15, g = lane>>4) owns pixels mbase + mi*16 + frow and the 16
-// contiguous produced channels cbase + 16*g .. +15 (acc[mi][i][r] = channel 4*i + r of that group).
-template <typename T, int MI>
-__device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[MI][4], int mbase, int cbase, int lane) {
+// Epilogue shared by the conv kernels: lane (frow = lane&15, g = lane>>4) owns pixels mbase + mi*16 + frow and the
+// CH = 4*WI contiguous produced channels cbase + CH*g .. (acc[mi][i][r] = channel 4*i + r of that group).
+template <typename T, int MI, int WI>
+__device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[MI][WI], int mbase, int cbase, int lane) {
+  constexpr int CH = 4 * WI;  // 16 or 8
   const int frow = lane & 15, g = lane >> 4;
   const ps_epilogue& e = a.epi;
-  const int cb = cbase + 16 * g;
-  float sc[16], sh[16];
+  const int cb = cbase + CH * g;
+  float sc[CH], sh[CH];
   if (e.mode != PS_EPI_NONE) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < CH; ++i) {
       sc[i] = e.scale ? e.scale[cb + i] : 1.f;
       sh[i] = (e.shift && e.mode == PS_EPI_BNRELU) ? e.shift[cb + i] : 0.f;
     }
   }
+  auto ld = [&](const void* base, long long ldc, int m, float* v) {
+#pragma unroll
+    for (int o = 0; o < CH; o += 8) ps_load8<T>(reinterpret_cast<const T*>(base) + (long long)m * ldc + cb + o, v + o);
+  };
+  auto st = [&](void* base, long long ldc, int m, const float* v) {
+#pragma unroll
+    for (int o = 0; o < CH; o += 8) ps_store8<T>(reinterpret_cast<T*>(base) + (long long)m * ldc + cb + o, v + o);
+  };
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = mbase + mi * 16 + frow;
     if (m >= a.M) continue;
-    float v[16];
+    float v[CH];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WI; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[mi][i][r];
     if (e.add0) {
-      float t[16];
-      load16<T>(reinterpret_cast<const T*>(e.add0) + (long long)m * e.ldc_add0 + cb, t);
+      float t[CH];
+      ld(e.add0, e.ldc_add0, m, t);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] += t[i];
+      for (int i = 0; i < CH; ++i) v[i] += t[i];
     }
-    if (e.out_raw) store16<T>(reinterpret_cast<T*>(e.out_raw) + (long long)m * e.ldc_raw + cb, v);
+    if (e.out_raw) st(e.out_raw, e.ldc_raw, m, v);
     if (e.mode == PS_EPI_NONE) continue;
-    float dm[16];
+    float dm[CH];
     if (e.drop) {
       const int n = m / (a.Ho * a.Wo);
       const float* d = e.drop + (long long)n * a.Cd + cb;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) dm[i] = d[i];
+      for (int i = 0; i < CH; ++i) dm[i] = d[i];
     } else {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) dm[i] = 1.f;
+      for (int i = 0; i < CH; ++i) dm[i] = 1.f;
     }
     if (e.mode == PS_EPI_BNRELU) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i] * sc[i] + sh[i], 0.f) * dm[i];
+      for (int i = 0; i < CH; ++i) v[i] = fmaxf(v[i] * sc[i] + sh[i], 0.f) * dm[i];
     } else {  // PS_EPI_RELUBWD
-      float ms[16];
-      load16<T>(reinterpret_cast<const T*>(e.mask_src) + (long long)m * e.ldc_mask + cb, ms);
+      float ms[CH];
+      ld(e.mask_src, e.ldc_mask, m, ms);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = ms[i] > 0.f ? v[i] * sc[i] * dm[i] : 0.f;
+      for (int i = 0; i < CH; ++i) v[i] = ms[i] > 0.f ? v[i] * sc[i] * dm[i] : 0.f;
       if (e.add1) {
-        float t[16];
-        load16<T>(reinterpret_cast<const T*>(e.add1) + (long long)m * e.ldc_add1 + cb, t);
+        float t[CH];
+        ld(e.add1, e.ldc_add1, m, t);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] += t[i];
+        for (int i = 0; i < CH; ++i) v[i] += t[i];
       }
     }
-    store16<T>(reinterpret_cast<T*>(e.out) + (long long)m * e.ldc_out + cb, v);
+    st(e.out, e.ldc_out, m, v);
   }
 }
 
-template <typename Tr, int BN, int STG>  // STG: 0 registers, 1 global_load_lds, 2 buffer_load...lds (default)
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
+// Two-stage kernel.  Block tile BM pixels x BN couts, 4 waves arranged WMW x WNW; each wave owns MI = BM/(16*WMW)
+// pixel fragments and WI = BN/(16*WNW) cout fragments.  Instantiated as
+//   128 x 128, waves 2x2 (64x64 per wave)   -- general large problems
+//   112 x 128, waves 1x4 (112x32 per wave)  -- 7-fragment pixel tile: with 28x28 / 56x56 / 112x112 feature maps the
+//                                              pixel count is a multiple of 49*16, so 112-pixel tiles give every CU
+//                                              the same number of blocks (a 128-pixel tiling leaves a ~15% tail)
+//   128 x 64,  waves 4x1 (32x64 per wave)   -- narrow layers / small problems
+// STG: 0 registers, 1 global_load_lds, 2 buffer_load ... lds (default)
+template <typename Tr, int BM, int BN, int WMW, int WNW, int STG>
+__global__ __launch_bounds__(64 * WMW * WNW) void conv_igemm_kernel(const IgemmArgs a) {
   typedef typename Tr::elem T;
-  constexpr int BM = 128;
-  constexpr int WM = (BN == 128) ? 64 : 32;  // pixels per wave
-  constexpr int MI = WM / 16;                // pixel fragments per wave
-  constexpr int BROWS = BN / 32;             // weight rows staged per lane
+  constexpr int NW = WMW * WNW;  // waves per block (4 or 8)
+  constexpr int MI = BM / (16 * WMW);        // pixel fragments per wave
+  constexpr int WI = BN / (16 * WNW);        // cout fragments per wave
+  constexpr int WM = 16 * MI, WN = 16 * WI;  // wave tile
+  constexpr int AINS = BM / 8, BINS = BN / 8;  // 8-row LDS-DMA instructions per stage (dealt round-robin to the waves)
+  constexpr int AJ = (AINS + NW - 1) / NW, BJ = (BINS + NW - 1) / NW;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bid = ps_xcd_remap(blockIdx.x, gridDim.x);
   const int tn = bid % a.ntn, tm = bid / a.ntn;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int wm = (BN == 128) ? (wave >> 1) : wave;
-  const int wn = (BN == 128) ? (wave & 1) : 0;
+  const int wm = wave / WNW, wn = wave % WNW;
 
   // ---------------- staging state ----------------
-  // pixel rows: LDS row R = wave*32 + j*8 + (lane>>3); the lane moves source chunk (lane&7)^(R&7) to position lane&7
+  // LDS row R = t*8 + (lane>>3) of instruction t = j*NW + wave; the lane moves source chunk (lane&7)^(R&7) to position lane&7
   const int srow = lane >> 3;
   const int chunk_off = ((lane & 7) ^ srow) << 4;
-  int py[4], px[4], nb[4];
+  int py[AJ], px[AJ], nb[AJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = m0 + wave * 32 + j * 8 + srow;
-    if (m < a.M) {
+  for (int j = 0; j < AJ; ++j) {
+    const int m = m0 + (j * NW + wave) * 8 + srow;
+    if (m < a.M && j * NW + wave < AINS) {
       const int hw = a.Ho * a.Wo;
       const int n = m / hw, rem = m - n * hw;
       const int p = rem / a.Wo, q = rem - p * a.Wo;
@@ -171,20 +191,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
       nb[j] = 0;
     }
   }
-  // weight rows: LDS row Rb = wave*(BN/4) + j*8 + (lane>>3) holds cout n0 + 64*(Rb>>6) + perm(Rb&63), where
-  // perm(16*i + rho) = 16*(rho>>2) + 4*i + (rho&3)  (so that accumulator register r of fragment i, lane
-  // group g is cout 16*g + 4*i + r: 16 contiguous couts per lane)
+  // weight rows: LDS row Rb of the wave column wg = Rb / WN holds cout n0 + wg*WN + perm(Rb % WN), where
+  // perm(16*i + rho) = 4*WI*(rho>>2) + 4*i + (rho&3)  (so that accumulator register r of fragment i, lane group g
+  // is cout 4*WI*g + 4*i + r: 4*WI contiguous couts per lane)
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, (int)a.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, 0, (int)a.wgt_bytes, 0x00020000);
-  unsigned woff[BROWS];
+  unsigned woff[BJ];
 #pragma unroll
-  for (int j = 0; j < BROWS; ++j) {
-    const int rb = wave * (BN / 4) + j * 8 + srow;
-    const int within = rb & 63, fi = within >> 4, rho = within & 15;
-    const int cout = n0 + (rb & ~63) + 16 * (rho >> 2) + 4 * fi + (rho & 3);
+  for (int j = 0; j < BJ; ++j) {
+    const int rb = (j * NW + wave) * 8 + srow;
+    const int wg = rb / WN, within = rb % WN, fi = within >> 4, rho = within & 15;
+    const int cout = n0 + wg * WN + 4 * WI * (rho >> 2) + 4 * fi + (rho & 3);
     woff[j] = (unsigned)(cout * a.wrow_bytes) + chunk_off;
   }
-  unsigned aoff[4];  // byte offset of each pixel row for the current tap, PAD_ROW if the tap falls outside
+  unsigned aoff[AJ];  // byte offset of each pixel row for the current tap, PAD_ROW if the tap falls outside
   int tap = 0, kl = 0;
   int wk = 0;  // running K byte offset in a weight row
 
@@ -193,7 +213,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
     const int dy = (ty - a.ctr) * a.dstep, dx = (tx - a.ctr) * a.dstep;
     const int dmask = (1 << a.div_shift) - 1;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < AJ; ++j) {
       const int yn = py[j] + dy, xn = px[j] + dx;
       const int y = yn >> a.div_shift, x = xn >> a.div_shift;
       const bool ok = (yn >= 0) && (xn >= 0) && (((yn | xn) & dmask) == 0) && (y < a.Hs) && (x < a.Ws);
@@ -202,26 +222,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
   };
   tap_offsets(0);
 
-  u32x4 ra[4], rb_[BROWS];  // register staging (STG == 0)
+  u32x4 ra[AJ], rb_[BJ];  // register staging (STG == 0)
   auto stage_issue = [&](int buf) {
-    unsigned char* sa = smem + buf * STAGE + (wave * 32) * 128;
-    unsigned char* sb = smem + buf * STAGE + A_BYTES + (wave * (BN / 4)) * 128;
+    unsigned char* sa = smem + buf * STAGE;
+    unsigned char* sb = smem + buf * STAGE + A_BYTES;
     const int ko = kl * 128;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if constexpr (STG == 2) BLDS16(rsA, sa + j * 1024, aoff[j], ko);
+    for (int j = 0; j < AJ; ++j) {
+      const int t = j * NW + wave;
+      if (AINS % NW != 0 && t >= AINS) continue;
+      if constexpr (STG == 2) BLDS16(rsA, sa + t * 1024, aoff[j], ko);
       else {
         const unsigned char* g = aoff[j] != PAD_ROW ? a.src + aoff[j] + ko : g_zero_line + (lane & 7) * 16;
-        if constexpr (STG == 1) GLDS16(g, sa + j * 1024);
+        if constexpr (STG == 1) GLDS16(g, sa + t * 1024);
         else ra[j] = *reinterpret_cast<const u32x4*>(g);
       }
     }
 #pragma unroll
-    for (int j = 0; j < BROWS; ++j) {
-      if constexpr (STG == 2) BLDS16(rsB, sb + j * 1024, woff[j], wk);
+    for (int j = 0; j < BJ; ++j) {
+      const int t = j * NW + wave;
+      if (BINS % NW != 0 && t >= BINS) continue;
+      if constexpr (STG == 2) BLDS16(rsB, sb + t * 1024, woff[j], wk);
       else {
         const unsigned char* g = a.wgt + woff[j] + wk;
-        if constexpr (STG == 1) GLDS16(g, sb + j * 1024);
+        if constexpr (STG == 1) GLDS16(g, sb + t * 1024);
         else rb_[j] = *reinterpret_cast<const u32x4*>(g);
       }
     }
@@ -233,26 +257,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
   };
   auto stage_commit = [&](int buf) {  // register staging only: registers -> LDS
     if constexpr (STG == 0) {
-      unsigned char* sa = smem + buf * STAGE + (wave * 32) * 128 + lane * 16;
-      unsigned char* sb = smem + buf * STAGE + A_BYTES + (wave * (BN / 4)) * 128 + lane * 16;
+      unsigned char* sa = smem + buf * STAGE + lane * 16;
+      unsigned char* sb = smem + buf * STAGE + A_BYTES + lane * 16;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(sa + j * 1024) = ra[j];
+      for (int j = 0; j < AJ; ++j)
+        if (j * NW + wave < AINS) *reinterpret_cast<u32x4*>(sa + (j * NW + wave) * 1024) = ra[j];
 #pragma unroll
-      for (int j = 0; j < BROWS; ++j) *reinterpret_cast<u32x4*>(sb + j * 1024) = rb_[j];
+      for (int j = 0; j < BJ; ++j)
+        if (j * NW + wave < BINS) *reinterpret_cast<u32x4*>(sb + (j * NW + wave) * 1024) = rb_[j];
     }
   };
 
   // ---------------- accumulate ----------------
-  f32x4 acc[MI][4];
+  f32x4 acc[MI][WI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[mi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < WI; ++i) acc[mi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15, g = lane >> 4;
   const int nsteps = a.taps * a.klines;
   // fragment byte offsets inside a stage (row&7 == lane&7 for both operands)
-  const int xfrag = (wm * WM + frow) * 128, wfrag = A_BYTES + (wn * 64 + frow) * 128;
+  const int xfrag = (wm * WM + frow) * 128, wfrag = A_BYTES + (wn * WN + frow) * 128;
   const int sw = lane & 7;
 
   stage_issue(0);
@@ -260,14 +286,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
   __syncthreads();
   for (int s = 0; s < nsteps; ++s) {
     const int cur = s & 1;
-    if (s + 1 < nsteps) stage_issue(cur ^ 1);
+    if (s + 1 < nsteps && !(a.ablate == 1 && s >= 1)) stage_issue(cur ^ 1);
     const unsigned char* st = smem + cur * STAGE;
-    u32x4 wf[2][4], xf[2][MI];  // all fragments of the K-line first: the reads overlap the MFMAs of the first half
+    u32x4 wf[2][WI], xf[2][MI];  // all fragments of the K-line first: the reads overlap the MFMAs of the first half
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int coff = ((g + 4 * kk) ^ sw) << 4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) wf[kk][i] = *reinterpret_cast<const u32x4*>(st + wfrag + i * 2048 + coff);
+      for (int i = 0; i < WI; ++i) wf[kk][i] = *reinterpret_cast<const u32x4*>(st + wfrag + i * 2048 + coff);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) xf[kk][mi] = *reinterpret_cast<const u32x4*>(st + xfrag + mi * 2048 + coff);
     }
@@ -276,12 +302,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) Tr::mma(wf[kk][i], xf[kk][mi], acc[mi][i]);
+        for (int i = 0; i < WI; ++i) Tr::mma(wf[kk][i], xf[kk][mi], acc[mi][i]);
     if (s + 1 < nsteps) stage_commit(cur ^ 1);
     __syncthreads();
   }
 
-  conv_epilogue<T, MI>(a, acc, m0 + wm * WM, n0 + wn * 64, lane);
+  conv_epilogue<T, MI, WI>(a, acc, m0 + wm * WM, n0 + wn * WN, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -410,23 +436,326 @@ __global__ __launch_bounds__(512) void conv_igemm3_kernel(const IgemmArgs a) {
     cur = (cur == 2) ? 0 : cur + 1;
     nxt2 = (nxt2 == 2) ? 0 : nxt2 + 1;
   }
-  conv_epilogue<T, MI>(a, acc, m0 + wm * WM, n0 + wn * 64, lane);
+  conv_epilogue<T, MI, 4>(a, acc, m0 + wm * WM, n0 + wn * 64, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ping-pong kernel: 8 waves = two groups of four; group g computes the pixel rows [g*GM, (g+1)*GM) of a (2*GM) x 128
+// tile against the SAME weight tile.  The groups run half a K-step apart, separated by block barriers:
+//     phase 2k   : group 0 issues the LDS-DMA of step k+2 and reads the fragments of step k | group 1 runs the MFMAs of step k-1
+//     phase 2k+1 : group 0 runs the MFMAs of step k                                        | group 1 issues step k+2, reads step k
+// so each SIMD always has one wave feeding the matrix pipe while its partner fetches, fragments are complete in
+// registers before a wave's MFMA burst starts, and the DMA of a step has two phases to land (3-stage LDS ring, counted
+// vmcnt, raw s_barrier).  GM = 128: groups are 2x2 waves of 64x64; GM = 112: 1x4 waves of 112x32 (balanced tiling for
+// 28x28-derived pixel counts, see conv_igemm_kernel).
+// ------------------------------------------------------------------------------------------------
+template <typename Tr, int GM>
+__global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const IgemmArgs a) {
+  typedef typename Tr::elem T;
+  constexpr int BM = 2 * GM, BN = 128;
+  constexpr int WMW = (GM == 128) ? 2 : 1, WNW = 4 / WMW;
+  constexpr int MI = GM / (16 * WMW), WI = BN / (16 * WNW);
+  constexpr int WM = 16 * MI, WN = 16 * WI;
+  constexpr int AINS = BM / 8, BINS = BN / 8, AJ = (AINS + 7) / 8, BJ = BINS / 8;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wl = wave & 3;
+  const int bid = ps_xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = bid % a.ntn, tm = bid / a.ntn;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int wm = wl / WNW, wn = wl % WNW;
+
+  const int srow = lane >> 3;
+  const int chunk_off = ((lane & 7) ^ srow) << 4;
+  int py[AJ], px[AJ], nb[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int m = m0 + (j * 8 + wave) * 8 + srow;
+    if (m < a.M && j * 8 + wave < AINS) {
+      const int hw = a.Ho * a.Wo;
+      const int n = m / hw, rem = m - n * hw;
+      const int p = rem / a.Wo, q = rem - p * a.Wo;
+      py[j] = p * a.mul;
+      px[j] = q * a.mul;
+      nb[j] = n * a.Hs * a.Ws;
+    } else {
+      py[j] = -(1 << 20);
+      px[j] = 0;
+      nb[j] = 0;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, (int)a.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, 0, (int)a.wgt_bytes, 0x00020000);
+  unsigned woff[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int rb = (j * 8 + wave) * 8 + srow;
+    const int wg = rb / WN, within = rb % WN, fi = within >> 4, rho = within & 15;
+    const int cout = n0 + wg * WN + 4 * WI * (rho >> 2) + 4 * fi + (rho & 3);
+    woff[j] = (unsigned)(cout * a.wrow_bytes) + chunk_off;
+  }
+  unsigned aoff[AJ];
+  int tap = 0, kl = 0, wk = 0;
+  auto tap_offsets = [&](int t) {
+    const int ty = (a.taps == 1) ? a.ctr : t / 3, tx = (a.taps == 1) ? a.ctr : t - (t / 3) * 3;
+    const int dy = (ty - a.ctr) * a.dstep, dx = (tx - a.ctr) * a.dstep;
+    const int dmask = (1 << a.div_shift) - 1;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int yn = py[j] + dy, xn = px[j] + dx;
+      const int y = yn >> a.div_shift, x = xn >> a.div_shift;
+      const bool ok = (yn >= 0) && (xn >= 0) && (((yn | xn) & dmask) == 0) && (y < a.Hs) && (x < a.Ws);
+      aoff[j] = ok ? (unsigned)((nb[j] + y * a.Ws + x) * (int)a.pix_bytes) + chunk_off : PAD_ROW;
+    }
+  };
+  tap_offsets(0);
+  // every wave issues exactly NLOAD loads per step (rows beyond the tile are issued as zero-filled padding so that
+  // the vmcnt bookkeeping is the same literal for all waves)
+  constexpr int NLOAD = AJ + BJ;
+  auto stage_issue = [&](int buf) {
+    unsigned char* sa = smem + buf * STAGE;
+    unsigned char* sb = smem + buf * STAGE + A_BYTES;
+    const int ko = kl * 128;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int t = j * 8 + wave;
+      if (AINS % 8 != 0 && t >= AINS) BLDS16(rsA, smem + 3 * STAGE, PAD_ROW, 0);  // dummy (scratch KiB after the ring)
+      else BLDS16(rsA, sa + t * 1024, aoff[j], ko);
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) BLDS16(rsB, sb + (j * 8 + wave) * 1024, woff[j], wk);
+    wk += 128;
+    if (++kl == a.klines) {
+      kl = 0;
+      if (++tap < a.taps) tap_offsets(tap);
+    }
+  };
+
+  f32x4 acc[MI][WI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int i = 0; i < WI; ++i) acc[mi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 wf[2][WI], xf[2][MI];
+
+  const int frow = lane & 15, g = lane >> 4;
+  const int nsteps = a.taps * a.klines;
+  const int xfrag = (grp * GM + wm * WM + frow) * 128, wfrag = A_BYTES + (wn * WN + frow) * 128;
+  const int sw = lane & 7;
+
+  auto read_frags = [&](int buf) {
+    const unsigned char* st = smem + buf * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int coff = ((g + 4 * kk) ^ sw) << 4;
+#pragma unroll
+      for (int i = 0; i < WI; ++i) wf[kk][i] = *reinterpret_cast<const u32x4*>(st + wfrag + i * 2048 + coff);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) xf[kk][mi] = *reinterpret_cast<const u32x4*>(st + xfrag + mi * 2048 + coff);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  auto mma_all = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int i = 0; i < WI; ++i) Tr::mma(wf[kk][i], xf[kk][mi], acc[mi][i]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto wait_older = [&](bool more_in_flight) {  // all but the newest step's loads of this wave have landed
+    if (more_in_flight) {
+      if constexpr (NLOAD == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
+
+  stage_issue(0);
+  if (nsteps > 1) stage_issue(1);
+  wait_older(nsteps > 1);
+  __builtin_amdgcn_s_barrier();
+  int cur = 0, nx2 = 2;
+  for (int k = 0; k < nsteps; ++k) {
+    // ---- phase 2k
+    if (grp == 0) {
+      if (k + 2 < nsteps) stage_issue(nx2);
+      read_frags(cur);
+    } else if (k > 0) {
+      mma_all();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 2k+1
+    if (grp == 0) {
+      mma_all();
+    } else {
+      if (k + 2 < nsteps) stage_issue(nx2);
+      read_frags(cur);
+    }
+    wait_older(k + 2 < nsteps);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    cur = (cur == 2) ? 0 : cur + 1;
+    nx2 = (nx2 == 2) ? 0 : nx2 + 1;
+  }
+  if (grp == 1) mma_all();
+  conv_epilogue<T, MI, WI>(a, acc, m0 + grp * GM + wm * WM, n0 + wn * WN, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wave-specialised kernel: 128 x 128 tile, 8 waves = 4 CONSUMER waves (2x2 of 64x64: ds_read + MFMA only) + 4 LOADER
+// waves (LDS-DMA issue only).  Issuing one 1-KiB LDS-DMA costs a wave ~100-180 cycles of its in-order issue stream
+// (measured: the 4-wave kernel spends more issue time on its 8 DMAs per K-step than on its 32 MFMAs); moving the
+// DMAs to partner waves on the same SIMD takes them out of the MFMA waves' streams.  <= 128 VGPRs so that two blocks
+// (2 consumers + 2 loaders per SIMD) stay resident per CU; two LDS stages, one block barrier per K-step.
+// ------------------------------------------------------------------------------------------------
+template <typename Tr>
+__global__ __launch_bounds__(512, 4) void conv_igemm_ws_kernel(const IgemmArgs a) {
+  typedef typename Tr::elem T;
+  constexpr int BM = 128, BN = 128, MI = 4, WI = 4, WM = 64, WN = 64;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bid = ps_xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = bid % a.ntn, tm = bid / a.ntn;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nsteps = a.taps * a.klines;
+
+  if (wave >= 4) {
+    // ================= loader =================
+    const int lw = wave - 4;
+    const int srow = lane >> 3;
+    const int chunk_off = ((lane & 7) ^ srow) << 4;
+    int py[4], px[4], nb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + (j * 4 + lw) * 8 + srow;
+      if (m < a.M) {
+        const int hw = a.Ho * a.Wo;
+        const int n = m / hw, rem = m - n * hw;
+        const int p = rem / a.Wo, q = rem - p * a.Wo;
+        py[j] = p * a.mul;
+        px[j] = q * a.mul;
+        nb[j] = n * a.Hs * a.Ws;
+      } else {
+        py[j] = -(1 << 20);
+        px[j] = 0;
+        nb[j] = 0;
+      }
+    }
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, (int)a.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, 0, (int)a.wgt_bytes, 0x00020000);
+    unsigned woff[4], aoff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int rb = (j * 4 + lw) * 8 + srow;
+      const int wg = rb / WN, within = rb % WN, fi = within >> 4, rho = within & 15;
+      const int cout = n0 + wg * WN + 4 * WI * (rho >> 2) + 4 * fi + (rho & 3);
+      woff[j] = (unsigned)(cout * a.wrow_bytes) + chunk_off;
+    }
+    int tap = 0, kl = 0, wk = 0;
+    auto tap_offsets = [&](int t) {
+      const int ty = (a.taps == 1) ? a.ctr : t / 3, tx = (a.taps == 1) ? a.ctr : t - (t / 3) * 3;
+      const int dy = (ty - a.ctr) * a.dstep, dx = (tx - a.ctr) * a.dstep;
+      const int dmask = (1 << a.div_shift) - 1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int yn = py[j] + dy, xn = px[j] + dx;
+        const int y = yn >> a.div_shift, x = xn >> a.div_shift;
+        const bool ok = (yn >= 0) && (xn >= 0) && (((yn | xn) & dmask) == 0) && (y < a.Hs) && (x < a.Ws);
+        aoff[j] = ok ? (unsigned)((nb[j] + y * a.Ws + x) * (int)a.pix_bytes) + chunk_off : PAD_ROW;
+      }
+    };
+    tap_offsets(0);
+    auto stage_issue = [&](int buf) {
+      unsigned char* sa = smem + buf * STAGE;
+      unsigned char* sb = smem + buf * STAGE + A_BYTES;
+      const int ko = kl * 128;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) BLDS16(rsA, sa + (j * 4 + lw) * 1024, aoff[j], ko);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) BLDS16(rsB, sb + (j * 4 + lw) * 1024, woff[j], wk);
+      wk += 128;
+      if (++kl == a.klines) {
+        kl = 0;
+        if (++tap < a.taps) tap_offsets(tap);
+      }
+    };
+    stage_issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < nsteps; ++s) {
+      if (s + 1 < nsteps) stage_issue((s + 1) & 1);  // the buffer the consumers finished before the last barrier
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
+
+  // ================= consumer =================
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x4 acc[MI][WI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int i = 0; i < WI; ++i) acc[mi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, g = lane >> 4;
+  const int xfrag = (wm * WM + frow) * 128, wfrag = A_BYTES + (wn * WN + frow) * 128;
+  const int sw = lane & 7;
+  __builtin_amdgcn_s_barrier();  // step 0 staged
+  for (int s = 0; s < nsteps; ++s) {
+    const unsigned char* st = smem + (s & 1) * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int coff = ((g + 4 * kk) ^ sw) << 4;
+      u32x4 wf[WI], xf[MI];
+#pragma unroll
+      for (int i = 0; i < WI; ++i) wf[i] = *reinterpret_cast<const u32x4*>(st + wfrag + i * 2048 + coff);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) xf[mi] = *reinterpret_cast<const u32x4*>(st + xfrag + mi * 2048 + coff);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int i = 0; i < WI; ++i) Tr::mma(wf[i], xf[mi], acc[mi][i]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  conv_epilogue<T, MI, WI>(a, acc, m0 + wm * WM, n0 + wn * WN, lane);
 }
 
 static int g_use_glds = 2;  // staging mode: 0 registers, 1 global_load_lds, 2 buffer_load ... lds
+static int g_use_pp = 0;       // experimental ping-pong kernel (correct, slower: r01 measurements)
+static int g_use_ws = 1;       // wave-specialised (loader/consumer) kernel for big problems
 static int g_use_3stage = 0;  // experimental 256x128 three-stage kernel: correct but slower than two 128x128 blocks per CU (r01 measurements)
+static int g_ablate = 0;
+static int g_force_bm = 0;  // testing: 112 or 128 forces the pixel-tile height of the 128-cout kernel
 static int g_force_bn = 0;  // testing: 64 or 128 forces the 2-stage tile width
 
-template <typename Tr, int BN>
-int launch_igemm(const IgemmArgs& a, int ntm, hipStream_t stream) {
-  const int grid = ntm * a.ntn;
-  const size_t lds = 2 * (128 * 128 + BN * 128);
+template <typename Tr, int BM, int BN, int WMW, int WNW>
+int launch_igemm(const IgemmArgs& a0, hipStream_t stream) {
+  IgemmArgs a = a0;
+  a.ntn = a.Cd / BN;
+  const int grid = ((a.M + BM - 1) / BM) * a.ntn;
+  const size_t lds = 2 * (BM * 128 + BN * 128);
+  const dim3 block(64 * WMW * WNW);
   if (g_use_glds == 2) {
-    hipLaunchKernelGGL((conv_igemm_kernel<Tr, BN, 2>), dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WMW, WNW, 2>), dim3(grid), block, lds, stream, a);
   } else if (g_use_glds == 1) {
-    hipLaunchKernelGGL((conv_igemm_kernel<Tr, BN, 1>), dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WMW, WNW, 1>), dim3(grid), block, lds, stream, a);
   } else {
-    hipLaunchKernelGGL((conv_igemm_kernel<Tr, BN, 0>), dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WMW, WNW, 0>), dim3(grid), block, lds, stream, a);
   }
   PS_CHECK_LAUNCH("conv_igemm");
   return PS_OK;
@@ -472,6 +801,7 @@ int set_extents(IgemmArgs& a, long long src_bytes, long long wgt_bytes) {
   PS_REQUIRE(src_bytes < (1LL << 31) && wgt_bytes < (1LL << 31), "conv: tensor larger than 2 GiB (%lld / %lld bytes)", src_bytes, wgt_bytes);
   a.src_bytes = (unsigned)src_bytes;
   a.wgt_bytes = (unsigned)wgt_bytes;
+  a.ablate = g_ablate;
   return PS_OK;
 }
 
@@ -486,16 +816,43 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
     PS_CHECK_LAUNCH("conv_igemm3");
     return PS_OK;
   }
-  const int ntm = (a.M + 127) / 128;
-  // BN = 128 whenever it divides Cd and there are enough tiles to fill 256 CUs twice over; else 64.
-  if (g_force_bn != 64 && a.Cd % 128 == 0 && ((long long)ntm * (a.Cd / 128) >= 512 || g_force_bn == 128)) {
+  // big problems: ping-pong kernel, one 8-wave block per CU; pick the group height by the busiest CU's load
+  if (g_use_pp && g_use_glds == 2 && a.Cd % 128 == 0) {
+    const long long n128 = a.Cd / 128;
+    const long long b256 = ((a.M + 255) / 256) * n128, b224 = ((a.M + 223) / 224) * n128;
+    if (b256 >= 512 || g_use_pp == 2) {
+      const long long c256 = ((b256 + 255) / 256) * 256, c224 = ((b224 + 255) / 256) * 224;
+      IgemmArgs b = a;
+      b.ntn = (int)n128;
+      if ((g_force_bm == 0 && c224 < c256) || g_force_bm == 112) {
+        hipLaunchKernelGGL((conv_igemm_pp_kernel<Tr, 112>), dim3((unsigned)b224), dim3(512), 3 * (224 * 128 + 128 * 128) + 1024, s, b);
+      } else {
+        hipLaunchKernelGGL((conv_igemm_pp_kernel<Tr, 128>), dim3((unsigned)b256), dim3(512), 3 * (256 * 128 + 128 * 128) + 1024, s, b);
+      }
+      PS_CHECK_LAUNCH("conv_igemm_pp");
+      return PS_OK;
+    }
+  }
+  if (g_use_ws && g_use_glds == 2 && a.Cd % 128 == 0 && (((long long)(a.M + 127) / 128) * (a.Cd / 128) >= 512 || g_use_ws == 2)) {
     IgemmArgs b = a;
     b.ntn = a.Cd / 128;
-    return launch_igemm<Tr, 128>(b, ntm, s);
+    hipLaunchKernelGGL((conv_igemm_ws_kernel<Tr>), dim3((unsigned)(((a.M + 127) / 128) * b.ntn)), dim3(512), 2 * (128 * 128 + 128 * 128), s, b);
+    PS_CHECK_LAUNCH("conv_igemm_ws");
+    return PS_OK;
   }
-  IgemmArgs b = a;
-  b.ntn = a.Cd / 64;
-  return launch_igemm<Tr, 64>(b, ntm, s);
+  // Tile choice.  Two blocks are resident per CU: the launch takes as long as the busiest CU needs for its
+  // ceil(blocks / 256) blocks, so compare pixel-tile heights by (blocks on the busiest CU) x (tile height).
+  const long long t128 = (a.M + 127) / 128, t112 = (a.M + 111) / 112;
+  if (a.Cd % 128 == 0 && g_force_bn != 64) {
+    const long long n128 = a.Cd / 128;
+    const long long c128 = ((t128 * n128 + 255) / 256) * 128, c112 = ((t112 * n128 + 255) / 256) * 112;
+    const bool big = t128 * n128 >= 512 || g_force_bn == 128;
+    if (big && (g_force_bm == 112 || (g_force_bm == 0 && c112 * 100 < c128 * 90))) return launch_igemm<Tr, 112, 128, 1, 4>(a, s);
+    if (big && g_force_bm == 1288) return launch_igemm<Tr, 128, 128, 2, 4>(a, s);  // experiment: 8 waves of 64x32
+    if (big && g_force_bm == 1289) return launch_igemm<Tr, 128, 128, 4, 2>(a, s);  // experiment: 8 waves of 32x64
+    if (big) return launch_igemm<Tr, 128, 128, 2, 2>(a, s);
+  }
+  return launch_igemm<Tr, 128, 64, 4, 1>(a, s);
 }
 
 }  // namespace
@@ -503,6 +860,10 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
 extern "C" void ps_debug_set_glds(int on) { g_use_glds = on; }  // 0 | 1 | 2
 extern "C" void ps_debug_set_3stage(int on) { g_use_3stage = on; }
 extern "C" void ps_debug_set_bn(int bn) { g_force_bn = bn; }
+extern "C" void ps_debug_set_bm(int bm) { g_force_bm = bm; }
+extern "C" void ps_debug_set_ablate(int v) { g_ablate = v; }
+extern "C" void ps_debug_set_pp(int v) { g_use_pp = v; }
+extern "C" void ps_debug_set_ws(int v) { g_use_ws = v; }
 
 extern "C" int ps_conv_supported(const ps_conv_geom* g) { return check_geom(g) == PS_OK ? 1 : 0; }
 

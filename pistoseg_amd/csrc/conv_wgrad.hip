@@ -237,10 +237,19 @@ int launch_wgrad(WgradArgs a, hipStream_t s) {
   a.dp = (Tr::KP / a.Wo) % a.Ho;
   a.dn = Tr::KP / (a.Wo * a.Ho);
   const long long tiles = (long long)a.tiles_co * a.tiles_ci * a.taps;
-  long long splits = (1536 + tiles - 1) / tiles;           // aim for >= ~1.5k blocks (256 CUs x 2-3 resident)
-  const long long max_splits = (a.ksteps + 7) / 8;          // at least 8 K-steps per block
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
+  // Split-K choice.  Two blocks are resident per CU; the launch takes as long as the busiest CU needs for its
+  // ceil(blocks / 256) blocks of (K-steps per block + epilogue).  Pick the split count minimising that estimate
+  // (ties go to fewer splits = fewer f32 atomics).
+  const long long max_splits = (a.ksteps + 7) / 8 > 0 ? (a.ksteps + 7) / 8 : 1;  // at least 8 K-steps per block
+  long long splits = 1, best = -1;
+  for (long long sp = 1; sp <= max_splits && tiles * sp <= 16384; ++sp) {
+    const long long per = (a.ksteps + sp - 1) / sp;
+    const long long live = (a.ksteps + per - 1) / per;  // splits that actually get work
+    const long long per_cu = (tiles * live + 255) / 256;  // blocks the busiest CU runs, two at a time
+    // two co-resident blocks take ~1.4x the time of one alone (measured: they hide each other's latencies)
+    const long long cost = ((per_cu / 2) * 14 + (per_cu % 2) * 10) * (per + 8);
+    if (best < 0 || cost < best) { best = cost; splits = sp; }
+  }
   a.splits = (int)splits;
   const size_t lds = 2 * (size_t)Tr::KP * (BCO + BCI) * Tr::ES;
   hipLaunchKernelGGL((conv_wgrad_kernel<Tr, BCO, BCI>), dim3((unsigned)(tiles * splits)), dim3(256), lds, s, a);

@@ -28,9 +28,10 @@ def _conv_label(kind: str, dtype: int, m: int, cd: int) -> str:
     dt = "bf16" if dtype == PS_BF16 else "f32"
     if kind == "wgrad":
         return f"conv_wgrad_kernel<{dt}>"
-    ntm = (m + 127) // 128
-    bn = 128 if (cd % 128 == 0 and ntm * (cd // 128) >= 512) else 64
-    return f"conv_igemm_kernel<{dt},BN={bn}>"
+    t128 = (m + 127) // 128
+    if cd % 128 == 0 and t128 * (cd // 128) >= 512:
+        return f"conv_igemm_ws_kernel<{dt}>"
+    return f"conv_igemm_kernel<{dt},128x64>"
 
 
 def _launch(label: str, flops: float, fn):

@@ -332,8 +332,8 @@ def test_optimizers_match_torch():
     # (n, h, w, cin, cout, k, s, d): large enough for the 256x128 three-stage kernel (>= 256 tiles)
     (4, 28, 28, 2048, 4096, 1, 1, 1), (16, 28, 28, 512, 1024, 3, 1, 4), (12, 56, 56, 256, 512, 3, 2, 1), (3, 112, 112, 128, 128, 3, 1, 1),
 ])
-def test_conv_three_stage_kernel_is_bit_identical_to_two_stage(case, dtype):
-    """The 3-stage LDS-DMA ring changes the pipeline, not the arithmetic: every output element is the same MFMA
+def test_conv_pipelined_kernels_are_bit_identical_to_two_stage(case, dtype):
+    """The 8-wave ping-pong kernel and the 3-stage LDS-DMA ring change the pipeline and the tiling, not the arithmetic: every output element is the same MFMA
     chain over the same K order, so fwd and dgrad must agree BITWISE with the 2-stage kernel (race screen: repeated),
     and one image is checked against the CPU."""
     from pistoseg_amd import _lib, ops
@@ -364,14 +364,66 @@ def test_conv_three_stage_kernel_is_bit_identical_to_two_stage(case, dtype):
 
     try:
         lib.ps_debug_set_3stage(0)
+        lib.ps_debug_set_pp(0)
+        lib.ps_debug_set_ws(0)
         ref = run()
-        lib.ps_debug_set_3stage(1)
-        for _ in range(3):
-            got = run()
-            for a_, b_ in zip(got, ref):
-                assert torch.equal(a_, b_)
+        # (3stage, ping-pong, forced group height, wave-specialised)
+        for setup in ((1, 0, 0, 0), (0, 2, 0, 0), (0, 2, 112, 0), (0, 2, 128, 0), (0, 0, 0, 2)):
+            lib.ps_debug_set_3stage(setup[0])
+            lib.ps_debug_set_pp(setup[1])
+            lib.ps_debug_set_bm(setup[2])
+            lib.ps_debug_set_ws(setup[3])
+            for _ in range(3):
+                got = run()
+                for a_, b_ in zip(got, ref):
+                    assert torch.equal(a_, b_), setup
     finally:
         lib.ps_debug_set_3stage(0)
+        lib.ps_debug_set_pp(0)
+        lib.ps_debug_set_bm(0)
+        lib.ps_debug_set_ws(1)
     cpu = F.conv2d(x[:1].permute(0, 3, 1, 2), wt, stride=s, padding=d if k == 3 else 0, dilation=d) + res[:1].float().cpu().permute(0, 3, 1, 2)
     tol = F32_TOL if dtype == torch.float32 else BF16_TOL
     assert rel_err(ref[0][:1].float().cpu(), nhwc(cpu)) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("bm", [112, 128])
+@pytest.mark.parametrize("case", [(128, 256, 3, 2, 1), (256, 256, 3, 1, 2), (512, 128, 1, 1, 1)])
+def test_conv_pixel_tile_variants(case, bm, dtype):
+    """The 112-pixel (7-fragment, waves 1x4) and 128-pixel (waves 2x2) tilings of the 128-cout kernel, forced on a
+    small problem with ragged M, against the CPU (fwd with the full epilogue, and dgrad)."""
+    from pistoseg_amd import _lib, ops
+
+    lib = _lib.load()
+    cin, cout, k, s, d = case
+    n, h, w = 3, 15, 14
+    g = torch.Generator().manual_seed(cin + bm)
+    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    x = q(torch.randn(n, cin, h, w, generator=g)).requires_grad_(True)
+    wt = q(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5)
+    y = F.conv2d(x, wt, stride=s, padding=d if k == 3 else 0, dilation=d)
+    res = q(torch.randn(y.shape, generator=g))
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    act = F.relu((y + res) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    gy = q(torch.randn(y.shape, generator=g))
+    y.backward(gy)
+    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    spec = ops.ConvSpec(cin, cout, k, s, d)
+    D = dev()
+    try:
+        lib.ps_debug_set_bn(128)
+        lib.ps_debug_set_bm(bm)
+        ho, wo = spec.out_hw(h, w)
+        out_raw = torch.full((n, ho, wo, cout), float("nan"), device=D, dtype=dtype)
+        out_act = torch.full((n, ho, wo, cout), float("nan"), device=D, dtype=dtype)
+        ops.conv2d_fwd(spec, nhwc(x.detach()).to(D, dtype), w_fwd_layout(wt).to(D, dtype), add0=nhwc(res).to(D, dtype), out_raw=out_raw,
+                       bn_scale=scale.to(D), bn_shift=shift.to(D), out_act=out_act)
+        assert rel_err(out_raw.float().cpu(), nhwc((y + res).detach())) < tol
+        assert rel_err(out_act.float().cpu(), nhwc(act.detach())) < tol
+        gx = torch.full((n, h, w, cin), float("nan"), device=D, dtype=dtype)
+        ops.conv2d_dgrad(spec, nhwc(gy).to(D, dtype), w_dgrad_layout(wt).to(D, dtype), (h, w), out_raw=gx)
+        assert rel_err(gx.float().cpu(), nhwc(x.grad)) < tol
+    finally:
+        lib.ps_debug_set_bn(0)
+        lib.ps_debug_set_bm(0)

@@ -53,6 +53,8 @@ def main():
             for r in range(3):  # interleaved rounds
                 for vn, vv in variants:
                     lib.ps_debug_set_3stage(0)
+                    lib.ps_debug_set_pp(0)
+                    lib.ps_debug_set_ws(0)
                     getattr(lib, "ps_debug_set_" + vn)(int(vv))
                     fns[what]()
                     torch.cuda.synchronize()
@@ -70,6 +72,10 @@ def main():
         print(line, flush=True)
     lib.ps_debug_set_3stage(0)
     lib.ps_debug_set_bn(0)
+    lib.ps_debug_set_bm(0)
+    lib.ps_debug_set_ablate(0)
+    lib.ps_debug_set_pp(0)
+    lib.ps_debug_set_ws(1)
 
 if __name__ == "__main__":
     main()
