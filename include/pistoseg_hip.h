@@ -262,6 +262,8 @@ void ps_debug_set_ablate(int v);
 void ps_debug_set_pp(int v);
 /* Testing hook: 1 (default) = big problems use the wave-specialised (4 loader + 4 consumer waves) conv kernel, 0 = never, 2 = always. */
 void ps_debug_set_ws(int v);
+/* Testing hook: 1 (default) = 128x128 weight-gradient tiles use the wave-specialised variant, 0 = the 4-wave kernel. */
+void ps_debug_set_wgrad_ws(int v);
 
 #ifdef __cplusplus
 }

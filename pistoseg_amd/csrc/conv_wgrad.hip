@@ -66,8 +66,11 @@ __device__ __forceinline__ int row_swz(int R) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(lptr), 16, (int)(voff), (int)(soff), 0, 0)
 constexpr unsigned PAD_ROW = 0x80000000u;
 
-template <typename Tr, int BCO, int BCI>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+// WS (wave-specialised): 8 waves; waves 4-7 only issue the LDS-DMA (and track the tap-shifted pixel addresses), waves
+// 0-3 only do transposed LDS reads + MFMA, <= 128 VGPRs so two blocks stay resident per CU (same idea and measurement
+// as conv_igemm_ws_kernel: issuing the DMAs costs a wave more issue time than its MFMAs).
+template <typename Tr, int BCO, int BCI, bool WS>
+__global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 1) void conv_wgrad_kernel(const WgradArgs a) {
   constexpr int ES = Tr::ES, KP = Tr::KP;
   constexpr int RBG = BCO * ES, RBX = BCI * ES;           // LDS row bytes of the dY / X tiles
   constexpr int G_BYTES = KP * RBG, X_BYTES = KP * RBX, STAGE = G_BYTES + X_BYTES;
@@ -76,7 +79,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   constexpr int MI = BCO / 32, NI = BCI / 32;             // 16x16 fragments per wave (2x2 waves)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = WS && wave_all >= 4;
+  const int wave = wave_all & 3;  // index within the role
   // block -> (co tile, ci tile, tap, split)
   int bid = blockIdx.x;
   const int split = bid % a.splits; bid /= a.splits;
@@ -149,11 +155,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int g = lane >> 4, l16 = lane & 15;
-  stage(0, ks0);
-  __syncthreads();
+  if constexpr (WS) {
+    if (loader) {
+      stage(0, ks0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      for (int ks = ks0; ks < ks1; ++ks) {
+        if (ks + 1 < ks1) stage(((ks - ks0) & 1) ^ 1, ks + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      return;
+    }
+    __builtin_amdgcn_s_barrier();
+  } else {
+    stage(0, ks0);
+    __syncthreads();
+  }
   for (int ks = ks0; ks < ks1; ++ks) {
     const int cur = (ks - ks0) & 1;
-    if (ks + 1 < ks1) stage(cur ^ 1, ks + 1);
+    if constexpr (!WS) {
+      if (ks + 1 < ks1) stage(cur ^ 1, ks + 1);
+    }
     const unsigned char* sg = smem + cur * STAGE;
     const unsigned char* sx = sg + G_BYTES;
     if constexpr (ES == 2) {
@@ -211,7 +234,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
           for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
       }
     }
-    __syncthreads();
+    if constexpr (WS) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    } else {
+      __syncthreads();
+    }
   }
 
   // D[row = cout: 4g + r][col = cin: l16]
@@ -227,6 +255,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         atomicAdd(a.dw + co * wrow + (long long)tap * a.cin + ci, acc[i][j][r]);
       }
 }
+
+static int g_wgrad_ws = 1;
 
 template <typename Tr, int BCO, int BCI>
 int launch_wgrad(WgradArgs a, hipStream_t s) {
@@ -252,7 +282,11 @@ int launch_wgrad(WgradArgs a, hipStream_t s) {
   }
   a.splits = (int)splits;
   const size_t lds = 2 * (size_t)Tr::KP * (BCO + BCI) * Tr::ES;
-  hipLaunchKernelGGL((conv_wgrad_kernel<Tr, BCO, BCI>), dim3((unsigned)(tiles * splits)), dim3(256), lds, s, a);
+  if (g_wgrad_ws && BCO == 128 && BCI == 128) {
+    hipLaunchKernelGGL((conv_wgrad_kernel<Tr, BCO, BCI, true>), dim3((unsigned)(tiles * splits)), dim3(512), lds, s, a);
+  } else {
+    hipLaunchKernelGGL((conv_wgrad_kernel<Tr, BCO, BCI, false>), dim3((unsigned)(tiles * splits)), dim3(256), lds, s, a);
+  }
   PS_CHECK_LAUNCH("conv_wgrad");
   return PS_OK;
 }
@@ -267,6 +301,8 @@ int dispatch_wgrad(const WgradArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" void ps_debug_set_wgrad_ws(int v) { g_wgrad_ws = v; }
 
 extern "C" int ps_conv2d_wgrad(const ps_conv_geom* g, const void* x, const void* dy, float* dw, void* stream) {
   PS_REQUIRE(g && x && dy && dw, "conv2d_wgrad: null argument");
