@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void fc8_bwd_kernel(const T* __restrict__ x, i
     if (c < C) ps_load8<float>(w + (long long)c * K + k0, wv[c]);
   }
   ps_load8<float>(scale7 + k0, s7);
+#pragma unroll 4
   for (int m = ma; m < me; ++m) {
     float xv[8], dv[8], g[8];
     ps_load8<T>(x + (long long)m * ldc + k0, xv);
@@ -224,20 +225,34 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float* __restrict__ v, __bf16* __restrict__ pb, long long n, float lr,
                                                     float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
   const long long stride = (long long)gridDim.x * 256 * 4;
-  const float step_size = lr / bc1;
+  const float step_size = lr / bc1, decay = 1.f - lr * wd;
+  auto upd = [&](float& pk, float gk, float& mk, float& vk) {
+    pk *= decay;
+    mk = mk + (gk - mk) * (1.f - b1);          // torch: exp_avg.lerp_(grad, 1 - beta1)
+    vk = b2 * vk + (1.f - b2) * gk * gk;        // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+    pk -= step_size * (mk / (sqrtf(vk) / bc2_sqrt + eps));
+  };
   for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
-    const int cnt = (i + 4 <= n) ? 4 : (int)(n - i);
-    for (int j = 0; j < cnt; ++j) {
-      const long long k = i + j;
-      float pk = p[k];
-      const float gk = g[k];
-      pk *= 1.f - lr * wd;
-      const float mk = m[k] + (gk - m[k]) * (1.f - b1);          // torch: exp_avg.lerp_(grad, 1 - beta1)
-      const float vk = b2 * v[k] + (1.f - b2) * gk * gk;          // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
-      const float denom = sqrtf(vk) / bc2_sqrt + eps;
-      pk -= step_size * (mk / denom);
-      p[k] = pk; m[k] = mk; v[k] = vk;
-      if (pb) pb[k] = static_cast<__bf16>(pk);
+    if (i + 4 <= n) {  // 16-byte accesses (the arenas are 16-byte aligned)
+      float4 pk = *reinterpret_cast<const float4*>(p + i), mk = *reinterpret_cast<const float4*>(m + i), vk = *reinterpret_cast<const float4*>(v + i);
+      const float4 gk = *reinterpret_cast<const float4*>(g + i);
+      upd(pk.x, gk.x, mk.x, vk.x); upd(pk.y, gk.y, mk.y, vk.y); upd(pk.z, gk.z, mk.z, vk.z); upd(pk.w, gk.w, mk.w, vk.w);
+      *reinterpret_cast<float4*>(p + i) = pk;
+      *reinterpret_cast<float4*>(m + i) = mk;
+      *reinterpret_cast<float4*>(v + i) = vk;
+      if (pb) {
+        uint2 o;
+        o.x = ps_f32_to_bf16(pk.x) | (static_cast<uint32_t>(ps_f32_to_bf16(pk.y)) << 16);
+        o.y = ps_f32_to_bf16(pk.z) | (static_cast<uint32_t>(ps_f32_to_bf16(pk.w)) << 16);
+        *reinterpret_cast<uint2*>(pb + i) = o;
+      }
+    } else {
+      for (long long k = i; k < n; ++k) {
+        float pk = p[k], mk = m[k], vk = v[k];
+        upd(pk, g[k], mk, vk);
+        p[k] = pk; m[k] = mk; v[k] = vk;
+        if (pb) pb[k] = static_cast<__bf16>(pk);
+      }
     }
   }
 }
@@ -359,6 +374,8 @@ extern "C" int ps_adamw_step(float* p, const float* g, float* m, float* v, void*
                              float beta2, float eps, float weight_decay, int32_t step, void* stream) {
   PS_REQUIRE(p && g && m && v && n >= 0 && step >= 1, "adamw_step: bad argument");
   if (n == 0) return PS_OK;
+  PS_REQUIRE(ps_aligned16(p) && ps_aligned16(g) && ps_aligned16(m) && ps_aligned16(v) && (!p_bf16 || (reinterpret_cast<uintptr_t>(p_bf16) & 7u) == 0),
+             "adamw_step: arenas must be 16-byte aligned");
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, (__bf16*)p_bf16,
