@@ -69,6 +69,26 @@ def timed(fn, steps, dist_on):
     return dt
 
 
+def pmc_traffic(kernel_label):
+    """HBM-side bytes per launch of the dominant kernel from the newest committed PMC summary (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled as the gfx950 guide prescribes).  PMC counters
+    cannot be collected from inside the timed run, so this is read from profiles/ (None if absent)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+    if not files:
+        return None
+    try:
+        data = json.load(open(files[-1]))
+    except Exception:
+        return None
+    stem = kernel_label.split("<")[0]
+    for k, v in data.items():
+        if stem in k:
+            return {"bytes_per_launch": round(v["hbm_bytes_per_launch_corrected"]), "source": os.path.basename(files[-1])}
+    return None
+
+
 def roofline_leg(run_step, precision):
     """One instrumented step: HIP events around every conv launch on the launch stream."""
     from pistoseg_amd import ops
@@ -91,7 +111,7 @@ def roofline_leg(run_step, precision):
                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in per.items()}
     return {
         "bound": "mfma", "kernel": name, "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(achieved / peak, 4), "traffic": None,
+        "frac": round(achieved / peak, 4), "traffic": pmc_traffic(name),
         "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 1),
         "flops_per_launch_avg": d["flops"] / d["launches"], "all_conv_kernels": kernels,
     }
