@@ -264,6 +264,10 @@ void ps_debug_set_pp(int v);
 void ps_debug_set_ws(int v);
 /* Testing hook: 1 (default) = 128x128 weight-gradient tiles use the wave-specialised variant, 0 = the 4-wave kernel. */
 void ps_debug_set_wgrad_ws(int v);
+/* Testing hook: cout tiles per super-column of the conv block raster (default 4; 0 = plain row-major). */
+void ps_debug_set_supertile(int v);
+/* Testing hook: weight-gradient block order: 0 pixel range slowest, 1 pixel range fastest, -1 (default) chosen by shape. */
+void ps_debug_set_wgrad_raster(int v);
 
 #ifdef __cplusplus
 }

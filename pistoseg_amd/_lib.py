@@ -89,6 +89,8 @@ PROTOTYPES = {
     "ps_debug_set_pp": (None, [C.c_int]),
     "ps_debug_set_ws": (None, [C.c_int]),
     "ps_debug_set_wgrad_ws": (None, [C.c_int]),
+    "ps_debug_set_supertile": (None, [C.c_int]),
+    "ps_debug_set_wgrad_raster": (None, [C.c_int]),
     "ps_bgemm": (C.c_int, [_I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P]),
     "ps_softmax_rows": (C.c_int, [_P, _L, _I, _P]),
     "ps_rfm_apply": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),

@@ -28,12 +28,29 @@ struct IgemmArgs {
   long long pix_bytes;        // source channel stride in bytes
   long long wrow_bytes;       // taps*Cs*esize
   int ntn;                    // number of cout tiles
+  int ntm;                    // number of pixel tiles
+  int supertile;              // cout tiles per super-column of the block raster (0 = plain row-major)
   int Cd;                     // produced channels
   unsigned src_bytes;         // extent of the gathered tensor / of the weights (buffer descriptors' num_records)
   unsigned wgt_bytes;
   int ablate;                 // timing experiments only: 1 = stage the first two K-steps only (no further loads)
   ps_epilogue epi;
 };
+
+// Block id -> (pixel tile, cout tile).  The blocks resident on one XCD at a time are a contiguous id range (see
+// ps_xcd_remap), so ids are laid out in super-columns of G (=4) cout tiles: 64 consecutive blocks then cover 16 x 4 tiles
+// (4 weight tiles + 16 activation tiles stream through that XCD's 4 MiB L2) instead of 2 x 32 (all of a wide layer's
+// weights per 2 pixel tiles: 16 MB for the 2048->4096 1x1, re-streamed from the Infinity Cache 25 times per XCD).
+__device__ __forceinline__ void ps_tile_of_block(int bid, int ntn, int ntm, int& tm, int& tn, int G) {
+  if (G > 0 && ntn > G && ntn % G == 0) {
+    const int per = G * ntm, sc = bid / per, r = bid - sc * per;
+    tm = r / G;
+    tn = sc * G + (r - tm * G);
+  } else {
+    tn = bid % ntn;
+    tm = bid / ntn;
+  }
+}
 
 struct TraitsBF16 {
   typedef __bf16 elem;
@@ -166,7 +183,8 @@ __global__ __launch_bounds__(64 * WMW * WNW) void conv_igemm_kernel(const IgemmA
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bid = ps_xcd_remap(blockIdx.x, gridDim.x);
-  const int tn = bid % a.ntn, tm = bid / a.ntn;
+  int tm, tn;
+  ps_tile_of_block(bid, a.ntn, a.ntm, tm, tn, a.supertile);
   const int m0 = tm * BM, n0 = tn * BN;
   const int wm = wave / WNW, wn = wave % WNW;
 
@@ -325,7 +343,8 @@ __global__ __launch_bounds__(512) void conv_igemm3_kernel(const IgemmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bid = ps_xcd_remap(blockIdx.x, gridDim.x);
-  const int tn = bid % a.ntn, tm = bid / a.ntn;
+  int tm, tn;
+  ps_tile_of_block(bid, a.ntn, a.ntm, tm, tn, a.supertile);
   const int m0 = tm * BM, n0 = tn * BN;
   const int wm = wave >> 1, wn = wave & 1;
 
@@ -464,7 +483,8 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const IgemmArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wl = wave & 3;
   const int bid = ps_xcd_remap(blockIdx.x, gridDim.x);
-  const int tn = bid % a.ntn, tm = bid / a.ntn;
+  int tm, tn;
+  ps_tile_of_block(bid, a.ntn, a.ntm, tm, tn, a.supertile);
   const int m0 = tm * BM, n0 = tn * BN;
   const int wm = wl / WNW, wn = wl % WNW;
 
@@ -628,7 +648,8 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_ws_kernel(const IgemmArgs a
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int bid = ps_xcd_remap(blockIdx.x, gridDim.x);
-  const int tn = bid % a.ntn, tm = bid / a.ntn;
+  int tm, tn;
+  ps_tile_of_block(bid, a.ntn, a.ntm, tm, tn, a.supertile);
   const int m0 = tm * BM, n0 = tn * BN;
   const int nsteps = a.taps * a.klines;
 
@@ -740,6 +761,7 @@ static int g_use_pp = 0;       // experimental ping-pong kernel (correct, slower
 static int g_use_ws = 1;       // wave-specialised (loader/consumer) kernel for big problems
 static int g_use_3stage = 0;  // experimental 256x128 three-stage kernel: correct but slower than two 128x128 blocks per CU (r01 measurements)
 static int g_ablate = 0;
+static int g_supertile = 4;  // measured best of {0,4,8,16} on the wide 28x28 layers (r01)
 static int g_force_bm = 0;  // testing: 112 or 128 forces the pixel-tile height of the 128-cout kernel
 static int g_force_bn = 0;  // testing: 64 or 128 forces the 2-stage tile width
 
@@ -747,7 +769,8 @@ template <typename Tr, int BM, int BN, int WMW, int WNW>
 int launch_igemm(const IgemmArgs& a0, hipStream_t stream) {
   IgemmArgs a = a0;
   a.ntn = a.Cd / BN;
-  const int grid = ((a.M + BM - 1) / BM) * a.ntn;
+  a.ntm = (a.M + BM - 1) / BM;
+  const int grid = a.ntm * a.ntn;
   const size_t lds = 2 * (BM * 128 + BN * 128);
   const dim3 block(64 * WMW * WNW);
   if (g_use_glds == 2) {
@@ -802,6 +825,7 @@ int set_extents(IgemmArgs& a, long long src_bytes, long long wgt_bytes) {
   a.src_bytes = (unsigned)src_bytes;
   a.wgt_bytes = (unsigned)wgt_bytes;
   a.ablate = g_ablate;
+  a.supertile = g_supertile;
   return PS_OK;
 }
 
@@ -811,7 +835,8 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
   if (g_use_3stage && g_use_glds == 2 && a.Cd % 128 == 0 && (long long)((a.M + 255) / 256) * (a.Cd / 128) >= 256) {
     IgemmArgs b = a;
     b.ntn = a.Cd / 128;
-    const int grid = ((a.M + 255) / 256) * b.ntn;
+    b.ntm = (a.M + 255) / 256;
+    const int grid = b.ntm * b.ntn;
     hipLaunchKernelGGL((conv_igemm3_kernel<Tr>), dim3(grid), dim3(512), 3 * (256 * 128 + 128 * 128), s, b);
     PS_CHECK_LAUNCH("conv_igemm3");
     return PS_OK;
@@ -824,6 +849,7 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
       const long long c256 = ((b256 + 255) / 256) * 256, c224 = ((b224 + 255) / 256) * 224;
       IgemmArgs b = a;
       b.ntn = (int)n128;
+      b.ntm = (int)(((g_force_bm == 0 && c224 < c256) || g_force_bm == 112) ? (a.M + 223) / 224 : (a.M + 255) / 256);
       if ((g_force_bm == 0 && c224 < c256) || g_force_bm == 112) {
         hipLaunchKernelGGL((conv_igemm_pp_kernel<Tr, 112>), dim3((unsigned)b224), dim3(512), 3 * (224 * 128 + 128 * 128) + 1024, s, b);
       } else {
@@ -836,7 +862,8 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
   if (g_use_ws && g_use_glds == 2 && a.Cd % 128 == 0 && (((long long)(a.M + 127) / 128) * (a.Cd / 128) >= 512 || g_use_ws == 2)) {
     IgemmArgs b = a;
     b.ntn = a.Cd / 128;
-    hipLaunchKernelGGL((conv_igemm_ws_kernel<Tr>), dim3((unsigned)(((a.M + 127) / 128) * b.ntn)), dim3(512), 2 * (128 * 128 + 128 * 128), s, b);
+    b.ntm = (a.M + 127) / 128;
+    hipLaunchKernelGGL((conv_igemm_ws_kernel<Tr>), dim3((unsigned)(b.ntm * b.ntn)), dim3(512), 2 * (128 * 128 + 128 * 128), s, b);
     PS_CHECK_LAUNCH("conv_igemm_ws");
     return PS_OK;
   }
@@ -864,6 +891,7 @@ extern "C" void ps_debug_set_bm(int bm) { g_force_bm = bm; }
 extern "C" void ps_debug_set_ablate(int v) { g_ablate = v; }
 extern "C" void ps_debug_set_pp(int v) { g_use_pp = v; }
 extern "C" void ps_debug_set_ws(int v) { g_use_ws = v; }
+extern "C" void ps_debug_set_supertile(int v) { g_supertile = v; }
 
 extern "C" int ps_conv_supported(const ps_conv_geom* g) { return check_geom(g) == PS_OK ? 1 : 0; }
 

@@ -43,6 +43,7 @@ struct WgradArgs {
   FastDiv div_hw, div_w;
   unsigned x_bytes, dy_bytes;  // buffer extents (num_records)
   int dq, dp, dn;              // how (q, p, n) of a pixel advance when its index grows by KP
+  int raster;                  // block order (see kernel)
 };
 
 struct WTraitsBF16 {
@@ -84,11 +85,21 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 1) void conv_wgrad_kernel(
   const bool loader = WS && wave_all >= 4;
   const int wave = wave_all & 3;  // index within the role
   // block -> (co tile, ci tile, tap, split)
-  int bid = blockIdx.x;
-  const int split = bid % a.splits; bid /= a.splits;
-  const int tci = bid % a.tiles_ci; bid /= a.tiles_ci;
-  const int tco = bid % a.tiles_co; bid /= a.tiles_co;
-  const int tap = bid;
+  // Raster: all (ci tile, co tile, tap) blocks of ONE pixel range are consecutive, so the blocks resident together
+  // share their dY chunk across ci tiles / taps and their X chunk across co tiles through L2 (order 1: legacy,
+  // split fastest -- neighbours share nothing).
+  int bid = blockIdx.x, split, tci, tco, tap;
+  if (a.raster == 1) {
+    split = bid % a.splits; bid /= a.splits;
+    tci = bid % a.tiles_ci; bid /= a.tiles_ci;
+    tco = bid % a.tiles_co; bid /= a.tiles_co;
+    tap = bid;
+  } else {
+    tci = bid % a.tiles_ci; bid /= a.tiles_ci;
+    tco = bid % a.tiles_co; bid /= a.tiles_co;
+    tap = bid % a.taps; bid /= a.taps;
+    split = bid;
+  }
   const int co0 = tco * BCO, ci0 = tci * BCI;
   const int ty = a.taps == 1 ? a.ctr : tap / 3, tx = a.taps == 1 ? a.ctr : tap - (tap / 3) * 3;
   const int dy_off = (ty - a.ctr) * a.dil, dx_off = (tx - a.ctr) * a.dil;
@@ -257,6 +268,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 1) void conv_wgrad_kernel(
 }
 
 static int g_wgrad_ws = 1;
+static int g_wgrad_raster = -1;  // -1: by shape (measured r01: pixel-range-slowest wins for 3x3 layers with >= 64 tiles)
 
 template <typename Tr, int BCO, int BCI>
 int launch_wgrad(WgradArgs a, hipStream_t s) {
@@ -266,6 +278,7 @@ int launch_wgrad(WgradArgs a, hipStream_t s) {
   a.dq = Tr::KP % a.Wo;
   a.dp = (Tr::KP / a.Wo) % a.Ho;
   a.dn = Tr::KP / (a.Wo * a.Ho);
+  a.raster = g_wgrad_raster >= 0 ? g_wgrad_raster : ((a.taps == 9 && (long long)a.tiles_co * a.tiles_ci * a.taps >= 64) ? 0 : 1);
   const long long tiles = (long long)a.tiles_co * a.tiles_ci * a.taps;
   // Split-K choice.  Two blocks are resident per CU; the launch takes as long as the busiest CU needs for its
   // ceil(blocks / 256) blocks of (K-steps per block + epilogue).  Pick the split count minimising that estimate
@@ -303,6 +316,7 @@ int dispatch_wgrad(const WgradArgs& a, hipStream_t s) {
 }  // namespace
 
 extern "C" void ps_debug_set_wgrad_ws(int v) { g_wgrad_ws = v; }
+extern "C" void ps_debug_set_wgrad_raster(int v) { g_wgrad_raster = v; }
 
 extern "C" int ps_conv2d_wgrad(const ps_conv_geom* g, const void* x, const void* dy, float* dw, void* stream) {
   PS_REQUIRE(g && x && dy && dw, "conv2d_wgrad: null argument");

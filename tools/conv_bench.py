@@ -54,7 +54,8 @@ def main():
                 for vn, vv in variants:
                     lib.ps_debug_set_3stage(0)
                     lib.ps_debug_set_pp(0)
-                    lib.ps_debug_set_ws(0)
+                    lib.ps_debug_set_ws(1)
+                    lib.ps_debug_set_supertile(4)
                     getattr(lib, "ps_debug_set_" + vn)(int(vv))
                     fns[what]()
                     torch.cuda.synchronize()
@@ -76,6 +77,7 @@ def main():
     lib.ps_debug_set_ablate(0)
     lib.ps_debug_set_pp(0)
     lib.ps_debug_set_ws(1)
+    lib.ps_debug_set_wgrad_raster(-1)
 
 if __name__ == "__main__":
     main()
