@@ -638,10 +638,12 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const IgemmArgs a) {
 // DMAs to partner waves on the same SIMD takes them out of the MFMA waves' streams.  <= 128 VGPRs so that two blocks
 // (2 consumers + 2 loaders per SIMD) stay resident per CU; two LDS stages, one block barrier per K-step.
 // ------------------------------------------------------------------------------------------------
-template <typename Tr>
+template <typename Tr, int BM>  // BM = 128: consumers 2x2 of 64x64; BM = 112: consumers 1x4 of 112x32 (balanced tiling, see above)
 __global__ __launch_bounds__(512, 4) void conv_igemm_ws_kernel(const IgemmArgs a) {
   typedef typename Tr::elem T;
-  constexpr int BM = 128, BN = 128, MI = 4, WI = 4, WM = 64, WN = 64;
+  constexpr int BN = 128, WMW = (BM == 128) ? 2 : 1, WNW = 4 / WMW;
+  constexpr int MI = BM / (16 * WMW), WI = BN / (16 * WNW), WM = 16 * MI, WN = 16 * WI;
+  constexpr int AINS = BM / 8;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -662,7 +664,7 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_ws_kernel(const IgemmArgs a
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int m = m0 + (j * 4 + lw) * 8 + srow;
-      if (m < a.M) {
+      if (m < a.M && j * 4 + lw < AINS) {
         const int hw = a.Ho * a.Wo;
         const int n = m / hw, rem = m - n * hw;
         const int p = rem / a.Wo, q = rem - p * a.Wo;
@@ -704,7 +706,8 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_ws_kernel(const IgemmArgs a
       unsigned char* sb = smem + buf * STAGE + A_BYTES;
       const int ko = kl * 128;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) BLDS16(rsA, sa + (j * 4 + lw) * 1024, aoff[j], ko);
+      for (int j = 0; j < 4; ++j)
+        if (AINS % 4 == 0 || j * 4 + lw < AINS) BLDS16(rsA, sa + (j * 4 + lw) * 1024, aoff[j], ko);
 #pragma unroll
       for (int j = 0; j < 4; ++j) BLDS16(rsB, sb + (j * 4 + lw) * 1024, woff[j], wk);
       wk += 128;
@@ -725,7 +728,7 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_ws_kernel(const IgemmArgs a
   }
 
   // ================= consumer =================
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WNW, wn = wave % WNW;
   f32x4 acc[MI][WI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -860,10 +863,18 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
     }
   }
   if (g_use_ws && g_use_glds == 2 && a.Cd % 128 == 0 && (((long long)(a.M + 127) / 128) * (a.Cd / 128) >= 512 || g_use_ws == 2)) {
+    // pixel-tile height by the busiest CU's load (two blocks resident per CU), as for the 4-wave kernel below
+    const long long n128 = a.Cd / 128, t128 = (a.M + 127) / 128, t112 = (a.M + 111) / 112;
+    const long long c128 = ((t128 * n128 + 255) / 256) * 128, c112 = ((t112 * n128 + 255) / 256) * 112;
     IgemmArgs b = a;
-    b.ntn = a.Cd / 128;
-    b.ntm = (a.M + 127) / 128;
-    hipLaunchKernelGGL((conv_igemm_ws_kernel<Tr>), dim3((unsigned)(b.ntm * b.ntn)), dim3(512), 2 * (128 * 128 + 128 * 128), s, b);
+    b.ntn = (int)n128;
+    if (g_force_bm == 112 || (g_force_bm == 0 && c112 * 100 < c128 * 90)) {
+      b.ntm = (int)t112;
+      hipLaunchKernelGGL((conv_igemm_ws_kernel<Tr, 112>), dim3((unsigned)(b.ntm * b.ntn)), dim3(512), 2 * (112 * 128 + 128 * 128), s, b);
+    } else {
+      b.ntm = (int)t128;
+      hipLaunchKernelGGL((conv_igemm_ws_kernel<Tr, 128>), dim3((unsigned)(b.ntm * b.ntn)), dim3(512), 2 * (128 * 128 + 128 * 128), s, b);
+    }
     PS_CHECK_LAUNCH("conv_igemm_ws");
     return PS_OK;
   }

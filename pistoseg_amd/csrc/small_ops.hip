@@ -7,55 +7,74 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------
-// conv1a: NCHW f32 image -> channels-last activation.  4 lanes per pixel, 16 couts each.
+// conv1a: NCHW f32 image -> channels-last activation, on the exact-f32 MFMA (16x16x4): the 27-tap im2col row of a
+// pixel is the B operand (lane (g = lane>>4, col = lane&15) fetches taps k = 4s + g of pixel col straight from the
+// image, zero outside), the [64][27] weights are the A operand held in registers for the whole kernel; 7 k-steps x 4
+// cout fragments per 16 pixels.  Same f32 arithmetic for both output dtypes; store-bound (64 channels per pixel).
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void conv1a_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ scale, const float* __restrict__ shift,
                                                      T* __restrict__ out_act, T* __restrict__ out_raw, int n, int h, int wd) {
-  __shared__ float ws[27][64];  // [k][cout], k = ci*9 + ky*3 + kx (OIHW order)
-  __shared__ float ssc[64], ssh[64];
-  for (int i = threadIdx.x; i < 27 * 64; i += 256) {
-    const int co = i / 27, k = i - co * 27;
-    ws[k][co] = w[i];
+  const int lane = threadIdx.x & 63, g = lane >> 4, col = lane & 15;
+  // A operand: lane supplies W[cout(f, col)][k = 4s + g]; cout(f, rho) = 16*(rho>>2) + 4f + (rho&3), so accumulator
+  // register r of fragment f in lane group g is channel 16g + 4f + r (16 contiguous channels per lane)
+  float wa[7][4];
+#pragma unroll
+  for (int sidx = 0; sidx < 7; ++sidx)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int k = 4 * sidx + g, co = 16 * (col >> 2) + 4 * f + (col & 3);
+      wa[sidx][f] = k < 27 ? w[co * 27 + k] : 0.f;
+    }
+  float sc[16], sh[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    sc[i] = scale ? scale[16 * g + i] : 1.f;
+    sh[i] = shift ? shift[16 * g + i] : 0.f;
   }
-  if (threadIdx.x < 64) {
-    ssc[threadIdx.x] = scale ? scale[threadIdx.x] : 1.f;
-    ssh[threadIdx.x] = shift ? shift[threadIdx.x] : 0.f;
+  // this lane's 7 taps: k = 4s + g -> (c, ky, kx)
+  int toff[7], tdy[7], tdx[7];
+#pragma unroll
+  for (int sidx = 0; sidx < 7; ++sidx) {
+    const int k = 4 * sidx + g, c = k / 9, r = k - 9 * c, ky = r / 3, kx = r - 3 * ky;
+    tdy[sidx] = k < 27 ? ky - 1 : (1 << 20);  // out-of-range tap -> never valid
+    tdx[sidx] = kx - 1;
+    toff[sidx] = c * h * wd;
   }
-  __syncthreads();
   const long long total = (long long)n * h * wd;
-  const int cg = threadIdx.x & 3;  // cout group of 16
-  for (long long pix = (long long)blockIdx.x * 64 + (threadIdx.x >> 2); pix < total; pix += (long long)gridDim.x * 64) {
-    const int img = (int)(pix / ((long long)h * wd));
-    const int rem = (int)(pix - (long long)img * h * wd);
+  const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+  for (long long p0 = wave_id * 16; p0 < total; p0 += nwaves * 16) {
+    const long long pix = p0 + col;
+    const bool live = pix < total;
+    const int img = live ? (int)(pix / ((long long)h * wd)) : 0;
+    const int rem = live ? (int)(pix - (long long)img * h * wd) : 0;
     const int y = rem / wd, xx = rem - y * wd;
-    float acc[16];
+    const float* xb = x + (long long)img * 3 * h * wd;
+    f32x4 acc[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int sidx = 0; sidx < 7; ++sidx) {
+      const int yy = y + tdy[sidx], xs = xx + tdx[sidx];
+      float v = 0.f;
+      if (live && yy >= 0 && yy < h && xs >= 0 && xs < wd) v = xb[toff[sidx] + yy * wd + xs];
 #pragma unroll
-    for (int ci = 0; ci < 3; ++ci)
+      for (int f = 0; f < 4; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[sidx][f], v, acc[f], 0, 0, 0);
+    }
+    if (!live) continue;
+    float v[16];
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
+    for (int f = 0; f < 4; ++f)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int yy = y + ky - 1, xs = xx + kx - 1;
-          float v = 0.f;
-          if (yy >= 0 && yy < h && xs >= 0 && xs < wd) v = x[(((long long)img * 3 + ci) * h + yy) * wd + xs];
-          const float* wr = &ws[ci * 9 + ky * 3 + kx][cg * 16];
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc[i] = fmaf(v, wr[i], acc[i]);
-        }
+      for (int r = 0; r < 4; ++r) v[4 * f + r] = acc[f][r];
     if (out_raw) {
-      ps_store8<T>(out_raw + pix * 64 + cg * 16, acc);
-      ps_store8<T>(out_raw + pix * 64 + cg * 16 + 8, acc + 8);
+      ps_store8<T>(out_raw + pix * 64 + 16 * g, v);
+      ps_store8<T>(out_raw + pix * 64 + 16 * g + 8, v + 8);
     }
     if (out_act) {
-      float a[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) a[i] = fmaxf(acc[i] * ssc[cg * 16 + i] + ssh[cg * 16 + i], 0.f);
-      ps_store8<T>(out_act + pix * 64 + cg * 16, a);
-      ps_store8<T>(out_act + pix * 64 + cg * 16 + 8, a + 8);
+      for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i] * sc[i] + sh[i], 0.f);
+      ps_store8<T>(out_act + pix * 64 + 16 * g, v);
+      ps_store8<T>(out_act + pix * 64 + 16 * g + 8, v + 8);
     }
   }
 }
@@ -116,7 +135,8 @@ __global__ __launch_bounds__(256) void fc8_fwd_kernel(const T* __restrict__ x, i
   }
 }
 
-// fc8 backward (+ ReLU(bn7) mask): a thread owns 8 channels and walks a pixel range.
+// fc8 backward (+ ReLU(bn7) mask): a thread owns 8 channels and walks a pixel range, four pixels per iteration so
+// that four 16-byte activation loads are in flight per lane (the kernel is a pure stream: read x, write dx).
 template <typename T>
 __global__ __launch_bounds__(256) void fc8_bwd_kernel(const T* __restrict__ x, int ldc, const float* __restrict__ w,
                                                       const float* __restrict__ drop, const float* __restrict__ scale7,
@@ -134,31 +154,41 @@ __global__ __launch_bounds__(256) void fc8_bwd_kernel(const T* __restrict__ x, i
     if (c < C) ps_load8<float>(w + (long long)c * K + k0, wv[c]);
   }
   ps_load8<float>(scale7 + k0, s7);
-#pragma unroll 4
-  for (int m = ma; m < me; ++m) {
-    float xv[8], dv[8], g[8];
-    ps_load8<T>(x + (long long)m * ldc + k0, xv);
-    if (drop) ps_load8<float>(drop + (long long)(m / ppi) * K + k0, dv);
-    else {
+  constexpr int U = 4;
+  for (int m0 = ma; m0 < me; m0 += U) {
+    float xv[U][8], dv[U][8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) dv[i] = 1.f;
-    }
+    for (int u = 0; u < U; ++u) {
+      const int m = min(m0 + u, me - 1);
+      ps_load8<T>(x + (long long)m * ldc + k0, xv[u]);
+      if (drop) ps_load8<float>(drop + (long long)(m / ppi) * K + k0, dv[u]);
+      else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) g[i] = 0.f;
-#pragma unroll
-    for (int c = 0; c < FC8_MAXC; ++c) {
-      if (c < C) {
-        const float d = dcam[(long long)m * C + c];  // wave-uniform
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          g[i] = fmaf(d, wv[c][i], g[i]);
-          gw[c][i] = fmaf(d, xv[i] * dv[i], gw[c][i]);
-        }
+        for (int i = 0; i < 8; ++i) dv[u][i] = 1.f;
       }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) g[i] = xv[i] > 0.f ? g[i] * dv[i] * s7[i] : 0.f;
-    ps_store8<T>(dx + (long long)m * ldc_dx + k0, g);
+    for (int u = 0; u < U; ++u) {
+      const int m = m0 + u;
+      if (m >= me) break;
+      float g[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) g[i] = 0.f;
+#pragma unroll
+      for (int c = 0; c < FC8_MAXC; ++c) {
+        if (c < C) {
+          const float d = dcam[(long long)m * C + c];  // wave-uniform
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            g[i] = fmaf(d, wv[c][i], g[i]);
+            gw[c][i] = fmaf(d, xv[u][i] * dv[u][i], gw[c][i]);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) g[i] = xv[u][i] > 0.f ? g[i] * dv[u][i] * s7[i] : 0.f;
+      ps_store8<T>(dx + (long long)m * ldc_dx + k0, g);
+    }
   }
 #pragma unroll
   for (int c = 0; c < FC8_MAXC; ++c) {
@@ -290,7 +320,8 @@ extern "C" int ps_conv1a_fwd(int32_t out_dtype, const float* x, const float* w, 
   PS_REQUIRE(n > 0 && h > 0 && wd > 0, "conv1a: empty input");
   PS_REQUIRE((!out_act || ps_aligned16(out_act)) && (!out_raw || ps_aligned16(out_raw)), "conv1a: misaligned output");
   const long long pix = (long long)n * h * wd;
-  const int grid = grid_for(pix, 64, 256 * 16);
+  PS_REQUIRE((long long)3 * h * wd < (1LL << 31), "conv1a: image too large");
+  const int grid = grid_for(pix, 64, 256 * 8);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (out_dtype == PS_BF16)
     hipLaunchKernelGGL(conv1a_kernel<__bf16>, dim3(grid), dim3(256), 0, s, x, w, scale, shift, (__bf16*)out_act, (__bf16*)out_raw, n, h, wd);

@@ -368,7 +368,7 @@ def test_conv_pipelined_kernels_are_bit_identical_to_two_stage(case, dtype):
         lib.ps_debug_set_ws(0)
         ref = run()
         # (3stage, ping-pong, forced group height, wave-specialised)
-        for setup in ((1, 0, 0, 0), (0, 2, 0, 0), (0, 2, 112, 0), (0, 2, 128, 0), (0, 0, 0, 2)):
+        for setup in ((1, 0, 0, 0), (0, 2, 0, 0), (0, 2, 112, 0), (0, 2, 128, 0), (0, 0, 0, 2), (0, 0, 112, 2), (0, 0, 128, 2)):
             lib.ps_debug_set_3stage(setup[0])
             lib.ps_debug_set_pp(setup[1])
             lib.ps_debug_set_bm(setup[2])
