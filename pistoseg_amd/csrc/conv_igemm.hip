@@ -33,7 +33,7 @@ struct IgemmArgs {
   int Cd;                     // produced channels
   unsigned src_bytes;         // extent of the gathered tensor / of the weights (buffer descriptors' num_records)
   unsigned wgt_bytes;
-  int ablate;                 // timing experiments only: 1 = stage the first two K-steps only (no further loads)
+  int ablate;                 // timing experiments only (results WRONG): 1 = stage the first two K-steps only; 2 = also no per-step barriers (ws kernel)
   ps_epilogue epi;
 };
 
@@ -631,6 +631,82 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const IgemmArgs a) {
   conv_epilogue<T, MI, WI>(a, acc, m0 + grp * GM + wm * WM, n0 + wn * WN, lane);
 }
 
+// Epilogue of the wave-specialised kernel (bf16): the per-channel scale/shift and the tile-shaped operands (residual
+// addend / ReLU-mask source / second addend) were brought into LDS by the LOADER waves while the consumers were still
+// in their last K-line, so the consumers' epilogue has no global-load latency in it (measured: ~11 us of the ~48 us a
+// 512-cout block lives were serialized epilogue/prologue latency).  Tile image: [row][256 B], 16-byte chunk c of row R
+// at position c ^ (R & 15) (conflict-free 16-byte reads of 16 different rows).
+template <int MI, int WI>
+__device__ __forceinline__ void conv_epilogue_lds(const IgemmArgs& a, f32x4 (&acc)[MI][WI], int mbase, int rbase, int cbase, int clocal,
+                                                  int lane, const float* prm, const unsigned char* t1, const unsigned char* t2) {
+  typedef __bf16 T;
+  constexpr int CH = 4 * WI, NV = CH / 8;
+  const int frow = lane & 15, g = lane >> 4;
+  const ps_epilogue& e = a.epi;
+  const int cb = cbase + CH * g, cl = clocal + CH * g;  // global / tile-local first channel of this lane
+  const bool bwd = e.mode == PS_EPI_RELUBWD;
+  auto tile8 = [&](const unsigned char* t, int R, int o, float* v) {  // 8 channels cl + 8o.. of tile row R
+    const int c = (cl + 8 * o) >> 3;
+    const uint4 raw = *reinterpret_cast<const uint4*>(t + R * 256 + ((c ^ (R & 15)) << 4));
+    v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
+    v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
+    v[4] = __uint_as_float(raw.z << 16); v[5] = __uint_as_float(raw.z & 0xffff0000u);
+    v[6] = __uint_as_float(raw.w << 16); v[7] = __uint_as_float(raw.w & 0xffff0000u);
+  };
+  // which operand sits in which tile (the loader uses the same rule)
+  const unsigned char* t_add0 = nullptr; const unsigned char* t_mask = nullptr; const unsigned char* t_add1 = nullptr;
+  if (!bwd) t_add0 = e.add0 ? t1 : nullptr;
+  else { t_mask = t1; if (e.add0) t_add0 = t2; else if (e.add1) t_add1 = t2; }
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int R = rbase + mi * 16 + frow, m = mbase + mi * 16 + frow;
+    if (m >= a.M) continue;
+#pragma unroll
+    for (int o = 0; o < NV; ++o) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = acc[mi][(8 * o + i) >> 2][(8 * o + i) & 3];
+      if (e.add0) {
+        float t[8];
+        if (t_add0) tile8(t_add0, R, o, t);
+        else ps_load8<T>(reinterpret_cast<const T*>(e.add0) + (long long)m * e.ldc_add0 + cb + 8 * o, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += t[i];
+      }
+      if (e.out_raw) ps_store8<T>(reinterpret_cast<T*>(e.out_raw) + (long long)m * e.ldc_raw + cb + 8 * o, v);
+      if (e.mode == PS_EPI_NONE) continue;
+      float sc[8], dm[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sc[i] = prm[cl + 8 * o + i];
+      if (e.drop) {
+        const float* d = e.drop + (long long)(m / (a.Ho * a.Wo)) * a.Cd + cb + 8 * o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dm[i] = d[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dm[i] = 1.f;
+      }
+      if (!bwd) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i] * sc[i] + prm[128 + cl + 8 * o + i], 0.f) * dm[i];
+      } else {
+        float ms[8];
+        tile8(t_mask, R, o, ms);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = ms[i] > 0.f ? v[i] * sc[i] * dm[i] : 0.f;
+        if (e.add1) {
+          float t[8];
+          if (t_add1) tile8(t_add1, R, o, t);
+          else ps_load8<T>(reinterpret_cast<const T*>(e.add1) + (long long)m * e.ldc_add1 + cb + 8 * o, t);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] += t[i];
+        }
+      }
+      ps_store8<T>(reinterpret_cast<T*>(e.out) + (long long)m * e.ldc_out + cb + 8 * o, v);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Wave-specialised kernel: 128 x 128 tile, 8 waves = 4 CONSUMER waves (2x2 of 64x64: ds_read + MFMA only) + 4 LOADER
 // waves (LDS-DMA issue only).  Issuing one 1-KiB LDS-DMA costs a wave ~100-180 cycles of its in-order issue stream
@@ -654,6 +730,15 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_ws_kernel(const IgemmArgs a
   ps_tile_of_block(bid, a.ntn, a.ntm, tm, tn, a.supertile);
   const int m0 = tm * BM, n0 = tn * BN;
   const int nsteps = a.taps * a.klines;
+  // bf16: epilogue operands travel through LDS (see conv_epilogue_lds); which tensor goes to which tile:
+  constexpr bool LDS_EPI = sizeof(T) == 2;
+  const ps_epilogue& ep = a.epi;
+  const bool ep_bwd = ep.mode == PS_EPI_RELUBWD;
+  const void* tile1_src = ep_bwd ? ep.mask_src : ep.add0;
+  const int tile1_ldc = ep_bwd ? ep.ldc_mask : ep.ldc_add0;
+  const void* tile2_src = ep_bwd ? (ep.add0 ? ep.add0 : ep.add1) : nullptr;
+  const int tile2_ldc = ep_bwd ? (ep.add0 ? ep.ldc_add0 : ep.ldc_add1) : 0;
+  float* prm = reinterpret_cast<float*>(smem + 2 * STAGE);  // scale[128] | shift[128]
 
   if (wave >= 4) {
     // ================= loader =================
@@ -716,11 +801,34 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_ws_kernel(const IgemmArgs a
         if (++tap < a.taps) tap_offsets(tap);
       }
     };
+    if (LDS_EPI && lw == 0) {  // per-channel epilogue parameters of this block's 128 couts
+      for (int i = lane; i < 128; i += 64) {
+        prm[i] = ep.scale ? ep.scale[n0 + i] : 1.f;
+        prm[128 + i] = (ep.shift && ep.mode == PS_EPI_BNRELU) ? ep.shift[n0 + i] : 0.f;
+      }
+    }
+    // DMA of a [BM][128-channel] bf16 tile of an epilogue operand into a free stage buffer (4 rows per instruction)
+    auto tile_issue = [&](const void* src, int ldc, unsigned char* dst) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)(a.M * ldc * 2), 0x00020000);
+      const int rin = lane >> 4, pos = lane & 15;
+#pragma unroll
+      for (int j = 0; j < BM / 16; ++j) {
+        const int t = j * 4 + lw, R = t * 4 + rin;
+        const unsigned off = (m0 + R < a.M) ? (unsigned)((m0 + R) * ldc * 2 + n0 * 2 + ((pos ^ (R & 15)) << 4)) : PAD_ROW;
+        BLDS16(rs, dst + t * 1024, off, 0);
+      }
+    };
     stage_issue(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     for (int s = 0; s < nsteps; ++s) {
-      if (s + 1 < nsteps) stage_issue((s + 1) & 1);  // the buffer the consumers finished before the last barrier
+      if (s + 1 < nsteps && !(a.ablate >= 1 && s >= 1)) stage_issue((s + 1) & 1);  // the buffer the consumers finished before the last barrier
+      if (LDS_EPI && s + 1 == nsteps && tile1_src) tile_issue(tile1_src, tile1_ldc, smem + ((s + 1) & 1) * STAGE);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (a.ablate != 2) __builtin_amdgcn_s_barrier();
+    }
+    if (LDS_EPI && tile2_src) {  // second operand: into the buffer the consumers have just finished
+      tile_issue(tile2_src, tile2_ldc, smem + ((nsteps - 1) & 1) * STAGE);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -754,9 +862,15 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_ws_kernel(const IgemmArgs a
         for (int i = 0; i < WI; ++i) Tr::mma(wf[i], xf[mi], acc[mi][i]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (a.ablate != 2) __builtin_amdgcn_s_barrier();
   }
-  conv_epilogue<T, MI, WI>(a, acc, m0 + wm * WM, n0 + wn * WN, lane);
+  if constexpr (LDS_EPI) {
+    if (tile2_src) __builtin_amdgcn_s_barrier();
+    conv_epilogue_lds<MI, WI>(a, acc, m0 + wm * WM, wm * WM, n0 + wn * WN, wn * WN, lane, prm, smem + (nsteps & 1) * STAGE,
+                              smem + ((nsteps - 1) & 1) * STAGE);
+  } else {
+    conv_epilogue<T, MI, WI>(a, acc, m0 + wm * WM, n0 + wn * WN, lane);
+  }
 }
 
 static int g_use_glds = 2;  // staging mode: 0 registers, 1 global_load_lds, 2 buffer_load ... lds
@@ -870,10 +984,10 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
     b.ntn = (int)n128;
     if (g_force_bm == 112 || (g_force_bm == 0 && c112 * 100 < c128 * 90)) {
       b.ntm = (int)t112;
-      hipLaunchKernelGGL((conv_igemm_ws_kernel<Tr, 112>), dim3((unsigned)(b.ntm * b.ntn)), dim3(512), 2 * (112 * 128 + 128 * 128), s, b);
+      hipLaunchKernelGGL((conv_igemm_ws_kernel<Tr, 112>), dim3((unsigned)(b.ntm * b.ntn)), dim3(512), 2 * (112 * 128 + 128 * 128) + 1024, s, b);
     } else {
       b.ntm = (int)t128;
-      hipLaunchKernelGGL((conv_igemm_ws_kernel<Tr, 128>), dim3((unsigned)(b.ntm * b.ntn)), dim3(512), 2 * (128 * 128 + 128 * 128), s, b);
+      hipLaunchKernelGGL((conv_igemm_ws_kernel<Tr, 128>), dim3((unsigned)(b.ntm * b.ntn)), dim3(512), 2 * (128 * 128 + 128 * 128) + 1024, s, b);
     }
     PS_CHECK_LAUNCH("conv_igemm_ws");
     return PS_OK;
