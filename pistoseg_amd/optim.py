@@ -12,6 +12,12 @@ import torch
 from . import ops
 
 
+def _touched(p: torch.Tensor) -> None:
+    """The kernels rewrite parameter memory through raw pointers; tell torch (the models cache bf16 / transposed weight
+    views keyed on the parameter's version counter)."""
+    torch._C._increment_version(p)
+
+
 def _dense_pair(p: torch.Tensor, g: torch.Tensor):
     """The kernels treat a parameter as flat memory: p must be dense and g laid out identically."""
     if g.stride() != p.stride():
@@ -46,6 +52,7 @@ class PolyOptimizer(torch.optim.Optimizer):
                     st["momentum_buffer"] = torch.empty_like(p)
                 pd, gd = _dense_pair(p.data, p.grad)
                 ops.sgd_step(pd, gd, st.get("momentum_buffer"), None, group["lr"], group["momentum"], group["weight_decay"], first)
+                _touched(p)
         self.global_step += 1
 
 
@@ -68,3 +75,4 @@ class FusedAdamW(torch.optim.Optimizer):
                 st["step"] += 1
                 pd, gd = _dense_pair(p.data, p.grad)
                 ops.adamw_step(pd, gd, st["exp_avg"], st["exp_avg_sq"], None, group["lr"], group["betas"], group["eps"], group["weight_decay"], st["step"])
+                _touched(p)

@@ -144,3 +144,102 @@ class SegTrainer:
     def lr_scheduler_step(self, gamma: float = 0.9) -> None:
         """ExponentialLR(gamma=0.9) once per epoch (segmentation_module.py:88)."""
         self.lr *= gamma
+
+
+class RFMTrainer:
+    """Native stage-3 step (`revise_pseudo_labels.py:232-301`): RFM forward plan -> fused cls/rfm/ecr losses with their
+    gradients (rfm_loss.py) -> reverse plan into a flat f32 gradient arena -> [N > 1: bucketed RCCL all-reduce overlapped
+    with the backward] -> utils.PolyOptimizer's update (SGD, momentum = the reference's mis-placed weight_decay argument,
+    per-group L2 decay, poly LR) as two fused launches over the arena: scratch heads (10 x lr) and pretrained backbone (lr).
+    """
+
+    def __init__(self, model, lr: float = 0.01, wt_dec: float = 5e-4, max_step: int = 1000, power: float = 0.9, process_group=None,
+                 bucket_mb: float = 48.0):
+        from .revise_net import FCAT, Net
+
+        assert isinstance(model, Net) and next(model.parameters()).is_cuda
+        self.model, self.FCAT = model, FCAT
+        self.lr0, self.wt_dec, self.max_step, self.power = lr, wt_dec, max_step, power
+        self.global_step = 0
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        dev = next(model.parameters()).device
+        model.train()
+        self.entries = arena_order(model)  # heads (from_scratch_layers) first, then b7 ... b3
+        total = sum(p.numel() for _, p in self.entries)
+        self.p_flat = torch.empty(total, device=dev, dtype=torch.float32)
+        self.g_flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.buf_flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.pb_flat = torch.empty(total, device=dev, dtype=torch.bfloat16) if model.precision == "bf16" else None
+        self.grads: Dict[str, Tensor] = {}
+        self.offsets: Dict[str, Tuple[int, int]] = {}
+        scratch = {id(m.weight) for m in model.from_scratch_layers}
+        off, self.n_scratch = 0, 0
+        for name, p in self.entries:
+            cout, cin, kh, kw = p.shape
+            n = p.numel()
+            view = self.p_flat[off:off + n].view(cout, kh, kw, cin)
+            view.copy_(p.detach().permute(0, 2, 3, 1))
+            p.data = view.permute(0, 3, 1, 2)
+            if not name.startswith("f9_"):
+                self.grads[name] = self.g_flat[off:off + n].view(cout, kh, kw, cin)
+                if self.pb_flat is not None:
+                    model._bf16_shadow[name] = self.pb_flat[off:off + n].view(cout, kh, kw, cin)
+            self.offsets[name] = (off, n)
+            off += n
+            if id(p) in scratch:
+                assert off - n == self.n_scratch, "scratch heads must be contiguous at the start of the arena"
+                self.n_scratch = off
+        self.f9_packed = torch.zeros((384, 1, 1, FCAT), device=dev, dtype=torch.float32)
+        self.grads["f9"] = self.f9_packed
+        if self.pb_flat is not None:
+            ops.cast_f32_bf16(self.p_flat, self.pb_flat)
+        model.invalidate_weight_cache()
+        self.reducer: Optional[BucketedAllReduce] = None
+        if self.world > 1:
+            buckets = plan_buckets([(name, p.numel()) for name, p in self.entries], int(bucket_mb * (1 << 20) / 4))
+            self.reducer = BucketedAllReduce(self.g_flat, buckets, process_group)
+
+    def train_step(self, x: Tensor, pmask: Tensor, pcam: Tensor, label: Tensor):
+        """x [N,3,H,W]; pmask/pcam [N,C,32,32] with the zero background channel; label [N,C] with label[:,0] = 1.
+        Returns (loss, loss_cls, loss_rfm, loss_ecr) as 1-element device tensors."""
+        from .rfm_loss import rfm_losses
+
+        model = self.model
+        self.g_flat.zero_()
+        self.f9_packed.zero_()
+        drop = model.sample_dropout(x.shape[0], x.device)
+        outs, ctx = model.rfm_forward(x, pmask, pcam, save=True, drop=drop)
+        losses, d_outs = rfm_losses(outs, pmask, pcam, label, want_grad=True, grad_scale=1.0 / self.world)
+        if self.reducer is not None:
+            self.reducer.begin_step()
+
+        def after(name):
+            if name == "heads":  # fc8 / f8_3 / f8_4 / f9 gradients are final: unpack f9 into its arena slots
+                g1, g2 = model._unpack_w9_grad(self.f9_packed.view(384, self.FCAT))
+                for nm, g in (("f9_1.weight", g1), ("f9_2.weight", g2)):
+                    o, n = self.offsets[nm]
+                    self.g_flat[o:o + n].view(192, 1, 1, 195).copy_(g.permute(0, 2, 3, 1))
+                if self.reducer is not None:
+                    for nm in ("fc8", "f8_3", "f8_4", "f9_1", "f9_2"):
+                        self.reducer.on_unit_done(nm)
+            elif self.reducer is not None:
+                self.reducer.on_unit_done(name)
+
+        model.rfm_backward(ctx, list(d_outs), self.grads, after_unit=after)
+        if self.reducer is not None:
+            self.reducer.finish()
+        # utils.PolyOptimizer.step
+        mult = (1 - self.global_step / self.max_step) ** self.power if self.global_step < self.max_step else None
+        if mult is not None:
+            self._lr_mult = mult
+        mult = getattr(self, "_lr_mult", 1.0)
+        first = self.global_step == 0
+        ns, tot = self.n_scratch, self.p_flat.numel()
+        for lo, hi, lr in ((0, ns, 10 * self.lr0 * mult), (ns, tot, self.lr0 * mult)):
+            if hi > lo:
+                ops.sgd_step(self.p_flat[lo:hi], self.g_flat[lo:hi], self.buf_flat[lo:hi], None if self.pb_flat is None else self.pb_flat[lo:hi],
+                             lr, self.wt_dec, self.wt_dec, first)
+        self.global_step += 1
+        model.invalidate_weight_cache()
+        return losses

@@ -177,3 +177,50 @@ def test_rfm_bf16_runs_and_is_close():
     # bf16 is not the parity path; require agreement on average only
     for o, r in zip(outs[1:], ref[1:]):
         assert torch.isfinite(o).all() and float((o.cpu() - r).abs().mean()) < 0.03 * float(r.abs().max())
+
+
+def test_rfm_trainer_step_matches_autograd_path_and_poly_optimizer():
+    """Native stage-3 step (flat arenas, fused SGD) == autograd node + rfm_losses + PolyOptimizer, two steps."""
+    from pistoseg_amd.optim import PolyOptimizer
+    from pistoseg_amd.revise_net import Net
+    from pistoseg_amd.rfm_loss import rfm_losses
+    from pistoseg_amd.trainer import RFMTrainer
+
+    n, s, c = 2, 64, 4
+    sd = ref_cpu.make_state_dict(c, True, seed=42)
+    x, pmask, pcam, lab = make_inputs(n, s, c, seed=110)
+    pm, pc, label = with_bg(pmask, pcam, lab)
+    xd, pmd, pcd, lbd = x.to(D), pm.to(D), pc.to(D), label.reshape(n, c).to(D)
+    drops = None
+    results = []
+    for native in (True, False):
+        model = Net(c, "fp32")
+        model.load_state_dict(sd)
+        model = model.to(D)
+        model.train()
+        if drops is None:
+            drops = [model.sample_dropout(n, D) for _ in range(2)]
+        it = iter(drops)
+        model.sample_dropout = lambda n_, dev_: next(it)
+        if native:
+            tr = RFMTrainer(model, lr=0.01, wt_dec=5e-4, max_step=10)
+            losses = [float(tr.train_step(xd, pmd, pcd, lbd)[0]) for _ in range(2)]
+        else:
+            groups = model.get_parameter_groups()
+            opt = PolyOptimizer([{"params": groups[0], "lr": 0.01, "weight_decay": 5e-4}, {"params": groups[1], "lr": 0.02, "weight_decay": 0},
+                                 {"params": groups[2], "lr": 0.1, "weight_decay": 5e-4}, {"params": groups[3], "lr": 0.2, "weight_decay": 0}],
+                                lr=0.01, weight_decay=5e-4, max_step=10)
+            losses = []
+            for _ in range(2):
+                opt.zero_grad()
+                outs = model(xd, pmd, pcd)
+                (loss, *_), grads = rfm_losses([o.detach() for o in outs], pmd, pcd, lbd, want_grad=True)
+                torch.autograd.backward(outs, grads)
+                opt.step()
+                losses.append(float(loss))
+        results.append((losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}))
+    (l1, s1), (l2, s2) = results
+    assert abs(l1[0] - l2[0]) < 1e-5 * abs(l2[0]) and abs(l1[1] - l2[1]) < 1e-3 * abs(l2[1])
+    for k in s1:
+        if s1[k].is_floating_point():
+            assert float((s1[k] - s2[k]).abs().max()) <= 1e-5 + 1e-3 * float((s2[k] - sd[k]).abs().max()), k
