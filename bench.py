@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 GFLOP_FWD_PER_TILE = 199.93   # SURVEY.md 8(d) / BASELINE.md 2: conv FLOPs, 2*MACs, per 224x224 tile (RFM net)
 GFLOP_TRAIN_PER_TILE = 556.28  # fwd + dgrad + wgrad, frozen conv1a/b2* skipped
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # /opt/skills/guides/MI355X_MICROARCH.md, dense
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # /opt/skills/guides/MI355X_MICROARCH.md, dense
 
 
 def parse():
@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="tiles per GPU per step")
     ap.add_argument("--tile", type=int, default=224)
     ap.add_argument("--classes", type=int, default=3)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=2)
@@ -130,7 +130,7 @@ def cpu_baseline(tiles, tile, classes):
     x = torch.randn(tiles, 3, tile, tile, generator=g)
     y = torch.randint(0, classes + 1, (tiles, tile, tile), generator=g)
     t0 = time.perf_counter()
-    loss = ref_cpu.seg_ce_loss(ref_cpu.seg_forward(sd, x), y, 3)
+    loss = ref_cpu.seg_ce_loss(ref_cpu.seg_forward(sd, x), y, classes)
     loss.backward()
     opt.step()
     dt = time.perf_counter() - t0
@@ -171,7 +171,7 @@ def main():
     model = ResNet38dSeg(classes=args.classes, precision=args.precision)
     init_weights_he(model, seed=42)
     model = model.to(dev)
-    trainer = SegTrainer(model, lr=1e-3, weight_decay=0.05, ignore_index=3,
+    trainer = SegTrainer(model, lr=1e-3, weight_decay=0.05, ignore_index=args.classes,
                          process_group=torch.distributed.group.WORLD if dist_on else None)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     x = torch.randn(args.batch, 3, args.tile, args.tile, generator=g).to(dev)
@@ -191,7 +191,8 @@ def main():
         "metric": "224x224 tiles/sec (train fwd+bwd+opt)", "value": round(value, 2), "unit": "tiles/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: segmentation_train.py step, ResNet38-d seg model, 3-class CE(ignore=3), AdamW, random-init",
+        "config": {"workload": f"BASELINE configs[{1 if (args.classes, args.precision, args.batch) == (3, 'bf16', 64) else 4}]: segmentation_train.py step, "
+                               f"ResNet38-d seg model, {args.classes}-class CE(ignore={args.classes}), AdamW, random-init",
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "tile": args.tile, "parallelism": f"dp{world}"},
         "train_conv_tflops_per_gpu": round(value / world * GFLOP_TRAIN_PER_TILE * (args.tile / 224.0) ** 2 / 1e3, 1),
     }

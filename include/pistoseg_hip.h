@@ -12,7 +12,8 @@
  *    every function enqueues work on `stream` (a hipStream_t passed as void*) and returns.
  *  - return value: 0 on success, negative ps_status on error; ps_last_error() gives a message
  *    (thread-local).
- *  - dtype: PS_F32 = exact-f32 MFMA path (parity), PS_BF16 = bf16 storage / f32 accumulate (throughput).
+ *  - dtype: PS_F32 = exact-f32 MFMA path (parity), PS_BF16 / PS_F16 = 16-bit storage / f32 accumulate (throughput;
+ *    PS_F16 training needs loss scaling: see ps_softmax_ce grad_scale and ps_adamw_step grad_inv_scale).
  *  - activation layout: channels-last  [N, H, W, C]  with an explicit channel stride `ldc` (elements per
  *    pixel), so a tensor may be a channel slice of a wider buffer.  Per-channel vectors (BN scale/shift)
  *    and all loss/optimizer state are f32.  Network inputs/outputs at the API edge are the reference's
@@ -38,7 +39,7 @@ typedef enum ps_status {
   PS_ERR_NOGPU = -3    /* no gfx950 device visible */
 } ps_status;
 
-typedef enum ps_dtype { PS_F32 = 0, PS_BF16 = 1 } ps_dtype;
+typedef enum ps_dtype { PS_F32 = 0, PS_BF16 = 1, PS_F16 = 2 } ps_dtype;
 
 int ps_version(void);
 const char* ps_last_error(void);
@@ -97,11 +98,13 @@ int ps_conv2d_dgrad(const ps_conv_geom* g, const void* dy, const void* w_dgrad, 
  * atomics (split over pixel ranges): zero dw first.  replaces: autograd of F.conv2d w.r.t. its weight. */
 int ps_conv2d_wgrad(const ps_conv_geom* g, const void* x, const void* dy, float* dw, void* stream);
 
-/* dst[cin][taps][cout] = src[cout][taps][cin]; src/dst dtype in {PS_F32, PS_BF16} (cast allowed f32->bf16). */
+/* dst[cin][taps][cout] = src[cout][taps][cin]; same 16-bit dtype on both sides, f32 -> f32, or f32 -> bf16/f16 (cast). */
 int ps_weight_transpose(int32_t src_dtype, int32_t dst_dtype, const void* src, void* dst, int32_t cout, int32_t taps,
                         int32_t cin, void* stream);
 /* dst = (bf16)src, n elements.  (per-step refresh of the bf16 forward weights from the f32 master arena) */
 int ps_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* dst = (dst_dtype)src for dst_dtype in {PS_BF16, PS_F16}. */
+int ps_cast_f32_lowp(const float* src, void* dst, int32_t dst_dtype, int64_t n, void* stream);
 
 /* conv1a: 3x3, 3 -> 64, stride 1, pad 1, reads the reference's NCHW f32 image, writes channels-last
  * activation out[m,c] = max(conv*scale[c]+shift[c], 0) (b2.bn_branch2a fused) and/or the raw conv.
@@ -240,10 +243,21 @@ int ps_minpool_bwd(const float* m, const uint8_t* arg, const float* label, const
  * Optionally refreshes a bf16 shadow copy of p (p_bf16 may be NULL). */
 int ps_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int32_t step, void* stream);
+/* Same, with the gradient multiplied by grad_inv_scale first (undoing fp16 loss scaling) and a 16-bit shadow of dtype
+ * shadow_dtype in {PS_BF16, PS_F16} (p_shadow may be NULL). */
+int ps_adamw_step_scaled(float* p, const float* g, float* m, float* v, void* p_shadow, int32_t shadow_dtype, int64_t n, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_inv_scale, void* stream);
 /* torch.optim.SGD with momentum (dampening 0, no nesterov) and L2 weight decay:
  *   g' = g + wd*p;  buf = first ? g' : mom*buf + g';  p -= lr*buf */
 int ps_sgd_step(float* p, const float* g, float* buf, void* p_bf16, int64_t n, float lr, float momentum,
                 float weight_decay, int32_t first_step, void* stream);
+/* Same, with the gradient multiplied by grad_inv_scale first and a 16-bit shadow of dtype shadow_dtype in {PS_BF16, PS_F16}. */
+int ps_sgd_step_scaled(float* p, const float* g, float* buf, void* p_shadow, int32_t shadow_dtype, int64_t n, float lr,
+                       float momentum, float weight_decay, int32_t first_step, float grad_inv_scale, void* stream);
+
+/* *count += number of inf/nan elements of g[0..n) (caller zeroes count).  Used by fp16 dynamic loss scaling: an overflowed
+ * activation gradient reaches the f32 gradient arena as inf/nan, and the step is then skipped. */
+int ps_nonfinite_count(const float* g, int64_t n, int32_t* count, void* stream);
 
 /* Testing hook: how conv operands are staged into LDS: 2 (default) LDS-DMA through buffer descriptors
  * (buffer_load ... lds; padding rows are out-of-range lanes, which the DMA zero-fills), 1 LDS-DMA with flat

@@ -17,7 +17,7 @@ import torch  # noqa: F401  (side effect: loads the HIP runtime torch uses)
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpistoseg_hip.so")
 
-PS_F32, PS_BF16 = 0, 1
+PS_F32, PS_BF16, PS_F16 = 0, 1, 2
 PS_EPI_NONE, PS_EPI_BNRELU, PS_EPI_RELUBWD = 0, 1, 2
 PS_MASK_PLAIN, PS_MASK_MUL, PS_MASK_FILL = 0, 1, 2
 
@@ -68,6 +68,7 @@ PROTOTYPES = {
     "ps_conv2d_wgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _P, _P, _P]),
     "ps_weight_transpose": (C.c_int, [_I, _I, _P, _P, _I, _I, _I, _P]),
     "ps_cast_f32_bf16": (C.c_int, [_P, _P, _L, _P]),
+    "ps_cast_f32_lowp": (C.c_int, [_P, _P, _I, _L, _P]),
     "ps_conv1a_fwd": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ps_fc8_fwd": (C.c_int, [_I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ps_fc8_bwd": (C.c_int, [_I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
@@ -81,6 +82,9 @@ PROTOTYPES = {
     "ps_confusion_accum": (C.c_int, [_P, _P, _P, _L, _I, _P]),
     "ps_adamw_step": (C.c_int, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
     "ps_sgd_step": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _I, _P]),
+    "ps_adamw_step_scaled": (C.c_int, [_P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
+    "ps_sgd_step_scaled": (C.c_int, [_P, _P, _P, _P, _I, _L, _F, _F, _F, _I, _F, _P]),
+    "ps_nonfinite_count": (C.c_int, [_P, _L, _P, _P]),
     "ps_debug_set_glds": (None, [C.c_int]),
     "ps_debug_set_3stage": (None, [C.c_int]),
     "ps_debug_set_bn": (None, [C.c_int]),

@@ -58,6 +58,12 @@ struct TraitsBF16 {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
   }
 };
+struct TraitsF16 {
+  typedef _Float16 elem;
+  static __device__ __forceinline__ void mma(const u32x4& w, const u32x4& x, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
+  }
+};
 struct TraitsF32 {
   typedef float elem;
   // a 16-byte chunk holds 4 consecutive k of this lane's row; MFMA j consumes element j of both operands,
@@ -636,10 +642,9 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const IgemmArgs a) {
 // in their last K-line, so the consumers' epilogue has no global-load latency in it (measured: ~11 us of the ~48 us a
 // 512-cout block lives were serialized epilogue/prologue latency).  Tile image: [row][256 B], 16-byte chunk c of row R
 // at position c ^ (R & 15) (conflict-free 16-byte reads of 16 different rows).
-template <int MI, int WI>
+template <typename T, int MI, int WI>
 __device__ __forceinline__ void conv_epilogue_lds(const IgemmArgs& a, f32x4 (&acc)[MI][WI], int mbase, int rbase, int cbase, int clocal,
                                                   int lane, const float* prm, const unsigned char* t1, const unsigned char* t2) {
-  typedef __bf16 T;
   constexpr int CH = 4 * WI, NV = CH / 8;
   const int frow = lane & 15, g = lane >> 4;
   const ps_epilogue& e = a.epi;
@@ -647,11 +652,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const IgemmArgs& a, f32x4 (&ac
   const bool bwd = e.mode == PS_EPI_RELUBWD;
   auto tile8 = [&](const unsigned char* t, int R, int o, float* v) {  // 8 channels cl + 8o.. of tile row R
     const int c = (cl + 8 * o) >> 3;
-    const uint4 raw = *reinterpret_cast<const uint4*>(t + R * 256 + ((c ^ (R & 15)) << 4));
-    v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
-    v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
-    v[4] = __uint_as_float(raw.z << 16); v[5] = __uint_as_float(raw.z & 0xffff0000u);
-    v[6] = __uint_as_float(raw.w << 16); v[7] = __uint_as_float(raw.w & 0xffff0000u);
+    ps_load8<T>(reinterpret_cast<const T*>(t + R * 256 + ((c ^ (R & 15)) << 4)), v);
   };
   // which operand sits in which tile (the loader uses the same rule)
   const unsigned char* t_add0 = nullptr; const unsigned char* t_mask = nullptr; const unsigned char* t_add1 = nullptr;
@@ -866,7 +867,7 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_ws_kernel(const IgemmArgs a
   }
   if constexpr (LDS_EPI) {
     if (tile2_src) __builtin_amdgcn_s_barrier();
-    conv_epilogue_lds<MI, WI>(a, acc, m0 + wm * WM, wm * WM, n0 + wn * WN, wn * WN, lane, prm, smem + (nsteps & 1) * STAGE,
+    conv_epilogue_lds<T, MI, WI>(a, acc, m0 + wm * WM, wm * WM, n0 + wn * WN, wn * WN, lane, prm, smem + (nsteps & 1) * STAGE,
                               smem + ((nsteps - 1) & 1) * STAGE);
   } else {
     conv_epilogue<T, MI, WI>(a, acc, m0 + wm * WM, n0 + wn * WN, lane);
@@ -903,7 +904,7 @@ int launch_igemm(const IgemmArgs& a0, hipStream_t stream) {
 
 int check_geom(const ps_conv_geom* g) {
   PS_REQUIRE(g != nullptr, "conv: null geometry");
-  PS_REQUIRE(g->dtype == PS_F32 || g->dtype == PS_BF16, "conv: dtype %d unsupported", g->dtype);
+  PS_REQUIRE(ps_dtype_ok(g->dtype), "conv: dtype %d unsupported", g->dtype);
   PS_REQUIRE(g->ksize == 1 || g->ksize == 3, "conv: ksize %d unsupported (1 or 3)", g->ksize);
   PS_REQUIRE(g->stride == 1 || g->stride == 2, "conv: stride %d unsupported (1 or 2)", g->stride);
   PS_REQUIRE(g->dilation >= 1 && g->dilation <= 64, "conv: dilation %d unsupported", g->dilation);
@@ -1039,8 +1040,10 @@ extern "C" int ps_conv2d_fwd(const ps_conv_geom* g, const void* x, const void* w
   a.Cd = g->cout;
   a.epi = *epi;
   if (int rc = set_extents(a, (long long)g->n * g->h * g->w * a.pix_bytes, (long long)g->cout * a.wrow_bytes)) return rc;
-  return g->dtype == PS_BF16 ? dispatch_bn<TraitsBF16>(a, static_cast<hipStream_t>(stream))
-                             : dispatch_bn<TraitsF32>(a, static_cast<hipStream_t>(stream));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (g->dtype == PS_BF16) return dispatch_bn<TraitsBF16>(a, s);
+  if (g->dtype == PS_F16) return dispatch_bn<TraitsF16>(a, s);
+  return dispatch_bn<TraitsF32>(a, s);
 }
 
 extern "C" int ps_conv2d_dgrad(const ps_conv_geom* g, const void* dy, const void* w_dgrad, const ps_epilogue* epi, void* stream) {
@@ -1062,6 +1065,8 @@ extern "C" int ps_conv2d_dgrad(const ps_conv_geom* g, const void* dy, const void
   a.Cd = g->cin;
   a.epi = *epi;
   if (int rc = set_extents(a, (long long)g->n * a.Hs * a.Ws * a.pix_bytes, (long long)g->cin * a.wrow_bytes)) return rc;
-  return g->dtype == PS_BF16 ? dispatch_bn<TraitsBF16>(a, static_cast<hipStream_t>(stream))
-                             : dispatch_bn<TraitsF32>(a, static_cast<hipStream_t>(stream));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (g->dtype == PS_BF16) return dispatch_bn<TraitsBF16>(a, s);
+  if (g->dtype == PS_F16) return dispatch_bn<TraitsF16>(a, s);
+  return dispatch_bn<TraitsF32>(a, s);
 }

@@ -48,9 +48,15 @@ struct WgradArgs {
 
 struct WTraitsBF16 {
   static constexpr int ES = 2, KP = 64;
+  [[maybe_unused]] static constexpr bool F16 = false;
+};
+struct WTraitsF16 {
+  static constexpr int ES = 2, KP = 64;
+  static constexpr bool F16 = true;
 };
 struct WTraitsF32 {
   static constexpr int ES = 4, KP = 32;
+  [[maybe_unused]] static constexpr bool F16 = false;
 };
 
 // XOR applied to the 16-byte chunk index of LDS row R (row = RB bytes); see file header.
@@ -221,7 +227,13 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 1) void conv_wgrad_kernel(
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NI; ++j) {
+            // the transposed read moves 16-bit words; fp16 reinterprets the same registers
+            if constexpr (Tr::F16)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[i]), __builtin_bit_cast(f16x8, bf[j]), acc[i][j], 0, 0, 0);
+            else
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+          }
       }
     } else {
       // exact f32: K = 4 pixels per MFMA; lane group g owns pixel row 4*kk + g
@@ -341,6 +353,8 @@ extern "C" int ps_conv2d_wgrad(const ps_conv_geom* g, const void* x, const void*
   PS_REQUIRE(xb < (1LL << 31) && gb < (1LL << 31), "conv2d_wgrad: tensor larger than 2 GiB");
   a.x_bytes = (unsigned)xb;
   a.dy_bytes = (unsigned)gb;
-  return g->dtype == PS_BF16 ? dispatch_wgrad<WTraitsBF16>(a, static_cast<hipStream_t>(stream))
-                             : dispatch_wgrad<WTraitsF32>(a, static_cast<hipStream_t>(stream));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (g->dtype == PS_BF16) return dispatch_wgrad<WTraitsBF16>(a, s);
+  if (g->dtype == PS_F16) return dispatch_wgrad<WTraitsF16>(a, s);
+  return dispatch_wgrad<WTraitsF32>(a, s);
 }

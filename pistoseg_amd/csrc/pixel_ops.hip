@@ -20,12 +20,10 @@ static T4 to_t4(const ps_tensor4* t) {
   return r;
 }
 __device__ __forceinline__ float t4_load(const T4& t, long long off) {
-  if (t.dtype == PS_BF16) return ps_bf16_to_f32(reinterpret_cast<const uint16_t*>(t.ptr)[off]);
-  return reinterpret_cast<const float*>(t.ptr)[off];
+  return ps_ld_dt(t.ptr, t.dtype, off);
 }
 __device__ __forceinline__ void t4_store(const T4& t, long long off, float v) {
-  if (t.dtype == PS_BF16) reinterpret_cast<uint16_t*>(t.ptr)[off] = ps_f32_to_bf16(v);
-  else reinterpret_cast<float*>(t.ptr)[off] = v;
+  ps_st_dt(t.ptr, t.dtype, off, v);
 }
 
 // torch's area_pixel_compute_scale / _source_index (aten/src/ATen/native/UpSample.h), f32 arithmetic.
@@ -335,7 +333,7 @@ static inline int grid_for(long long items, int per_block, int cap = 2048) {
 
 int check_t4(const ps_tensor4* t, const char* who) {
   PS_REQUIRE(t && t->ptr, "%s: null tensor", who);
-  PS_REQUIRE(t->dtype == PS_F32 || t->dtype == PS_BF16, "%s: dtype %d unsupported", who, t->dtype);
+  PS_REQUIRE(ps_dtype_ok(t->dtype), "%s: dtype %d unsupported", who, t->dtype);
   PS_REQUIRE(t->n > 0 && t->c > 0 && t->h > 0 && t->w > 0, "%s: empty tensor", who);
   return PS_OK;
 }

@@ -9,6 +9,8 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
@@ -31,7 +33,8 @@ void ps_set_error(const char* fmt, ...);
     }                                                                                \
   } while (0)
 
-static inline int ps_esize(int dtype) { return dtype == PS_BF16 ? 2 : 4; }
+static inline int ps_esize(int dtype) { return dtype == PS_F32 ? 4 : 2; }
+static inline bool ps_dtype_ok(int dtype) { return dtype == PS_F32 || dtype == PS_BF16 || dtype == PS_F16; }
 static inline bool ps_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- device helpers -------------------------------------------------------------------------
@@ -39,6 +42,20 @@ __device__ __forceinline__ float ps_bf16_to_f32(uint16_t b) { return __uint_as_f
 __device__ __forceinline__ uint16_t ps_f32_to_bf16(float f) {
   __bf16 h = static_cast<__bf16>(f);  // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
   return __builtin_bit_cast(uint16_t, h);
+}
+
+__device__ __forceinline__ float ps_f16_to_f32(uint16_t b) { return static_cast<float>(__builtin_bit_cast(_Float16, b)); }
+__device__ __forceinline__ uint16_t ps_f32_to_f16(float f) { return __builtin_bit_cast(uint16_t, static_cast<_Float16>(f)); }
+// generic 16-bit / f32 scalar access by runtime dtype (per-pixel kernels)
+__device__ __forceinline__ float ps_ld_dt(const void* p, int dtype, long long i) {
+  if (dtype == PS_BF16) return ps_bf16_to_f32(reinterpret_cast<const uint16_t*>(p)[i]);
+  if (dtype == PS_F16) return ps_f16_to_f32(reinterpret_cast<const uint16_t*>(p)[i]);
+  return reinterpret_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void ps_st_dt(void* p, int dtype, long long i, float v) {
+  if (dtype == PS_BF16) reinterpret_cast<uint16_t*>(p)[i] = ps_f32_to_bf16(v);
+  else if (dtype == PS_F16) reinterpret_cast<uint16_t*>(p)[i] = ps_f32_to_f16(v);
+  else reinterpret_cast<float*>(p)[i] = v;
 }
 
 // 8 consecutive channels <-> 8 floats
@@ -58,8 +75,22 @@ __device__ __forceinline__ void ps_load8<__bf16>(const __bf16* p, float* v) {
   v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
   v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
 }
+template <>
+__device__ __forceinline__ void ps_load8<_Float16>(const _Float16* p, float* v) {
+  const uint4 a = *reinterpret_cast<const uint4*>(p);
+  const f16x8 h = __builtin_bit_cast(f16x8, a);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = static_cast<float>(h[i]);
+}
 template <typename T>
 __device__ __forceinline__ void ps_store8(T* p, const float* v);
+template <>
+__device__ __forceinline__ void ps_store8<_Float16>(_Float16* p, const float* v) {
+  f16x8 h;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) h[i] = static_cast<_Float16>(v[i]);
+  *reinterpret_cast<uint4*>(p) = __builtin_bit_cast(uint4, h);
+}
 template <>
 __device__ __forceinline__ void ps_store8<float>(float* p, const float* v) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);

@@ -9,11 +9,10 @@
 namespace {
 
 __device__ __forceinline__ float ld(const void* p, int dtype, long long i) {
-  return dtype == PS_BF16 ? ps_bf16_to_f32(reinterpret_cast<const uint16_t*>(p)[i]) : reinterpret_cast<const float*>(p)[i];
+  return ps_ld_dt(p, dtype, i);
 }
 __device__ __forceinline__ void st(void* p, int dtype, long long i, float v) {
-  if (dtype == PS_BF16) reinterpret_cast<uint16_t*>(p)[i] = ps_f32_to_bf16(v);
-  else reinterpret_cast<float*>(p)[i] = v;
+  ps_st_dt(p, dtype, i, v);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -215,6 +215,12 @@ __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <>
 __device__ __forceinline__ uint16_t from_f32<uint16_t>(float v) { return ps_f32_to_bf16(v); }
 
+struct h16 { uint16_t bits; };  // fp16 storage tag (uint16_t is taken by bf16 here)
+template <>
+__device__ __forceinline__ float to_f32<h16>(h16 v) { return ps_f16_to_f32(v.bits); }
+template <>
+__device__ __forceinline__ h16 from_f32<h16>(float v) { return h16{ps_f32_to_f16(v)}; }
+
 template <typename S, typename D>
 __global__ __launch_bounds__(256) void weight_transpose_kernel(const S* __restrict__ src, D* __restrict__ dst, int cout, int taps,
                                                                int cin) {
@@ -235,15 +241,16 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const S* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long long n) {
+template <typename D>
+__global__ __launch_bounds__(256) void cast_f32_lowp_kernel(const float* __restrict__ src, D* __restrict__ dst, long long n) {
   const long long stride = (long long)gridDim.x * 256 * 8;
   for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += stride) {
     if (i + 8 <= n) {
       float v[8];
       ps_load8<float>(src + i, v);
-      ps_store8<__bf16>(dst + i, v);
+      ps_store8<D>(dst + i, v);
     } else {
-      for (long long j = i; j < n; ++j) dst[j] = static_cast<__bf16>(src[j]);
+      for (long long j = i; j < n; ++j) dst[j] = static_cast<D>(src[j]);
     }
   }
 }
@@ -251,12 +258,14 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------------
 // optimisers over a flat arena
 // ------------------------------------------------------------------------------------------------
+template <typename SH>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, __bf16* __restrict__ pb, long long n, float lr,
-                                                    float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+                                                    float* __restrict__ v, SH* __restrict__ pb, long long n, float lr,
+                                                    float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float ginv) {
   const long long stride = (long long)gridDim.x * 256 * 4;
   const float step_size = lr / bc1, decay = 1.f - lr * wd;
   auto upd = [&](float& pk, float gk, float& mk, float& vk) {
+    gk *= ginv;  // 1 unless the gradient carries an fp16 loss scale (x * 1.0f is exact)
     pk *= decay;
     mk = mk + (gk - mk) * (1.f - b1);          // torch: exp_avg.lerp_(grad, 1 - beta1)
     vk = b2 * vk + (1.f - b2) * gk * gk;        // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
@@ -271,28 +280,29 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
       *reinterpret_cast<float4*>(m + i) = mk;
       *reinterpret_cast<float4*>(v + i) = vk;
       if (pb) {
-        uint2 o;
-        o.x = ps_f32_to_bf16(pk.x) | (static_cast<uint32_t>(ps_f32_to_bf16(pk.y)) << 16);
-        o.y = ps_f32_to_bf16(pk.z) | (static_cast<uint32_t>(ps_f32_to_bf16(pk.w)) << 16);
-        *reinterpret_cast<uint2*>(pb + i) = o;
+        typedef SH sh4 __attribute__((ext_vector_type(4)));
+        sh4 o;
+        o[0] = static_cast<SH>(pk.x); o[1] = static_cast<SH>(pk.y); o[2] = static_cast<SH>(pk.z); o[3] = static_cast<SH>(pk.w);
+        *reinterpret_cast<sh4*>(pb + i) = o;
       }
     } else {
       for (long long k = i; k < n; ++k) {
         float pk = p[k], mk = m[k], vk = v[k];
         upd(pk, g[k], mk, vk);
         p[k] = pk; m[k] = mk; v[k] = vk;
-        if (pb) pb[k] = static_cast<__bf16>(pk);
+        if (pb) pb[k] = static_cast<SH>(pk);
       }
     }
   }
 }
 
+template <typename SH>
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
-                                                  __bf16* __restrict__ pb, long long n, float lr, float mom, float wd, int first) {
+                                                  SH* __restrict__ pb, long long n, float lr, float mom, float wd, int first, float ginv) {
   const long long stride = (long long)gridDim.x * 256;
   for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
     float pk = p[k];
-    float gk = g[k];
+    float gk = g[k] * ginv;
     if (wd != 0.f) gk = fmaf(wd, pk, gk);
     if (mom != 0.f) {
       const float b = first ? gk : mom * buf[k] + gk;
@@ -301,8 +311,26 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     }
     pk -= lr * gk;
     p[k] = pk;
-    if (pb) pb[k] = static_cast<__bf16>(pk);
+    if (pb) pb[k] = static_cast<SH>(pk);
   }
+}
+
+// count of non-finite elements (fp16 dynamic loss scaling: an overflowed activation gradient reaches the arena as inf/nan)
+__global__ __launch_bounds__(256) void nonfinite_kernel(const float* __restrict__ g, long long n, int* __restrict__ out) {
+  const long long stride = (long long)gridDim.x * 256 * 4;
+  int bad = 0;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n) {
+      const uint4 u = *reinterpret_cast<const uint4*>(g + i);
+      bad += ((u.x & 0x7f800000u) == 0x7f800000u) + ((u.y & 0x7f800000u) == 0x7f800000u) + ((u.z & 0x7f800000u) == 0x7f800000u) +
+             ((u.w & 0x7f800000u) == 0x7f800000u);
+    } else {
+      for (long long k = i; k < n; ++k) bad += (__float_as_uint(g[k]) & 0x7f800000u) == 0x7f800000u;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(out, bad);
 }
 
 static inline int grid_for(long long work_items, int per_block, int cap = 256 * 8) {
@@ -325,6 +353,8 @@ extern "C" int ps_conv1a_fwd(int32_t out_dtype, const float* x, const float* w, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (out_dtype == PS_BF16)
     hipLaunchKernelGGL(conv1a_kernel<__bf16>, dim3(grid), dim3(256), 0, s, x, w, scale, shift, (__bf16*)out_act, (__bf16*)out_raw, n, h, wd);
+  else if (out_dtype == PS_F16)
+    hipLaunchKernelGGL(conv1a_kernel<_Float16>, dim3(grid), dim3(256), 0, s, x, w, scale, shift, (_Float16*)out_act, (_Float16*)out_raw, n, h, wd);
   else if (out_dtype == PS_F32)
     hipLaunchKernelGGL(conv1a_kernel<float>, dim3(grid), dim3(256), 0, s, x, w, scale, shift, (float*)out_act, (float*)out_raw, n, h, wd);
   else
@@ -343,6 +373,8 @@ extern "C" int ps_fc8_fwd(int32_t dtype, const void* x, int32_t ldc_x, const flo
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == PS_BF16)
     hipLaunchKernelGGL(fc8_fwd_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, ldc_x, w, drop, cam, m_total, ppi, k, c);
+  else if (dtype == PS_F16)
+    hipLaunchKernelGGL(fc8_fwd_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)x, ldc_x, w, drop, cam, m_total, ppi, k, c);
   else if (dtype == PS_F32)
     hipLaunchKernelGGL(fc8_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ldc_x, w, drop, cam, m_total, ppi, k, c);
   else
@@ -365,6 +397,9 @@ extern "C" int ps_fc8_bwd(int32_t dtype, const void* x, int32_t ldc_x, const flo
   if (dtype == PS_BF16)
     hipLaunchKernelGGL(fc8_bwd_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, ldc_x, w, drop, scale7, dcam, (__bf16*)dx,
                        ldc_dx, dw, m_total, ppi, k, c, ppb);
+  else if (dtype == PS_F16)
+    hipLaunchKernelGGL(fc8_bwd_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)x, ldc_x, w, drop, scale7, dcam, (_Float16*)dx,
+                       ldc_dx, dw, m_total, ppi, k, c, ppb);
   else if (dtype == PS_F32)
     hipLaunchKernelGGL(fc8_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ldc_x, w, drop, scale7, dcam, (float*)dx,
                        ldc_dx, dw, m_total, ppi, k, c, ppb);
@@ -383,7 +418,9 @@ extern "C" int ps_weight_transpose(int32_t sdt, int32_t ddt, const void* src, vo
     hipLaunchKernelGGL((weight_transpose_kernel<float, float>), grid, dim3(256), 0, s, (const float*)src, (float*)dst, cout, taps, cin);
   else if (sdt == PS_F32 && ddt == PS_BF16)
     hipLaunchKernelGGL((weight_transpose_kernel<float, uint16_t>), grid, dim3(256), 0, s, (const float*)src, (uint16_t*)dst, cout, taps, cin);
-  else if (sdt == PS_BF16 && ddt == PS_BF16)
+  else if (sdt == PS_F32 && ddt == PS_F16)
+    hipLaunchKernelGGL((weight_transpose_kernel<float, h16>), grid, dim3(256), 0, s, (const float*)src, (h16*)dst, cout, taps, cin);
+  else if ((sdt == PS_BF16 && ddt == PS_BF16) || (sdt == PS_F16 && ddt == PS_F16))  // same 16-bit type: bits move unchanged (bf16 <-> f32 is exact)
     hipLaunchKernelGGL((weight_transpose_kernel<uint16_t, uint16_t>), grid, dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)dst, cout, taps, cin);
   else
     PS_REQUIRE(false, "weight_transpose: dtype pair (%d,%d) unsupported", sdt, ddt);
@@ -391,36 +428,76 @@ extern "C" int ps_weight_transpose(int32_t sdt, int32_t ddt, const void* src, vo
   return PS_OK;
 }
 
-extern "C" int ps_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
-  PS_REQUIRE(src && dst && n >= 0, "cast_f32_bf16: bad argument");
+extern "C" int ps_cast_f32_lowp(const float* src, void* dst, int32_t dst_dtype, int64_t n, void* stream) {
+  PS_REQUIRE(src && dst && n >= 0, "cast_f32_lowp: bad argument");
+  PS_REQUIRE(dst_dtype == PS_BF16 || dst_dtype == PS_F16, "cast_f32_lowp: dtype %d unsupported", dst_dtype);
   if (n == 0) return PS_OK;
-  PS_REQUIRE(ps_aligned16(src) && ps_aligned16(dst), "cast_f32_bf16: misaligned pointer");
-  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n, 256 * 8)), dim3(256), 0, static_cast<hipStream_t>(stream), src, (__bf16*)dst,
-                     (long long)n);
-  PS_CHECK_LAUNCH("cast_f32_bf16");
+  PS_REQUIRE(ps_aligned16(src) && ps_aligned16(dst), "cast_f32_lowp: misaligned pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dst_dtype == PS_BF16)
+    hipLaunchKernelGGL(cast_f32_lowp_kernel<__bf16>, dim3(grid_for(n, 256 * 8)), dim3(256), 0, s, src, (__bf16*)dst, (long long)n);
+  else
+    hipLaunchKernelGGL(cast_f32_lowp_kernel<_Float16>, dim3(grid_for(n, 256 * 8)), dim3(256), 0, s, src, (_Float16*)dst, (long long)n);
+  PS_CHECK_LAUNCH("cast_f32_lowp");
+  return PS_OK;
+}
+
+extern "C" int ps_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  return ps_cast_f32_lowp(src, dst, PS_BF16, n, stream);
+}
+
+extern "C" int ps_adamw_step_scaled(float* p, const float* g, float* m, float* v, void* p_shadow, int32_t shadow_dtype, int64_t n,
+                                    float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                                    float grad_inv_scale, void* stream) {
+  PS_REQUIRE(p && g && m && v && n >= 0 && step >= 1, "adamw_step: bad argument");
+  PS_REQUIRE(!p_shadow || shadow_dtype == PS_BF16 || shadow_dtype == PS_F16, "adamw_step: shadow dtype %d unsupported", shadow_dtype);
+  if (n == 0) return PS_OK;
+  PS_REQUIRE(ps_aligned16(p) && ps_aligned16(g) && ps_aligned16(m) && ps_aligned16(v) && (!p_shadow || (reinterpret_cast<uintptr_t>(p_shadow) & 7u) == 0),
+             "adamw_step: arenas must be 16-byte aligned");
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (p_shadow && shadow_dtype == PS_F16)
+    hipLaunchKernelGGL(adamw_kernel<_Float16>, dim3(grid_for(n, 256 * 4)), dim3(256), 0, s, p, g, m, v, (_Float16*)p_shadow, (long long)n, lr,
+                       beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_inv_scale);
+  else
+    hipLaunchKernelGGL(adamw_kernel<__bf16>, dim3(grid_for(n, 256 * 4)), dim3(256), 0, s, p, g, m, v, (__bf16*)p_shadow, (long long)n, lr,
+                       beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_inv_scale);
+  PS_CHECK_LAUNCH("adamw_step");
   return PS_OK;
 }
 
 extern "C" int ps_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1,
                              float beta2, float eps, float weight_decay, int32_t step, void* stream) {
-  PS_REQUIRE(p && g && m && v && n >= 0 && step >= 1, "adamw_step: bad argument");
+  return ps_adamw_step_scaled(p, g, m, v, p_bf16, PS_BF16, n, lr, beta1, beta2, eps, weight_decay, step, 1.0f, stream);
+}
+
+extern "C" int ps_nonfinite_count(const float* g, int64_t n, int32_t* count, void* stream) {
+  PS_REQUIRE(g && count && n >= 0, "nonfinite_count: bad argument");
   if (n == 0) return PS_OK;
-  PS_REQUIRE(ps_aligned16(p) && ps_aligned16(g) && ps_aligned16(m) && ps_aligned16(v) && (!p_bf16 || (reinterpret_cast<uintptr_t>(p_bf16) & 7u) == 0),
-             "adamw_step: arenas must be 16-byte aligned");
-  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
-  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, (__bf16*)p_bf16,
-                     (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt);
-  PS_CHECK_LAUNCH("adamw_step");
+  PS_REQUIRE(ps_aligned16(g), "nonfinite_count: misaligned pointer");
+  hipLaunchKernelGGL(nonfinite_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, static_cast<hipStream_t>(stream), g, (long long)n, count);
+  PS_CHECK_LAUNCH("nonfinite_count");
+  return PS_OK;
+}
+
+extern "C" int ps_sgd_step_scaled(float* p, const float* g, float* buf, void* p_shadow, int32_t shadow_dtype, int64_t n, float lr,
+                                  float momentum, float weight_decay, int32_t first_step, float grad_inv_scale, void* stream) {
+  PS_REQUIRE(p && g && n >= 0 && (momentum == 0.f || buf), "sgd_step: bad argument");
+  PS_REQUIRE(!p_shadow || shadow_dtype == PS_BF16 || shadow_dtype == PS_F16, "sgd_step: shadow dtype %d unsupported", shadow_dtype);
+  if (n == 0) return PS_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (p_shadow && shadow_dtype == PS_F16)
+    hipLaunchKernelGGL(sgd_kernel<_Float16>, dim3(grid_for(n, 256)), dim3(256), 0, s, p, g, buf, (_Float16*)p_shadow, (long long)n, lr, momentum,
+                       weight_decay, first_step, grad_inv_scale);
+  else
+    hipLaunchKernelGGL(sgd_kernel<__bf16>, dim3(grid_for(n, 256)), dim3(256), 0, s, p, g, buf, (__bf16*)p_shadow, (long long)n, lr, momentum,
+                       weight_decay, first_step, grad_inv_scale);
+  PS_CHECK_LAUNCH("sgd_step");
   return PS_OK;
 }
 
 extern "C" int ps_sgd_step(float* p, const float* g, float* buf, void* p_bf16, int64_t n, float lr, float momentum,
                            float weight_decay, int32_t first_step, void* stream) {
-  PS_REQUIRE(p && g && n >= 0 && (momentum == 0.f || buf), "sgd_step: bad argument");
-  if (n == 0) return PS_OK;
-  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, buf, (__bf16*)p_bf16,
-                     (long long)n, lr, momentum, weight_decay, first_step);
-  PS_CHECK_LAUNCH("sgd_step");
-  return PS_OK;
+  return ps_sgd_step_scaled(p, g, buf, p_bf16, PS_BF16, n, lr, momentum, weight_decay, first_step, 1.0f, stream);
 }

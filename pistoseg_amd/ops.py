@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import PS_BF16, PS_EPI_BNRELU, PS_EPI_NONE, PS_EPI_RELUBWD, PS_F32, ConvGeom, Epilogue, Tensor4
+from ._lib import PS_BF16, PS_EPI_BNRELU, PS_EPI_NONE, PS_EPI_RELUBWD, PS_F16, PS_F32, ConvGeom, Epilogue, Tensor4
 
 Tensor = torch.Tensor
 
@@ -25,7 +25,7 @@ PROFILE = None
 
 def _conv_label(kind: str, dtype: int, m: int, cd: int) -> str:
     """Mirrors dispatch_bn() in csrc/conv_igemm.hip: which instantiation serves this launch."""
-    dt = "bf16" if dtype == PS_BF16 else "f32"
+    dt = {PS_BF16: "bf16", PS_F16: "f16"}.get(dtype, "f32")
     if kind == "wgrad":
         return f"conv_wgrad_kernel<{dt}>"
     t128 = (m + 127) // 128
@@ -51,6 +51,8 @@ def _dt(t_or_dtype) -> int:
         return PS_F32
     if d == torch.bfloat16:
         return PS_BF16
+    if d == torch.float16:
+        return PS_F16
     raise TypeError(f"unsupported dtype {d}")
 
 
@@ -170,6 +172,14 @@ def cast_f32_bf16(src: Tensor, dst: Tensor) -> None:
     assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
     lib = _lib.load()
     _lib.check(lib.ps_cast_f32_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), "ps_cast_f32_bf16")
+
+
+def cast_f32_lowp(src: Tensor, dst: Tensor) -> None:
+    """dst (bf16 or fp16) = cast(src f32): refresh of the 16-bit forward weights from the f32 master arena."""
+    _require_gpu(src, dst)
+    assert src.dtype == torch.float32 and dst.dtype in (torch.bfloat16, torch.float16) and src.numel() == dst.numel()
+    lib = _lib.load()
+    _lib.check(lib.ps_cast_f32_lowp(src.data_ptr(), dst.data_ptr(), _dt(dst), src.numel(), _stream()), "ps_cast_f32_lowp")
 
 
 def conv1a_fwd(x_nchw: Tensor, w_oihw: Tensor, bn_scale: Optional[Tensor], bn_shift: Optional[Tensor], out_act: Optional[Tensor],
@@ -298,21 +308,39 @@ def confusion_accum(pred: Tensor, gt: Tensor, cm: Tensor, num_class: int) -> Non
     _lib.check(lib.ps_confusion_accum(pred.data_ptr(), gt.data_ptr(), cm.data_ptr(), pred.numel(), num_class, _stream()), "ps_confusion_accum")
 
 
-def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, p_bf16: Optional[Tensor], lr: float, betas, eps: float, weight_decay: float, step: int) -> None:
+def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, p_shadow: Optional[Tensor], lr: float, betas, eps: float, weight_decay: float, step: int,
+               grad_inv_scale: float = 1.0) -> None:
+    """Fused AdamW over a flat arena; p_shadow (bf16 or fp16, optional) receives the refreshed 16-bit weights;
+    grad_inv_scale undoes an fp16 loss scale."""
     _require_gpu(p, g, m, v)
     lib = _lib.load()
+    sdt = PS_BF16 if p_shadow is None else _dt(p_shadow)
     _lib.check(
-        lib.ps_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(p_bf16), p.numel(), lr, betas[0], betas[1], eps, weight_decay, step, _stream()),
-        "ps_adamw_step",
+        lib.ps_adamw_step_scaled(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(p_shadow), sdt, p.numel(), lr, betas[0], betas[1], eps,
+                                 weight_decay, step, float(grad_inv_scale), _stream()),
+        "ps_adamw_step_scaled",
     )
 
 
-def sgd_step(p: Tensor, g: Tensor, buf: Optional[Tensor], p_bf16: Optional[Tensor], lr: float, momentum: float, weight_decay: float, first_step: bool) -> None:
+def nonfinite_count(g: Tensor) -> Tensor:
+    """1-element int32 device tensor: number of inf/nan entries of the f32 tensor g."""
+    _require_gpu(g)
+    assert g.dtype == torch.float32 and g.is_contiguous()
+    out = torch.zeros(1, device=g.device, dtype=torch.int32)
+    lib = _lib.load()
+    _lib.check(lib.ps_nonfinite_count(g.data_ptr(), g.numel(), out.data_ptr(), _stream()), "ps_nonfinite_count")
+    return out
+
+
+def sgd_step(p: Tensor, g: Tensor, buf: Optional[Tensor], p_shadow: Optional[Tensor], lr: float, momentum: float, weight_decay: float, first_step: bool,
+             grad_inv_scale: float = 1.0) -> None:
     _require_gpu(p, g)
     lib = _lib.load()
+    sdt = PS_BF16 if p_shadow is None else _dt(p_shadow)
     _lib.check(
-        lib.ps_sgd_step(p.data_ptr(), g.data_ptr(), _ptr(buf), _ptr(p_bf16), p.numel(), lr, momentum, weight_decay, int(first_step), _stream()),
-        "ps_sgd_step",
+        lib.ps_sgd_step_scaled(p.data_ptr(), g.data_ptr(), _ptr(buf), _ptr(p_shadow), sdt, p.numel(), lr, momentum, weight_decay, int(first_step),
+                               float(grad_inv_scale), _stream()),
+        "ps_sgd_step_scaled",
     )
 
 

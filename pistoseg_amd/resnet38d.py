@@ -103,7 +103,7 @@ class Net(nn.Module):
 
     def __init__(self, precision: str = "bf16"):
         super().__init__()
-        assert precision in ("bf16", "fp32")
+        assert precision in ("bf16", "fp16", "fp32")
         self.precision = precision
         self.conv1a = nn.Conv2d(3, 64, 3, padding=1, bias=False)
         for name, kind, cin, cmid, cout, stride, fdil, dil, p in UNITS:
@@ -154,7 +154,7 @@ class Net(nn.Module):
     # ------------------------------------------------------------------ device-side views of the parameters
     @property
     def compute_dtype(self):
-        return torch.bfloat16 if self.precision == "bf16" else torch.float32
+        return {"bf16": torch.bfloat16, "fp16": torch.float16}.get(self.precision, torch.float32)
 
     def _cached(self, key: str, deps: Tuple[Tensor, ...], make):
         sig = tuple((t.data_ptr(), t._version) for t in deps) + (self.precision, self._weights_epoch)
@@ -180,8 +180,8 @@ class Net(nn.Module):
             return shadow
 
         def make():
-            out = torch.empty(flat.shape, device=w.device, dtype=torch.bfloat16)
-            ops.cast_f32_bf16(flat, out)
+            out = torch.empty(flat.shape, device=w.device, dtype=self.compute_dtype)
+            ops.cast_f32_lowp(flat, out)
             return out
 
         return self._cached("wf:" + key, (w,), make)

@@ -70,7 +70,8 @@ def arena_order(model: ResNet38dSeg) -> List[Tuple[str, torch.nn.Parameter]]:
 
 class SegTrainer:
     def __init__(self, model: ResNet38dSeg, lr: float = 1e-3, weight_decay: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8,
-                 ignore_index: Optional[int] = 3, process_group=None, bucket_mb: float = 48.0, track_iou: bool = True):
+                 ignore_index: Optional[int] = 3, process_group=None, bucket_mb: float = 48.0, track_iou: bool = True,
+                 loss_scale: Optional[float] = None):
         assert next(model.parameters()).is_cuda, "move the model to the GPU first"
         self.model = model
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
@@ -88,7 +89,12 @@ class SegTrainer:
         self.g_flat = torch.zeros(total, device=dev, dtype=torch.float32)
         self.m_flat = torch.zeros(total, device=dev, dtype=torch.float32)
         self.v_flat = torch.zeros(total, device=dev, dtype=torch.float32)
-        self.pb_flat = torch.empty(total, device=dev, dtype=torch.bfloat16) if model.precision == "bf16" else None
+        self.pb_flat = torch.empty(total, device=dev, dtype=model.compute_dtype) if model.precision != "fp32" else None
+        # fp16 activations gradients underflow without a loss scale (a CE gradient is ~1/(N*H*W) = 3e-7 per pixel):
+        # dynamic scaling a la torch.cuda.amp.GradScaler (x0.5 and skip on overflow, x2 every 200 clean steps).
+        self.dynamic_scale = model.precision == "fp16" and loss_scale is None
+        self.loss_scale = float(loss_scale) if loss_scale is not None else (65536.0 if model.precision == "fp16" else 1.0)
+        self.clean_steps, self.skipped_steps = 0, 0
         self.grads: Dict[str, Tensor] = {}
         self.offsets: Dict[str, Tuple[int, int]] = {}
         off = 0
@@ -104,7 +110,7 @@ class SegTrainer:
             self.offsets[name] = (off, n)
             off += n
         if self.pb_flat is not None:
-            ops.cast_f32_bf16(self.p_flat, self.pb_flat)
+            ops.cast_f32_lowp(self.p_flat, self.pb_flat)
         model.invalidate_weight_cache()
         # all-reduce buckets: (unit after which the bucket is final, start, end) over the arena
         self.reducer: Optional[BucketedAllReduce] = None
@@ -123,7 +129,7 @@ class SegTrainer:
         feats, saved = model.run_backbone(image, save=True, drop=drop)
         logits, _ = model.head_forward(feats["conv6"], drop.get("dropout7"), image.shape[-2:])
         # mean over the GLOBAL batch: every rank scales its gradient by 1/world, the all-reduce sums
-        loss, dlogits = ops.softmax_ce(logits, mask, self.ignore_index, want_grad=True, grad_scale=1.0 / self.world)
+        loss, dlogits = ops.softmax_ce(logits, mask, self.ignore_index, want_grad=True, grad_scale=self.loss_scale / self.world)
         if self.track_iou:  # self.train_iou(mask_pred, mask), segmentation_module.py:108 -- kept on the device
             pred = ops.argmax_mask(logits, mode=_lib.PS_MASK_PLAIN, softmax_first=True)
             ops.confusion_accum(pred, mask, self.cm, model.classes)
@@ -135,10 +141,20 @@ class SegTrainer:
         model.backward_backbone(saved, g_x7, self.grads, after_unit=self.reducer.on_unit_done if self.reducer is not None else None)
         if self.reducer is not None:
             self.reducer.finish()
+        if self.dynamic_scale:
+            # one 4-byte D2H per step (the all-reduce already summed the arenas, so every rank sees the same count)
+            if int(ops.nonfinite_count(self.g_flat).item()) > 0:
+                self.loss_scale = max(self.loss_scale * 0.5, 1.0)
+                self.clean_steps = 0
+                self.skipped_steps += 1
+                return loss
+            self.clean_steps += 1
         self.step_count += 1
         ops.adamw_step(self.p_flat, self.g_flat, self.m_flat, self.v_flat, self.pb_flat, self.lr, self.betas, self.eps,
-                       self.weight_decay, self.step_count)
+                       self.weight_decay, self.step_count, grad_inv_scale=1.0 / self.loss_scale)
         model.invalidate_weight_cache()
+        if self.dynamic_scale and self.clean_steps >= 200:
+            self.loss_scale, self.clean_steps = min(self.loss_scale * 2.0, 2.0 ** 24), 0
         return loss
 
     def lr_scheduler_step(self, gamma: float = 0.9) -> None:
@@ -154,7 +170,7 @@ class RFMTrainer:
     """
 
     def __init__(self, model, lr: float = 0.01, wt_dec: float = 5e-4, max_step: int = 1000, power: float = 0.9, process_group=None,
-                 bucket_mb: float = 48.0):
+                 bucket_mb: float = 48.0, loss_scale: Optional[float] = None):
         from .revise_net import FCAT, Net
 
         assert isinstance(model, Net) and next(model.parameters()).is_cuda
@@ -170,7 +186,10 @@ class RFMTrainer:
         self.p_flat = torch.empty(total, device=dev, dtype=torch.float32)
         self.g_flat = torch.zeros(total, device=dev, dtype=torch.float32)
         self.buf_flat = torch.zeros(total, device=dev, dtype=torch.float32)
-        self.pb_flat = torch.empty(total, device=dev, dtype=torch.bfloat16) if model.precision == "bf16" else None
+        self.pb_flat = torch.empty(total, device=dev, dtype=model.compute_dtype) if model.precision != "fp32" else None
+        self.dynamic_scale = model.precision == "fp16" and loss_scale is None
+        self.loss_scale = float(loss_scale) if loss_scale is not None else (1024.0 if model.precision == "fp16" else 1.0)
+        self.clean_steps, self.skipped_steps = 0, 0
         self.grads: Dict[str, Tensor] = {}
         self.offsets: Dict[str, Tuple[int, int]] = {}
         scratch = {id(m.weight) for m in model.from_scratch_layers}
@@ -193,7 +212,7 @@ class RFMTrainer:
         self.f9_packed = torch.zeros((384, 1, 1, FCAT), device=dev, dtype=torch.float32)
         self.grads["f9"] = self.f9_packed
         if self.pb_flat is not None:
-            ops.cast_f32_bf16(self.p_flat, self.pb_flat)
+            ops.cast_f32_lowp(self.p_flat, self.pb_flat)
         model.invalidate_weight_cache()
         self.reducer: Optional[BucketedAllReduce] = None
         if self.world > 1:
@@ -210,7 +229,7 @@ class RFMTrainer:
         self.f9_packed.zero_()
         drop = model.sample_dropout(x.shape[0], x.device)
         outs, ctx = model.rfm_forward(x, pmask, pcam, save=True, drop=drop)
-        losses, d_outs = rfm_losses(outs, pmask, pcam, label, want_grad=True, grad_scale=1.0 / self.world)
+        losses, d_outs = rfm_losses(outs, pmask, pcam, label, want_grad=True, grad_scale=self.loss_scale / self.world)
         if self.reducer is not None:
             self.reducer.begin_step()
 
@@ -229,6 +248,16 @@ class RFMTrainer:
         model.rfm_backward(ctx, list(d_outs), self.grads, after_unit=after)
         if self.reducer is not None:
             self.reducer.finish()
+        if self.dynamic_scale:
+            if int(ops.nonfinite_count(self.g_flat).item()) > 0:
+                self.loss_scale = max(self.loss_scale * 0.5, 1.0)
+                self.clean_steps = 0
+                self.skipped_steps += 1
+                return losses
+            self.clean_steps += 1
+            if self.clean_steps >= 200:
+                self.loss_scale, self.clean_steps = min(self.loss_scale * 2.0, 2.0 ** 24), 0
+        inv = 1.0 / self.loss_scale
         # utils.PolyOptimizer.step
         mult = (1 - self.global_step / self.max_step) ** self.power if self.global_step < self.max_step else None
         if mult is not None:
@@ -239,7 +268,7 @@ class RFMTrainer:
         for lo, hi, lr in ((0, ns, 10 * self.lr0 * mult), (ns, tot, self.lr0 * mult)):
             if hi > lo:
                 ops.sgd_step(self.p_flat[lo:hi], self.g_flat[lo:hi], self.buf_flat[lo:hi], None if self.pb_flat is None else self.pb_flat[lo:hi],
-                             lr, self.wt_dec, self.wt_dec, first)
+                             lr, self.wt_dec, self.wt_dec, first, grad_inv_scale=inv)
         self.global_step += 1
         model.invalidate_weight_cache()
         return losses

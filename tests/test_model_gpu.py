@@ -102,6 +102,59 @@ def test_seg_forward_bf16_close_to_oracle():
     assert agree > 0.97, agree
 
 
+def test_seg_forward_fp16_close_to_oracle():
+    """BASELINE configs[4] storage type (BCSS-WSSS: 4 classes, fp16 MFMA path): 11-bit storage, f32 accumulate."""
+    c, n, s = 4, 2, 96
+    sd = ref_cpu.make_state_dict(c, False, seed=42)
+    model = build(c, "fp16", sd)
+    model.eval()
+    x, *_ = make_inputs(n, s, 4, 105)
+    with torch.no_grad():
+        got = model(x.to(D)).cpu()
+        ref = ref_cpu.seg_forward(sd, x)
+    assert rel_err(got, ref) < 1e-2
+    agree = float((got.argmax(1) == ref.argmax(1)).float().mean())
+    assert agree > 0.995, agree
+
+
+def test_seg_trainer_fp16_loss_scaling_tracks_fp32():
+    """fp16 native step (dynamic loss scale, fp16 shadow weights) against the fp32 native step on the same batch and
+    dropout masks: same loss trajectory within fp16 storage error, no skipped steps at the default scale, and an
+    injected overflow halves the scale and leaves the weights untouched."""
+    from pistoseg_amd.seg_model import ResNet38dSeg
+    from pistoseg_amd.trainer import SegTrainer
+
+    c, n, s = 4, 2, 64
+    sd = ref_cpu.make_state_dict(c, False, seed=42)
+    x, *_ = make_inputs(n, s, 4, 111)
+    target = torch.randint(0, c + 1, (n, s, s), generator=torch.Generator().manual_seed(3))
+    drops, out = None, {}
+    for prec in ("fp32", "fp16"):
+        model = ResNet38dSeg(c, prec)
+        model.load_state_dict(sd)
+        model = model.to(D)
+        if drops is None:
+            drops = [model.sample_dropout(n, D) for _ in range(3)]
+        it = iter(drops)
+        model.sample_dropout = lambda n_, dev_: next(it)
+        tr = SegTrainer(model, lr=1e-4, weight_decay=0.05, ignore_index=c)
+        losses = [float(tr.train_step(x.to(D), target.to(D))) for _ in range(3)]
+        out[prec] = (losses, tr, model)
+    l32, l16 = out["fp32"][0], out["fp16"][0]
+    tr16, m16 = out["fp16"][1], out["fp16"][2]
+    assert tr16.skipped_steps == 0 and tr16.loss_scale == 65536.0
+    for a, b in zip(l32, l16):
+        assert abs(a - b) < 2e-2 * abs(a), (l32, l16)
+    # the fp16 shadow is the rounded f32 master
+    assert torch.equal(tr16.pb_flat, tr16.p_flat.half())
+    # forced overflow: an absurd scale must be detected, skipped and halved
+    tr16.loss_scale = 2.0 ** 40
+    before = tr16.p_flat.clone()
+    m16.sample_dropout = lambda n_, dev_: drops[0]
+    tr16.train_step(x.to(D), target.to(D))
+    assert tr16.skipped_steps == 1 and tr16.loss_scale == 2.0 ** 39 and torch.equal(before, tr16.p_flat)
+
+
 def relu_pattern_flips(saved, collect):
     """Number of post-ReLU activations whose zero/non-zero pattern differs between device and oracle."""
     flips = 0

@@ -12,6 +12,13 @@ pytestmark = pytest.mark.gpu
 
 F32_TOL = 1e-4
 BF16_TOL = 1.2e-2
+F16_TOL = 2e-3  # fp16 storage (11 significant bits), f32 accumulate
+TOL = {torch.float32: F32_TOL, torch.bfloat16: BF16_TOL, torch.float16: F16_TOL}
+
+
+def quant(dtype):
+    """Round operands to the storage dtype on the CPU side, so only accumulation order / output rounding differ."""
+    return (lambda t: t) if dtype == torch.float32 else (lambda t: t.to(dtype).float())
 
 
 def dev():
@@ -44,7 +51,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("glds", [2, 1, 0])  # operand staging: buffer LDS-DMA (default), flat LDS-DMA, registers
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd_dgrad_wgrad(case, dtype, glds):
     from pistoseg_amd import _lib, ops
@@ -59,16 +66,14 @@ def test_conv_fwd_dgrad_wgrad(case, dtype, glds):
         g = torch.Generator().manual_seed(sum(case) * 7 + k)
         x = torch.randn(n, cin, h, w, generator=g)
         wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
-        if dtype == torch.bfloat16:
-            x, wt = x.bfloat16().float(), wt.bfloat16().float()
+        x, wt = quant(dtype)(x), quant(dtype)(wt)
         x.requires_grad_(True)
         wt.requires_grad_(True)
         y = F.conv2d(x, wt, stride=s, padding=d if k == 3 else 0, dilation=d)
         gy = torch.randn(y.shape, generator=g)
-        if dtype == torch.bfloat16:
-            gy = gy.bfloat16().float()
+        gy = quant(dtype)(gy)
         y.backward(gy)
-        tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+        tol = TOL[dtype]
 
         spec = ops.ConvSpec(cin, cout, k, s, d)
         xd = nhwc(x.detach()).to(dev(), dtype)
@@ -98,15 +103,15 @@ def test_conv_fwd_dgrad_wgrad(case, dtype, glds):
         lib.ps_debug_set_glds(2)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_conv_epilogues(dtype):
     from pistoseg_amd import ops
 
-    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    tol = TOL[dtype]
     n, h, w, cin, cout = 3, 9, 11, 128, 256
     g = torch.Generator().manual_seed(5)
     rnd = lambda *s: torch.randn(*s, generator=g)
-    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    q = quant(dtype)
     x, wt, res = q(rnd(n, cin, h, w)), q(rnd(cout, cin, 3, 3) * 0.03), q(rnd(n, cout, h, w))
     scale, shift = torch.rand(cout, generator=g) + 0.5, rnd(cout) * 0.2
     drop = (torch.rand(n, cout, generator=g) > 0.3).float() / 0.7
@@ -162,12 +167,12 @@ def test_conv_full_size_tile_properties():
     assert rel_err(y1[:1].cpu(), nhwc(ref)) < F32_TOL
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_conv1a_and_fc8(dtype):
     from pistoseg_amd import ops
 
     D = dev()
-    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    tol = TOL[dtype]
     g = torch.Generator().manual_seed(3)
     n, h, w = 2, 17, 20
     x = torch.randn(n, 3, h, w, generator=g)
@@ -183,7 +188,7 @@ def test_conv1a_and_fc8(dtype):
 
     # fc8 forward / backward
     k, c, gsz = 4096, 4, 5
-    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    q = quant(dtype)
     feat = q(F.relu(torch.randn(n, k, gsz, gsz, generator=g)))
     w8 = torch.randn(c, k, generator=g) * 0.02
     drop = (torch.rand(n, k, generator=g) > 0.5).float() * 2
@@ -327,7 +332,40 @@ def test_optimizers_match_torch():
     assert rel_err(p.cpu(), pt.detach()) < 1e-6
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scaled_optimizers_fp16_shadow_and_nonfinite():
+    """fp16 loss-scaling plumbing: scaled gradients + grad_inv_scale == the unscaled update; fp16 shadow weights;
+    inf/nan detection over the gradient arena."""
+    from pistoseg_amd import ops
+
+    D = dev()
+    g = torch.Generator().manual_seed(4)
+    n = 70_001
+    p0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    scale = 4096.0
+    pa, ma, va = p0.clone().to(D), torch.zeros(n, device=D), torch.zeros(n, device=D)
+    pbm, mb, vb = p0.clone().to(D), torch.zeros(n, device=D), torch.zeros(n, device=D)
+    sh = torch.empty(n, device=D, dtype=torch.float16)
+    ops.adamw_step(pa, gr.to(D), ma, va, None, 1e-3, (0.9, 0.999), 1e-8, 0.05, 1)
+    ops.adamw_step(pbm, (gr * scale).to(D), mb, vb, sh, 1e-3, (0.9, 0.999), 1e-8, 0.05, 1, grad_inv_scale=1.0 / scale)
+    assert torch.equal(pa, pbm)  # power-of-two scale: exact
+    assert torch.equal(sh.cpu(), pbm.cpu().half())
+    pa, ba = p0.clone().to(D), torch.zeros(n, device=D)
+    pbm, bb = p0.clone().to(D), torch.zeros(n, device=D)
+    ops.sgd_step(pa, gr.to(D), ba, None, 0.01, 0.9, 5e-4, True)
+    ops.sgd_step(pbm, (gr * scale).to(D), bb, sh, 0.01, 0.9, 5e-4, True, grad_inv_scale=1.0 / scale)
+    assert torch.equal(pa, pbm) and torch.equal(sh.cpu(), pbm.cpu().half())
+    # cast kernel
+    lo = torch.empty(n, device=D, dtype=torch.float16)
+    ops.cast_f32_lowp(p0.to(D), lo)
+    assert torch.equal(lo.cpu(), p0.half())
+    # non-finite count
+    t = torch.randn(n, generator=g)
+    assert int(ops.nonfinite_count(t.to(D))) == 0
+    t[5], t[n - 1], t[4097] = float("inf"), float("nan"), float("-inf")
+    assert int(ops.nonfinite_count(t.to(D))) == 3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", [
     # (n, h, w, cin, cout, k, s, d): large enough for the 256x128 three-stage kernel (>= 256 tiles)
     (4, 28, 28, 2048, 4096, 1, 1, 1), (16, 28, 28, 512, 1024, 3, 1, 4), (12, 56, 56, 256, 512, 3, 2, 1), (3, 112, 112, 128, 128, 3, 1, 1),
@@ -341,7 +379,7 @@ def test_conv_pipelined_kernels_are_bit_identical_to_two_stage(case, dtype):
     lib = _lib.load()
     n, h, w, cin, cout, k, s, d = case
     g = torch.Generator().manual_seed(n * 1000 + cin)
-    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    q = quant(dtype)
     x = q(torch.randn(n, h, w, cin, generator=g))
     wt = q(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5)
     spec = ops.ConvSpec(cin, cout, k, s, d)
@@ -383,11 +421,11 @@ def test_conv_pipelined_kernels_are_bit_identical_to_two_stage(case, dtype):
         lib.ps_debug_set_bm(0)
         lib.ps_debug_set_ws(1)
     cpu = F.conv2d(x[:1].permute(0, 3, 1, 2), wt, stride=s, padding=d if k == 3 else 0, dilation=d) + res[:1].float().cpu().permute(0, 3, 1, 2)
-    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    tol = TOL[dtype]
     assert rel_err(ref[0][:1].float().cpu(), nhwc(cpu)) < tol
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("bm", [112, 128])
 @pytest.mark.parametrize("case", [(128, 256, 3, 2, 1), (256, 256, 3, 1, 2), (512, 128, 1, 1, 1)])
 def test_conv_pixel_tile_variants(case, bm, dtype):
@@ -399,7 +437,7 @@ def test_conv_pixel_tile_variants(case, bm, dtype):
     cin, cout, k, s, d = case
     n, h, w = 3, 15, 14
     g = torch.Generator().manual_seed(cin + bm)
-    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    q = quant(dtype)
     x = q(torch.randn(n, cin, h, w, generator=g)).requires_grad_(True)
     wt = q(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5)
     y = F.conv2d(x, wt, stride=s, padding=d if k == 3 else 0, dilation=d)
@@ -408,7 +446,7 @@ def test_conv_pixel_tile_variants(case, bm, dtype):
     act = F.relu((y + res) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
     gy = q(torch.randn(y.shape, generator=g))
     y.backward(gy)
-    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    tol = TOL[dtype]
     spec = ops.ConvSpec(cin, cout, k, s, d)
     D = dev()
     try:
