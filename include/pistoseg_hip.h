@@ -85,6 +85,17 @@ typedef struct ps_epilogue {
 
 /* 1 if the MFMA implicit-GEMM path handles this geometry, else 0 (message in ps_last_error). */
 int ps_conv_supported(const ps_conv_geom* g);
+/* Which implicit-GEMM instantiation ps_conv2d_fwd (dgrad = 0) / ps_conv2d_dgrad (dgrad = 1) will launch for this geometry
+ * (profiling labels; -1 if the geometry is unsupported). */
+enum {
+  PS_CONV_4WAVE = 1,    /* conv_igemm_kernel: 4 waves stage and compute (small / narrow problems) */
+  PS_CONV_WS_128 = 2,   /* conv_igemm_ws_kernel<128>: 4 loader + 4 consumer waves, 128x128 tile, two blocks per CU */
+  PS_CONV_WS_112 = 3,   /* conv_igemm_ws_kernel<112> */
+  PS_CONV_WS2_256 = 4,  /* conv_igemm_ws2_kernel<256>: 256x128 tile, one block per CU, 3-stage ring */
+  PS_CONV_WS2_224 = 5,  /* conv_igemm_ws2_kernel<224> */
+  PS_CONV_OTHER = 6     /* an experimental kernel forced through the testing hooks */
+};
+int ps_conv_variant(const ps_conv_geom* g, int32_t dgrad);
 
 /* y = conv(x, W_fwd) with epilogue.  x: [n,h,w,cin]; produces [n,ho,wo,cout], ho = (h-1)/stride+1. */
 int ps_conv2d_fwd(const ps_conv_geom* g, const void* x, const void* w_fwd, const ps_epilogue* epi, void* stream);
@@ -276,6 +287,8 @@ void ps_debug_set_ablate(int v);
 void ps_debug_set_pp(int v);
 /* Testing hook: 1 (default) = big problems use the wave-specialised (4 loader + 4 consumer waves) conv kernel, 0 = never, 2 = always. */
 void ps_debug_set_ws(int v);
+/* Testing hook: large-tile (256|224 x 128, one block per CU) wave-specialised kernel: 0 off, 1 (default) chosen by the cost model, 256 / 224 forced. */
+void ps_debug_set_ws2(int v);
 /* Testing hook: 1 (default) = 128x128 weight-gradient tiles use the wave-specialised variant, 0 = the 4-wave kernel. */
 void ps_debug_set_wgrad_ws(int v);
 /* Testing hook: cout tiles per super-column of the conv block raster (default 4; 0 = plain row-major). */

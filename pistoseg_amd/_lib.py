@@ -63,6 +63,7 @@ PROTOTYPES = {
     "ps_last_error": (C.c_char_p, []),
     "ps_device_count": (C.c_int, []),
     "ps_conv_supported": (C.c_int, [C.POINTER(ConvGeom)]),
+    "ps_conv_variant": (C.c_int, [C.POINTER(ConvGeom), _I]),
     "ps_conv2d_fwd": (C.c_int, [C.POINTER(ConvGeom), _P, _P, C.POINTER(Epilogue), _P]),
     "ps_conv2d_dgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _P, C.POINTER(Epilogue), _P]),
     "ps_conv2d_wgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _P, _P, _P]),
@@ -92,6 +93,7 @@ PROTOTYPES = {
     "ps_debug_set_ablate": (None, [C.c_int]),
     "ps_debug_set_pp": (None, [C.c_int]),
     "ps_debug_set_ws": (None, [C.c_int]),
+    "ps_debug_set_ws2": (None, [C.c_int]),
     "ps_debug_set_wgrad_ws": (None, [C.c_int]),
     "ps_debug_set_supertile": (None, [C.c_int]),
     "ps_debug_set_wgrad_raster": (None, [C.c_int]),

@@ -21,3 +21,16 @@ extern "C" int ps_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
+
+// Compute units of the current device (grid size of the persistent kernels); cached per device id, 256 on MI355X.
+int ps_num_cus(void) {
+  static int cached[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}

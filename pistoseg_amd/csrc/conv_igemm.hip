@@ -874,9 +874,201 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_ws_kernel(const IgemmArgs a
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wave-specialised kernel, large tile: BM x 128 (BM = 256 or 224 pixels), 8 waves = 4 CONSUMER waves (2x2, each
+// (BM/2) x 64: 8 or 7 pixel fragments x 4 cout fragments) + 4 LOADER waves, ONE block per CU (<= 256 VGPRs), 3-stage
+// LDS ring.  Against the 128x128 / two-blocks-per-CU kernel above:
+//   * LDS traffic per MFMA falls by a quarter (a 128x64 wave tile reads 12 fragments per 32 MFMAs instead of 8 per 16,
+//     and the block stages 48 KiB per 256 MFMAs/wave-step instead of 32 KiB per 128) -- the LDS array (fragment reads +
+//     DMA writes) is what the small tile saturates;
+//   * the consumers software-pipeline the fragments ACROSS the block barrier: after barrier s a wave issues the reads of
+//     step s+1's first K-half and immediately has the 32 MFMAs of step s's second K-half to run (operands already in
+//     registers), so no LDS latency is exposed behind a barrier;
+//   * the loaders run two K-steps ahead (counted vmcnt), so a DMA has two barrier intervals (~2 x 1024 cycles) to land.
+// BM = 224 (7-fragment waves) makes 28x28-derived pixel counts tile exactly: 64 x 784 = 224 x 224.
+// ------------------------------------------------------------------------------------------------
+template <typename Tr, int BM>
+__global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs a) {
+  typedef typename Tr::elem T;
+  constexpr int BN = 128, MI = BM / 32, WI = 4, WM = 16 * MI, WN = 64;
+  constexpr int AINS = BM / 8, AJ = AINS / 4, BJ = 4, NLD = AJ + BJ;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  static_assert(BM == 256 || BM == 224, "pixel tile");
+  static_assert(NLD == 12 || NLD == 11, "vmcnt literals below");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // PERSISTENT over tiles: block b works on tiles b, b + G, b + 2G, ... of the raster (G = gridDim.x <= #CUs).  The K-steps of
+  // all its tiles form ONE flat sequence through the LDS ring, so the loaders prefetch the next tile's first two steps while
+  // the consumers are still in the epilogue, and the epilogue's global stores drain behind the next tile's main loop (with
+  // one block per CU and equal tiles, every CU reaches its epilogue at the same time: as separate blocks the stores of a
+  // whole round -- tens of MB -- were exposed at HBM speed before any CU could start its next tile).
+  const int G = gridDim.x;
+  const int first = ps_xcd_remap(blockIdx.x, G);
+  const int ntiles = a.ntm * a.ntn;
+  const int nsteps = a.taps * a.klines;
+  const int my_tiles = (ntiles - first + G - 1) / G;  // >= 1 (G <= ntiles)
+  const int total_steps = my_tiles * nsteps;
+
+  if (wave >= 4) {
+    // ================= loader =================
+    const int lw = wave - 4;
+    const int srow = lane >> 3;
+    const int chunk_off = ((lane & 7) ^ srow) << 4;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, (int)a.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, 0, (int)a.wgt_bytes, 0x00020000);
+    int py[AJ], px[AJ], nb[AJ];
+    unsigned woff[BJ], aoff[AJ];
+    int tap = 0, kl = 0, wk = 0;
+    auto tap_offsets = [&](int t) {
+      const int ty = (a.taps == 1) ? a.ctr : t / 3, tx = (a.taps == 1) ? a.ctr : t - (t / 3) * 3;
+      const int dy = (ty - a.ctr) * a.dstep, dx = (tx - a.ctr) * a.dstep;
+      const int dmask = (1 << a.div_shift) - 1;
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        const int yn = py[j] + dy, xn = px[j] + dx;
+        const int y = yn >> a.div_shift, x = xn >> a.div_shift;
+        const bool ok = (yn >= 0) && (xn >= 0) && (((yn | xn) & dmask) == 0) && (y < a.Hs) && (x < a.Ws);
+        aoff[j] = ok ? (unsigned)((nb[j] + y * a.Ws + x) * (int)a.pix_bytes) + chunk_off : PAD_ROW;
+      }
+    };
+    auto tile_setup = [&](int tile) {
+      int tm, tn;
+      ps_tile_of_block(tile, a.ntn, a.ntm, tm, tn, a.supertile);
+      const int m0 = tm * BM, n0 = tn * BN;
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) {
+        const int m = m0 + (j * 4 + lw) * 8 + srow;
+        if (m < a.M) {
+          const int hw = a.Ho * a.Wo;
+          const int n = m / hw, rem = m - n * hw;
+          const int p = rem / a.Wo, q = rem - p * a.Wo;
+          py[j] = p * a.mul;
+          px[j] = q * a.mul;
+          nb[j] = n * a.Hs * a.Ws;
+        } else {
+          py[j] = -(1 << 20);
+          px[j] = 0;
+          nb[j] = 0;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < BJ; ++j) {
+        const int rb = (j * 4 + lw) * 8 + srow;
+        const int wg = rb / WN, within = rb % WN, fi = within >> 4, rho = within & 15;
+        const int cout = n0 + wg * WN + 4 * WI * (rho >> 2) + 4 * fi + (rho & 3);
+        woff[j] = (unsigned)(cout * a.wrow_bytes) + chunk_off;
+      }
+      tap = 0; kl = 0; wk = 0;
+      tap_offsets(0);
+    };
+    int tile = first, slot = 0, issued = 0;
+    tile_setup(tile);
+    auto issue_next = [&]() -> bool {  // stages the next K-step of the flat sequence (exactly NLD loads per wave)
+      if (issued >= total_steps) return false;
+      unsigned char* sa = smem + slot * STAGE;
+      unsigned char* sb = sa + A_BYTES;
+      const int ko = kl * 128;
+#pragma unroll
+      for (int j = 0; j < AJ; ++j) BLDS16(rsA, sa + (j * 4 + lw) * 1024, aoff[j], ko);
+#pragma unroll
+      for (int j = 0; j < BJ; ++j) BLDS16(rsB, sb + (j * 4 + lw) * 1024, woff[j], wk);
+      ++issued;
+      slot = (slot == 2) ? 0 : slot + 1;
+      wk += 128;
+      if (++kl == a.klines) {
+        kl = 0;
+        if (++tap < a.taps) {
+          tap_offsets(tap);
+        } else if (issued < total_steps) {
+          tile += G;
+          tile_setup(tile);
+        }
+      }
+      return true;
+    };
+    auto wait_older = [&](bool newest_in_flight) {  // everything but the newest step's loads has landed
+      if (newest_in_flight) {
+        if constexpr (NLD == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    };
+    issue_next();
+    wait_older(issue_next());
+    __builtin_amdgcn_s_barrier();  // step 0 visible
+    for (int gs = 0; gs < total_steps; ++gs) {
+      // ring slot (gs+2)%3 held step gs-1: the consumers' reads of it completed before the previous barrier
+      wait_older(issue_next());  // step gs+1 landed
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
+
+  // ================= consumer =================
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 15, g = lane >> 4;
+  const int xfrag = (wm * WM + frow) * 128, wfrag = A_BYTES + (wn * WN + frow) * 128;
+  const int sw = lane & 7;
+  const int coff0 = (g ^ sw) << 4, coff1 = ((g + 4) ^ sw) << 4;
+
+  __builtin_amdgcn_s_barrier();  // step 0 visible
+  int cur = 0;
+  for (int tile = first; tile < ntiles; tile += G) {
+    f32x4 acc[MI][WI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int i = 0; i < WI; ++i) acc[mi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 wf0[WI], xf0[MI], wf1[WI], xf1[MI];  // fragments of the first / second K-half of a step
+    for (int s = 0; s < nsteps; ++s) {
+      const unsigned char* st = smem + cur * STAGE;
+      // reads of this step's first K-half ...
+#pragma unroll
+      for (int i = 0; i < WI; ++i) wf0[i] = *reinterpret_cast<const u32x4*>(st + wfrag + i * 2048 + coff0);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) xf0[mi] = *reinterpret_cast<const u32x4*>(st + xfrag + mi * 2048 + coff0);
+      __builtin_amdgcn_sched_barrier(0);
+      // ... hidden behind the MFMAs of the previous step's second K-half (operands already in registers)
+      if (s > 0) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int i = 0; i < WI; ++i) Tr::mma(wf1[i], xf1[mi], acc[mi][i]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < WI; ++i) wf1[i] = *reinterpret_cast<const u32x4*>(st + wfrag + i * 2048 + coff1);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) xf1[mi] = *reinterpret_cast<const u32x4*>(st + xfrag + mi * 2048 + coff1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int i = 0; i < WI; ++i) Tr::mma(wf0[i], xf0[mi], acc[mi][i]);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads of this slot are done: the loaders may refill it
+      __builtin_amdgcn_s_barrier();
+      cur = (cur == 2) ? 0 : cur + 1;
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int i = 0; i < WI; ++i) Tr::mma(wf1[i], xf1[mi], acc[mi][i]);
+    int tm, tn;
+    ps_tile_of_block(tile, a.ntn, a.ntm, tm, tn, a.supertile);
+    conv_epilogue<T, MI, WI>(a, acc, tm * BM + wm * WM, tn * BN + wn * WN, lane);
+  }
+}
+
 static int g_use_glds = 2;  // staging mode: 0 registers, 1 global_load_lds, 2 buffer_load ... lds
 static int g_use_pp = 0;       // experimental ping-pong kernel (correct, slower: r01 measurements)
 static int g_use_ws = 1;       // wave-specialised (loader/consumer) kernel for big problems
+static int g_use_ws2 = 1;      // large-tile wave-specialised kernel: 0 off, 1 by cost model, 256 / 224 force that pixel tile
 static int g_use_3stage = 0;  // experimental 256x128 three-stage kernel: correct but slower than two 128x128 blocks per CU (r01 measurements)
 static int g_ablate = 0;
 static int g_supertile = 4;  // measured best of {0,4,8,16} on the wide 28x28 layers (r01)
@@ -947,6 +1139,32 @@ int set_extents(IgemmArgs& a, long long src_bytes, long long wgt_bytes) {
   return PS_OK;
 }
 
+// Which wave-specialised kernel serves a (produced pixels M, produced channels Cd) problem; shared by the dispatcher and
+// ps_conv_variant().  Returns PS_CONV_WS2_256 / _224 / PS_CONV_WS_128 / _112, or 0 if neither applies.
+//   * large tile (one block per CU): the busiest CU's pixel rows decide between 224- and 256-pixel tiles; 256 wins ties
+//     (fewer passes over the weights) -- measured r01: 1x1 2048->4096 prefers 256 at equal quantisation;
+//   * it beats the two-blocks-per-CU kernel whenever there are >= 2 cout tiles (r01: +5..+12 % on the 28x28 layers, equal on
+//     256-channel 56x56); single-cout-tile layers (128 channels @112x112, 18 K-steps) keep the small tile, whose second
+//     resident block hides the epilogue.
+static int pick_ws_variant(long long M, int Cd, int esize) {
+  if (g_use_glds != 2 || Cd % 128 != 0) return 0;
+  const long long n128 = Cd / 128;
+  if (g_use_ws2 && (g_use_ws2 > 1 || (esize == 2 && n128 >= 2 && ((M + 255) / 256) * n128 >= 256))) {
+    const long long t256 = (M + 255) / 256, t224 = (M + 223) / 224;
+    const long long c256 = ((t256 * n128 + 255) / 256) * 256, c224 = ((t224 * n128 + 255) / 256) * 224;
+    if (g_use_ws2 == 256) return PS_CONV_WS2_256;
+    if (g_use_ws2 == 224) return PS_CONV_WS2_224;
+    return c224 * 103 < c256 * 100 ? PS_CONV_WS2_224 : PS_CONV_WS2_256;
+  }
+  if (g_use_ws && (((M + 127) / 128) * n128 >= 512 || g_use_ws == 2)) {
+    // pixel-tile height by the busiest CU's load (two blocks resident per CU)
+    const long long t128 = (M + 127) / 128, t112 = (M + 111) / 112;
+    const long long c128 = ((t128 * n128 + 255) / 256) * 128, c112 = ((t112 * n128 + 255) / 256) * 112;
+    return (g_force_bm == 112 || (g_force_bm == 0 && c112 * 100 < c128 * 90)) ? PS_CONV_WS_112 : PS_CONV_WS_128;
+  }
+  return 0;
+}
+
 template <typename Tr>
 int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
   // big problems: 256 x 128 tile, 3-stage LDS-DMA ring (1 block of 8 waves per CU)
@@ -977,19 +1195,17 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
       return PS_OK;
     }
   }
-  if (g_use_ws && g_use_glds == 2 && a.Cd % 128 == 0 && (((long long)(a.M + 127) / 128) * (a.Cd / 128) >= 512 || g_use_ws == 2)) {
-    // pixel-tile height by the busiest CU's load (two blocks resident per CU), as for the 4-wave kernel below
-    const long long n128 = a.Cd / 128, t128 = (a.M + 127) / 128, t112 = (a.M + 111) / 112;
-    const long long c128 = ((t128 * n128 + 255) / 256) * 128, c112 = ((t112 * n128 + 255) / 256) * 112;
+  if (const int v = pick_ws_variant(a.M, a.Cd, (int)sizeof(typename Tr::elem))) {
     IgemmArgs b = a;
-    b.ntn = (int)n128;
-    if (g_force_bm == 112 || (g_force_bm == 0 && c112 * 100 < c128 * 90)) {
-      b.ntm = (int)t112;
-      hipLaunchKernelGGL((conv_igemm_ws_kernel<Tr, 112>), dim3((unsigned)(b.ntm * b.ntn)), dim3(512), 2 * (112 * 128 + 128 * 128) + 1024, s, b);
-    } else {
-      b.ntm = (int)t128;
-      hipLaunchKernelGGL((conv_igemm_ws_kernel<Tr, 128>), dim3((unsigned)(b.ntm * b.ntn)), dim3(512), 2 * (128 * 128 + 128 * 128) + 1024, s, b);
-    }
+    b.ntn = a.Cd / 128;
+    const int bm = v == PS_CONV_WS2_256 ? 256 : v == PS_CONV_WS2_224 ? 224 : v == PS_CONV_WS_128 ? 128 : 112;
+    b.ntm = (a.M + bm - 1) / bm;
+    const dim3 grid((unsigned)(b.ntm * b.ntn));
+    const dim3 pgrid((unsigned)std::min<long long>((long long)b.ntm * b.ntn, ps_num_cus()));  // persistent: one block per CU
+    if (v == PS_CONV_WS2_256) hipLaunchKernelGGL((conv_igemm_ws2_kernel<Tr, 256>), pgrid, dim3(512), 3 * (256 * 128 + 128 * 128), s, b);
+    else if (v == PS_CONV_WS2_224) hipLaunchKernelGGL((conv_igemm_ws2_kernel<Tr, 224>), pgrid, dim3(512), 3 * (224 * 128 + 128 * 128), s, b);
+    else if (v == PS_CONV_WS_112) hipLaunchKernelGGL((conv_igemm_ws_kernel<Tr, 112>), grid, dim3(512), 2 * (112 * 128 + 128 * 128) + 1024, s, b);
+    else hipLaunchKernelGGL((conv_igemm_ws_kernel<Tr, 128>), grid, dim3(512), 2 * (128 * 128 + 128 * 128) + 1024, s, b);
     PS_CHECK_LAUNCH("conv_igemm_ws");
     return PS_OK;
   }
@@ -1017,9 +1233,19 @@ extern "C" void ps_debug_set_bm(int bm) { g_force_bm = bm; }
 extern "C" void ps_debug_set_ablate(int v) { g_ablate = v; }
 extern "C" void ps_debug_set_pp(int v) { g_use_pp = v; }
 extern "C" void ps_debug_set_ws(int v) { g_use_ws = v; }
+extern "C" void ps_debug_set_ws2(int v) { g_use_ws2 = v; }
 extern "C" void ps_debug_set_supertile(int v) { g_supertile = v; }
 
 extern "C" int ps_conv_supported(const ps_conv_geom* g) { return check_geom(g) == PS_OK ? 1 : 0; }
+
+extern "C" int ps_conv_variant(const ps_conv_geom* g, int32_t dgrad) {
+  if (check_geom(g) != PS_OK) return -1;
+  const long long ho = (g->h - 1) / g->stride + 1, wo = (g->w - 1) / g->stride + 1;
+  const long long M = dgrad ? (long long)g->n * g->h * g->w : (long long)g->n * ho * wo;
+  if (g_use_3stage || g_use_pp) return PS_CONV_OTHER;
+  const int v = pick_ws_variant(M, dgrad ? g->cin : g->cout, ps_esize(g->dtype));
+  return v ? v : PS_CONV_4WAVE;
+}
 
 extern "C" int ps_conv2d_fwd(const ps_conv_geom* g, const void* x, const void* w_fwd, const ps_epilogue* epi, void* stream) {
   if (int rc = check_geom(g)) return rc;

@@ -15,6 +15,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 void ps_set_error(const char* fmt, ...);
+int ps_num_cus(void);  // compute units of the current device (api.cpp)
 
 #define PS_REQUIRE(cond, ...)            \
   do {                                   \

@@ -23,15 +23,17 @@ Tensor = torch.Tensor
 PROFILE = None
 
 
-def _conv_label(kind: str, dtype: int, m: int, cd: int) -> str:
-    """Mirrors dispatch_bn() in csrc/conv_igemm.hip: which instantiation serves this launch."""
-    dt = {PS_BF16: "bf16", PS_F16: "f16"}.get(dtype, "f32")
+_VARIANT_NAMES = {1: "conv_igemm_kernel", 2: "conv_igemm_ws_kernel", 3: "conv_igemm_ws_kernel", 4: "conv_igemm_ws2_kernel", 5: "conv_igemm_ws2_kernel",
+                  6: "conv_igemm_experimental"}
+
+
+def _conv_label(kind: str, g: ConvGeom) -> str:
+    """Kernel family serving this launch (asked of the library: ps_conv_variant mirrors the dispatcher)."""
+    dt = {PS_BF16: "bf16", PS_F16: "f16"}.get(g.dtype, "f32")
     if kind == "wgrad":
         return f"conv_wgrad_kernel<{dt}>"
-    t128 = (m + 127) // 128
-    if cd % 128 == 0 and t128 * (cd // 128) >= 512:
-        return f"conv_igemm_ws_kernel<{dt}>"
-    return f"conv_igemm_kernel<{dt},128x64>"
+    v = int(_lib.load().ps_conv_variant(C.byref(g), 1 if kind == "dgrad" else 0))
+    return f"{_VARIANT_NAMES.get(v, 'conv_igemm_kernel')}<{dt}>"
 
 
 def _launch(label: str, flops: float, fn):
@@ -126,7 +128,7 @@ def conv2d_fwd(spec: ConvSpec, x: Tensor, w_fwd: Tensor, *, add0=None, out_raw=N
     lib = _lib.load()
     ho, wo = spec.out_hw(h, w)
     m = n * ho * wo
-    _launch(_conv_label("fwd", g.dtype, m, spec.cout), 2.0 * m * spec.cout * spec.cin * spec.ksize**2,
+    _launch(_conv_label("fwd", g) if PROFILE is not None else "", 2.0 * m * spec.cout * spec.cin * spec.ksize**2,
             lambda: _lib.check(lib.ps_conv2d_fwd(C.byref(g), x.data_ptr(), w_fwd.data_ptr(), C.byref(e), _stream()), "ps_conv2d_fwd"))
 
 
@@ -143,7 +145,7 @@ def conv2d_dgrad(spec: ConvSpec, dy: Tensor, w_dgrad: Tensor, x_hw, *, add0=None
     e = _epilogue(mode, add0=add0, out_raw=out_raw, scale=bn_scale, drop=drop, mask_src=mask_src, add1=add1, out=out)
     lib = _lib.load()
     mo = n * dy.shape[1] * dy.shape[2]
-    _launch(_conv_label("dgrad", g.dtype, n * h * w, spec.cin), 2.0 * mo * spec.cout * spec.cin * spec.ksize**2,
+    _launch(_conv_label("dgrad", g) if PROFILE is not None else "", 2.0 * mo * spec.cout * spec.cin * spec.ksize**2,
             lambda: _lib.check(lib.ps_conv2d_dgrad(C.byref(g), dy.data_ptr(), w_dgrad.data_ptr(), C.byref(e), _stream()), "ps_conv2d_dgrad"))
 
 
@@ -156,7 +158,7 @@ def conv2d_wgrad(spec: ConvSpec, x: Tensor, dy: Tensor, dw: Tensor) -> None:
     g = _geom(spec, _dt(x), n, h, w, _ldc(x), _ldc(dy))
     lib = _lib.load()
     mo = n * dy.shape[1] * dy.shape[2]
-    _launch(_conv_label("wgrad", g.dtype, mo, spec.cout), 2.0 * mo * spec.cout * spec.cin * spec.ksize**2,
+    _launch(_conv_label("wgrad", g) if PROFILE is not None else "", 2.0 * mo * spec.cout * spec.cin * spec.ksize**2,
             lambda: _lib.check(lib.ps_conv2d_wgrad(C.byref(g), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _stream()), "ps_conv2d_wgrad"))
 
 

@@ -10,6 +10,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+WS2_DEFAULT = 1  # library default of ps_debug_set_ws2 (restored after tests that force a variant)
 F32_TOL = 1e-4
 BF16_TOL = 1.2e-2
 F16_TOL = 2e-3  # fp16 storage (11 significant bits), f32 accumulate
@@ -404,13 +405,16 @@ def test_conv_pipelined_kernels_are_bit_identical_to_two_stage(case, dtype):
         lib.ps_debug_set_3stage(0)
         lib.ps_debug_set_pp(0)
         lib.ps_debug_set_ws(0)
+        lib.ps_debug_set_ws2(0)
         ref = run()
-        # (3stage, ping-pong, forced group height, wave-specialised)
-        for setup in ((1, 0, 0, 0), (0, 2, 0, 0), (0, 2, 112, 0), (0, 2, 128, 0), (0, 0, 0, 2), (0, 0, 112, 2), (0, 0, 128, 2)):
+        # (3stage, ping-pong, forced group height, wave-specialised, large-tile wave-specialised)
+        for setup in ((1, 0, 0, 0, 0), (0, 2, 0, 0, 0), (0, 2, 112, 0, 0), (0, 2, 128, 0, 0), (0, 0, 0, 2, 0), (0, 0, 112, 2, 0), (0, 0, 128, 2, 0),
+                      (0, 0, 0, 0, 256), (0, 0, 0, 0, 224)):
             lib.ps_debug_set_3stage(setup[0])
             lib.ps_debug_set_pp(setup[1])
             lib.ps_debug_set_bm(setup[2])
             lib.ps_debug_set_ws(setup[3])
+            lib.ps_debug_set_ws2(setup[4])
             for _ in range(3):
                 got = run()
                 for a_, b_ in zip(got, ref):
@@ -420,17 +424,19 @@ def test_conv_pipelined_kernels_are_bit_identical_to_two_stage(case, dtype):
         lib.ps_debug_set_pp(0)
         lib.ps_debug_set_bm(0)
         lib.ps_debug_set_ws(1)
+        lib.ps_debug_set_ws2(WS2_DEFAULT)
     cpu = F.conv2d(x[:1].permute(0, 3, 1, 2), wt, stride=s, padding=d if k == 3 else 0, dilation=d) + res[:1].float().cpu().permute(0, 3, 1, 2)
     tol = TOL[dtype]
     assert rel_err(ref[0][:1].float().cpu(), nhwc(cpu)) < tol
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("bm", [112, 128])
+@pytest.mark.parametrize("bm", [112, 128, 224, 256])
 @pytest.mark.parametrize("case", [(128, 256, 3, 2, 1), (256, 256, 3, 1, 2), (512, 128, 1, 1, 1)])
 def test_conv_pixel_tile_variants(case, bm, dtype):
-    """The 112-pixel (7-fragment, waves 1x4) and 128-pixel (waves 2x2) tilings of the 128-cout kernel, forced on a
-    small problem with ragged M, against the CPU (fwd with the full epilogue, and dgrad)."""
+    """The 112-pixel (7-fragment, waves 1x4) and 128-pixel (waves 2x2) tilings of the 128-cout kernel and the 224- /
+    256-pixel tilings of the large-tile wave-specialised kernel, forced on a small problem with ragged M (tiles with
+    zero-filled tail rows, 1-2 K-steps up to 36), against the CPU (fwd with the full epilogue, and dgrad)."""
     from pistoseg_amd import _lib, ops
 
     lib = _lib.load()
@@ -450,8 +456,11 @@ def test_conv_pixel_tile_variants(case, bm, dtype):
     spec = ops.ConvSpec(cin, cout, k, s, d)
     D = dev()
     try:
-        lib.ps_debug_set_bn(128)
-        lib.ps_debug_set_bm(bm)
+        if bm >= 224:
+            lib.ps_debug_set_ws2(bm)
+        else:
+            lib.ps_debug_set_bn(128)
+            lib.ps_debug_set_bm(bm)
         ho, wo = spec.out_hw(h, w)
         out_raw = torch.full((n, ho, wo, cout), float("nan"), device=D, dtype=dtype)
         out_act = torch.full((n, ho, wo, cout), float("nan"), device=D, dtype=dtype)
@@ -465,3 +474,4 @@ def test_conv_pixel_tile_variants(case, bm, dtype):
     finally:
         lib.ps_debug_set_bn(0)
         lib.ps_debug_set_bm(0)
+        lib.ps_debug_set_ws2(WS2_DEFAULT)
