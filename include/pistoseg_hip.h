@@ -291,6 +291,12 @@ void ps_debug_set_ws(int v);
 void ps_debug_set_ws2(int v);
 /* Testing hook: 1 (default) = 128x128 weight-gradient tiles use the wave-specialised variant, 0 = the 4-wave kernel. */
 void ps_debug_set_wgrad_ws(int v);
+/* Testing hook: large-tile persistent weight-gradient kernel (256x128 tile, one block per CU): 0 off, 1 (default) for big 16-bit problems, 2 forced. */
+void ps_debug_set_wgrad_ws2(int v);
+/* Timing experiments only (results WRONG): 1 = the large-tile weight-gradient kernel skips its atomics, 2 = plain stores instead. */
+void ps_debug_set_wgrad_ablate(int v);
+/* Tuning hook: per-item overhead (in 64-pixel K-steps) the large-tile weight-gradient kernel's split-K cost model assumes. */
+void ps_debug_set_wgrad_ovh(int v);
 /* Testing hook: cout tiles per super-column of the conv block raster (default 4; 0 = plain row-major). */
 void ps_debug_set_supertile(int v);
 /* Testing hook: weight-gradient block order: 0 pixel range slowest, 1 pixel range fastest, -1 (default) chosen by shape. */

@@ -95,6 +95,9 @@ PROTOTYPES = {
     "ps_debug_set_ws": (None, [C.c_int]),
     "ps_debug_set_ws2": (None, [C.c_int]),
     "ps_debug_set_wgrad_ws": (None, [C.c_int]),
+    "ps_debug_set_wgrad_ws2": (None, [C.c_int]),
+    "ps_debug_set_wgrad_ablate": (None, [C.c_int]),
+    "ps_debug_set_wgrad_ovh": (None, [C.c_int]),
     "ps_debug_set_supertile": (None, [C.c_int]),
     "ps_debug_set_wgrad_raster": (None, [C.c_int]),
     "ps_bgemm": (C.c_int, [_I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P]),

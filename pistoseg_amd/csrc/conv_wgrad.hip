@@ -10,6 +10,8 @@
 // a 32-lane half hit 8 distinct 32-byte bank slices.
 // Block = 4 waves (2x2), tile BCO x BCI in {64,128}^2, one tap and one pixel range (split-K) per block;
 // partial sums are added to the f32 gradient with global_atomic_add_f32 (64-byte row segments).
+#include <algorithm>
+
 #include "ps_internal.h"
 
 namespace {
@@ -44,6 +46,7 @@ struct WgradArgs {
   unsigned x_bytes, dy_bytes;  // buffer extents (num_records)
   int dq, dp, dn;              // how (q, p, n) of a pixel advance when its index grows by KP
   int raster;                  // block order (see kernel)
+  int ablate;                  // timing experiments only (results WRONG): 1 = no atomics, 2 = plain stores instead of atomics
 };
 
 struct WTraitsBF16 {
@@ -63,7 +66,7 @@ struct WTraitsF32 {
 template <int ES, int RB>
 __device__ __forceinline__ int row_swz(int R) {
   if constexpr (ES == 4) return (R & 1) << 2;
-  else if constexpr (RB == 256) return ((R & 3) << 1) | (((R >> 3) & 1) << 3);
+  else if constexpr (RB >= 256) return ((R & 3) << 1) | (((R >> 3) & 1) << 3);  // rows of 256 or 512 bytes: whole bank rows
   else return (((R >> 1) & 1) << 1) | (((R >> 3) & 1) << 2);
 }
 
@@ -279,7 +282,238 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 1) void conv_wgrad_kernel(
       }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Large-tile wave-specialised weight gradient: 256 cout x 128 cin tile of one tap, 8 waves = 4 CONSUMERS (2x2, each
+// 128 cout x 64 cin: 8 x 4 fragments) + 4 LOADERS, ONE persistent block per CU (<= 256 VGPRs), 3-stage LDS ring of
+// 64-pixel K-steps -- the same pipeline as conv_igemm_ws2_kernel:
+//   * a quarter less LDS traffic per MFMA than the 128x128 tile (12 fragments per 32 MFMAs instead of 8 per 16);
+//   * the consumers keep the fragments of the NEXT half K-step in flight across the block barrier (the MFMAs of the
+//     previous half step, operands already in registers, run right behind the barrier);
+//   * the loaders run two K-steps ahead (counted vmcnt);
+//   * work items (tile, tap, pixel range) form one flat K-step sequence per block, so the next item's first stages are
+//     prefetched while the consumers issue the (no-return) f32 atomics of the finished one, and those drain behind the
+//     next item's main loop.
+// 16-bit operands only (transposed LDS reads); cout % 256 == 0 and cin % 128 == 0 (every trainable backbone conv).
+// ------------------------------------------------------------------------------------------------
+template <bool F16>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs a) {
+  constexpr int ES = 2, KP = 64, BCO = 256, BCI = 128;
+  constexpr int RBG = BCO * ES, RBX = BCI * ES;             // 512 / 256 bytes per LDS row
+  constexpr int G_BYTES = KP * RBG, X_BYTES = KP * RBX, STAGE = G_BYTES + X_BYTES;  // 32 + 16 KiB
+  constexpr int NIG = G_BYTES / 1024 / 4, NIX = X_BYTES / 1024 / 4;  // 8 + 4 LDS-DMA instructions per loader wave per step
+  constexpr int RPG = 1024 / RBG, RPX = 1024 / RBX;         // 2 / 4 rows per instruction
+  constexpr int MI = 8, NI = 4, NLD = NIG + NIX;
+  static_assert(NLD == 12, "vmcnt literal below");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // blocks that share an XCD (= an L2) get CONSECUTIVE items: with the pixel range slowest in the item order they then stream the
+  // same dY / X pixel rows (measured before the remap: every XCD pulled every pixel range through its L2, ~1 GB per launch
+  // on the memory side of L2 for a 100 MB working set)
+  const int G = gridDim.x, first = ps_xcd_remap(blockIdx.x, G);
+  const int per = (a.ksteps + a.splits - 1) / a.splits;           // K-steps per pixel range
+  const int live = (a.ksteps + per - 1) / per;                    // ranges that get work
+  const int nitems = a.tiles_co * a.tiles_ci * a.taps * live;
+  // item -> (ci tile, co tile, tap, pixel range), pixel range slowest (co-running blocks share their dY / X chunks in L2)
+  auto decode = [&](int item, int& tci, int& tco, int& tap, int& ks0, int& ks1) {
+    tci = item % a.tiles_ci; item /= a.tiles_ci;
+    tco = item % a.tiles_co; item /= a.tiles_co;
+    tap = item % a.taps; item /= a.taps;
+    ks0 = item * per;
+    ks1 = min(a.ksteps, ks0 + per);
+  };
+  // total K-steps of this block's items (ranges are equal except the last)
+  int total_steps = 0;
+  for (int it = first; it < nitems; it += G) {
+    const int sp = it / (a.tiles_ci * a.tiles_co * a.taps);
+    total_steps += min(a.ksteps, (sp + 1) * per) - sp * per;
+  }
+
+  if (wave_all >= 4) {
+    // ================= loader =================
+    const int wave = wave_all - 4;
+    const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)a.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const int g_rowin = lane / (RBG / 16), g_pos = lane % (RBG / 16);
+    const int x_rowin = lane / (RBX / 16), x_pos = lane % (RBX / 16);
+    const int n_img = a.M / (a.Ho * a.Wo);
+    unsigned goff[NIG], xchunk[NIX];
+    int xn[NIX], xp[NIX], xq[NIX];
+    int item = first, ks = 0, ks_end = 0, dy_off = 0, dx_off = 0;
+    auto item_setup = [&](int it) {
+      int tci, tco, tap;
+      decode(it, tci, tco, tap, ks, ks_end);
+      const int ty = a.taps == 1 ? a.ctr : tap / 3, tx = a.taps == 1 ? a.ctr : tap - (tap / 3) * 3;
+      dy_off = (ty - a.ctr) * a.dil;
+      dx_off = (tx - a.ctr) * a.dil;
+#pragma unroll
+      for (int j = 0; j < NIG; ++j) {
+        const int R = (wave * NIG + j) * RPG + g_rowin;
+        goff[j] = (unsigned)(R * (int)a.dy_pix_bytes + tco * BCO * ES + ((g_pos ^ row_swz<ES, RBG>(R)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NIX; ++j) {
+        const int R = (wave * NIX + j) * RPX + x_rowin;
+        const uint32_t m = (uint32_t)(ks * KP + R);
+        const uint32_t n = fdiv(m, a.div_hw);
+        const uint32_t rem = m - n * a.div_hw.d;
+        const uint32_t p = fdiv(rem, a.div_w);
+        xn[j] = (int)n; xp[j] = (int)p; xq[j] = (int)(rem - p * a.div_w.d);
+        xchunk[j] = (unsigned)(tci * BCI * ES + ((x_pos ^ row_swz<ES, RBX>(R)) << 4));
+      }
+    };
+    item_setup(item);
+    int slot = 0, issued = 0;
+    auto issue_next = [&]() -> bool {  // stages the next K-step of the flat sequence: exactly NLD loads per wave
+      if (issued >= total_steps) return false;
+      unsigned char* sg = smem + slot * STAGE;
+      unsigned char* sx = sg + G_BYTES;
+      const int gso = ks * KP * (int)a.dy_pix_bytes;
+#pragma unroll
+      for (int j = 0; j < NIG; ++j) BLDS16(rsG, sg + (wave * NIG + j) * 1024, goff[j], gso);
+#pragma unroll
+      for (int j = 0; j < NIX; ++j) {
+        const int y = xp[j] * a.stride + dy_off, xx = xq[j] * a.stride + dx_off;
+        const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)xx < (unsigned)a.W && xn[j] < n_img;
+        const unsigned off = ok ? (unsigned)(((xn[j] * a.H + y) * a.W + xx) * (int)a.x_pix_bytes) + xchunk[j] : PAD_ROW;
+        BLDS16(rsX, sx + (wave * NIX + j) * 1024, off, 0);
+        int q = xq[j] + a.dq;  // advance this lane's pixel by KP
+        const int c1 = q >= a.Wo;
+        q -= c1 ? a.Wo : 0;
+        int p = xp[j] + a.dp + c1;
+        const int c2 = p >= a.Ho;
+        p -= c2 ? a.Ho : 0;
+        xq[j] = q; xp[j] = p; xn[j] += a.dn + c2;
+      }
+      ++issued;
+      slot = (slot == 2) ? 0 : slot + 1;
+      if (++ks == ks_end && issued < total_steps) {
+        item += G;
+        item_setup(item);
+      }
+      return true;
+    };
+    auto wait_older = [&](bool newest_in_flight) {
+      if (newest_in_flight) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    issue_next();
+    wait_older(issue_next());
+    __builtin_amdgcn_s_barrier();  // step 0 visible
+    for (int gs = 0; gs < total_steps; ++gs) {
+      wait_older(issue_next());  // step gs+1 landed; ring slot (gs+2)%3 was released by the previous barrier
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
+
+  // ================= consumer =================
+  const int wave = wave_all;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int g = lane >> 4, l16 = lane & 15, q4 = l16 >> 2, p4 = l16 & 3;
+  // byte offsets of this lane's transposed reads inside a stage, for K-half kk and half-fragment h: row R = 32kk + 8g + 4h + q4.
+  // row_swz only depends on R & 3 (= q4) and (R >> 3) & 1 (= g & 1), so one swizzle value serves every (kk, h).
+  const int swz = row_swz<ES, RBG>(8 * g + q4);  // identical formula for both row widths
+  const int a_lane = (8 * g + q4) * RBG + (p4 & 1) * 8, b_lane = G_BYTES + (8 * g + q4) * RBX + (p4 & 1) * 8;
+  int a_chunk[MI], b_chunk[NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) a_chunk[i] = ((((wr * 128 + i * 16) >> 3) + (p4 >> 1)) ^ swz) << 4;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) b_chunk[j] = ((((wc * 64 + j * 16) >> 3) + (p4 >> 1)) ^ swz) << 4;
+
+  auto rd = [&](const unsigned char* st, int kk, bf16x8 (&af)[MI], bf16x8 (&bf)[NI]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int roff = (kk * 32 + 4 * h);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(st + a_lane + roff * RBG + a_chunk[i]));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) af[i][4 * h + e] = t[e];
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(st + b_lane + roff * RBX + b_chunk[j]));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bf[j][4 * h + e] = t[e];
+      }
+    }
+  };
+  auto mma = [&](f32x4 (&acc)[MI][NI], const bf16x8 (&af)[MI], const bf16x8 (&bf)[NI]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        if constexpr (F16)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[i]), __builtin_bit_cast(f16x8, bf[j]), acc[i][j], 0, 0, 0);
+        else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+  };
+
+  __builtin_amdgcn_s_barrier();  // step 0 visible
+  int cur = 0;
+  const long long wrow = (long long)a.taps * a.cin;
+  for (int item = first; item < nitems; item += G) {
+    int tci, tco, tap, ks0, ks1;
+    decode(item, tci, tco, tap, ks0, ks1);
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af0[MI], bf0[NI], af1[MI], bf1[NI];
+    for (int ks = ks0; ks < ks1; ++ks) {
+      const unsigned char* st = smem + cur * STAGE;
+      rd(st, 0, af0, bf0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks > ks0) mma(acc, af1, bf1);  // previous step's second half: operands already in registers
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      rd(st, 1, af1, bf1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(acc, af0, bf0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this ring slot may be refilled after the barrier
+      __builtin_amdgcn_s_barrier();
+      cur = (cur == 2) ? 0 : cur + 1;
+    }
+    mma(acc, af1, bf1);
+    // D fragment (i, j): lane (g, l16) holds rows 4g + r, column l16.  A 4x4 transpose between the lane-group index g and the
+    // fragment index j (two half-wave swaps + two row swaps per register quartet) leaves register j' of lane (g', l16) with
+    // row 4j' + r, column 16g' + l16 = the lane id: every atomic wave-instruction then adds ONE 256-byte contiguous row
+    // segment (the shape the memory-side atomic units take at full rate) instead of four 64-byte pieces.
+    float* base = a.dw + (long long)(tco * BCO + wr * 128) * wrow + (long long)tap * a.cin + tci * BCI + wc * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        uint32_t v0 = __float_as_uint(acc[i][0][r]), v1 = __float_as_uint(acc[i][1][r]);
+        uint32_t v2 = __float_as_uint(acc[i][2][r]), v3 = __float_as_uint(acc[i][3][r]);
+        auto s02 = __builtin_amdgcn_permlane32_swap(v0, v2, false, false);  // g bit 1 <-> j bit 1
+        auto s13 = __builtin_amdgcn_permlane32_swap(v1, v3, false, false);
+        v0 = s02[0]; v2 = s02[1]; v1 = s13[0]; v3 = s13[1];
+        auto s01 = __builtin_amdgcn_permlane16_swap(v0, v1, false, false);  // g bit 0 <-> j bit 0
+        auto s23 = __builtin_amdgcn_permlane16_swap(v2, v3, false, false);
+        const float o[4] = {__uint_as_float(s01[0]), __uint_as_float(s01[1]), __uint_as_float(s23[0]), __uint_as_float(s23[1])};
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) {
+          float* dst = base + (long long)(i * 16 + 4 * jp + r) * wrow;
+          if (a.ablate == 0) atomicAdd(dst, o[jp]);
+          else if (a.ablate == 2) *dst = o[jp];
+          else asm volatile("" ::"v"(o[jp]));
+        }
+      }
+  }
+}
+
 static int g_wgrad_ws = 1;
+static int g_wgrad_ablate = 0;
+static int g_wgrad_ovh = 16;  // per-item overhead of the persistent kernel in K-step units (atomics + pipeline refill)
+static int g_wgrad_ws2 = 1;  // large-tile persistent kernel for 16-bit operands with cout % 256 == 0, cin % 128 == 0
+
 static int g_wgrad_raster = -1;  // -1: by shape (measured r01: pixel-range-slowest wins for 3x3 layers with >= 64 tiles)
 
 template <typename Tr, int BCO, int BCI>
@@ -317,7 +551,40 @@ int launch_wgrad(WgradArgs a, hipStream_t s) {
 }
 
 template <typename Tr>
+int launch_wgrad_ws2(WgradArgs a, hipStream_t s) {
+  a.tiles_co = a.cout / 256;
+  a.tiles_ci = a.cin / 128;
+  a.ksteps = (a.M + 63) / 64;
+  a.dq = 64 % a.Wo;
+  a.dp = (64 / a.Wo) % a.Ho;
+  a.dn = 64 / (a.Wo * a.Ho);
+  a.raster = 0;
+  a.ablate = g_wgrad_ablate;
+  const long long tiles = (long long)a.tiles_co * a.tiles_ci * a.taps;
+  const int ncu = ps_num_cus();
+  // Pixel-range count: one block per CU works through ceil(items / CUs) items of `per` K-steps each (+ ~6 K-steps' worth of
+  // atomics and pipeline refill per item); ties go to fewer ranges (fewer atomics).
+  long long splits = 1, best = -1;
+  const long long max_splits = std::max<long long>(1, a.ksteps / 8);
+  for (long long sp = 1; sp <= max_splits && tiles * sp <= 65536; ++sp) {
+    const long long per = (a.ksteps + sp - 1) / sp, live = (a.ksteps + per - 1) / per;
+    const long long rounds = (tiles * live + ncu - 1) / ncu;
+    const long long cost = rounds * (per + g_wgrad_ovh);
+    if (best < 0 || cost < best) { best = cost; splits = sp; }
+  }
+  a.splits = (int)splits;
+  const long long per = (a.ksteps + splits - 1) / splits, live = (a.ksteps + per - 1) / per;
+  const long long items = tiles * live;
+  const unsigned grid = (unsigned)std::min<long long>(items, ncu);
+  hipLaunchKernelGGL((conv_wgrad_ws2_kernel<Tr::F16>), dim3(grid), dim3(512), 3 * 64 * (256 + 128) * 2, s, a);
+  PS_CHECK_LAUNCH("conv_wgrad_ws2");
+  return PS_OK;
+}
+
+template <typename Tr>
 int dispatch_wgrad(const WgradArgs& a, hipStream_t s) {
+  if (g_wgrad_ws2 && Tr::ES == 2 && a.cout % 256 == 0 && a.cin % 128 == 0 && (g_wgrad_ws2 > 1 || (long long)a.M * a.cout * a.cin * a.taps >= (1LL << 31)))
+    return launch_wgrad_ws2<Tr>(a, s);
   const bool co128 = a.cout % 128 == 0, ci128 = a.cin % 128 == 0;
   if (co128 && ci128) return launch_wgrad<Tr, 128, 128>(a, s);
   if (co128) return launch_wgrad<Tr, 128, 64>(a, s);
@@ -328,6 +595,9 @@ int dispatch_wgrad(const WgradArgs& a, hipStream_t s) {
 }  // namespace
 
 extern "C" void ps_debug_set_wgrad_ws(int v) { g_wgrad_ws = v; }
+extern "C" void ps_debug_set_wgrad_ws2(int v) { g_wgrad_ws2 = v; }
+extern "C" void ps_debug_set_wgrad_ablate(int v) { g_wgrad_ablate = v; }
+extern "C" void ps_debug_set_wgrad_ovh(int v) { g_wgrad_ovh = v; }
 extern "C" void ps_debug_set_wgrad_raster(int v) { g_wgrad_raster = v; }
 
 extern "C" int ps_conv2d_wgrad(const ps_conv_geom* g, const void* x, const void* dy, float* dw, void* stream) {

@@ -143,8 +143,11 @@ def test_seg_trainer_fp16_loss_scaling_tracks_fp32():
     l32, l16 = out["fp32"][0], out["fp16"][0]
     tr16, m16 = out["fp16"][1], out["fp16"][2]
     assert tr16.skipped_steps == 0 and tr16.loss_scale == 65536.0
-    for a, b in zip(l32, l16):
-        assert abs(a - b) < 2e-2 * abs(a), (l32, l16)
+    # step 1 sees identical weights: fp16 storage error only.  Later steps compare two Adam trajectories (every weight moves by
+    # ~lr * sign(g) per step, so elements whose gradient sits at the rounding floor diverge): loose bound.
+    assert abs(l32[0] - l16[0]) < 2e-3 * abs(l32[0]), (l32, l16)
+    for a, b in zip(l32[1:], l16[1:]):
+        assert abs(a - b) < 1e-1 * abs(a), (l32, l16)
     # the fp16 shadow is the rounded f32 master
     assert torch.equal(tr16.pb_flat, tr16.p_flat.half())
     # forced overflow: an absurd scale must be detected, skipped and halved

@@ -430,6 +430,48 @@ def test_conv_pipelined_kernels_are_bit_identical_to_two_stage(case, dtype):
     assert rel_err(ref[0][:1].float().cpu(), nhwc(cpu)) < tol
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [
+    # (n, h, w, cin, cout, k, s, d): ragged pixel counts (zero-filled K tail), 1 .. several work items per persistent block
+    (2, 13, 10, 128, 256, 3, 2, 1), (2, 13, 10, 256, 256, 3, 1, 1), (3, 9, 11, 256, 512, 1, 2, 1), (2, 13, 10, 512, 1024, 3, 1, 2),
+    (4, 14, 14, 1024, 2048, 3, 1, 4), (16, 28, 28, 512, 512, 3, 1, 1), (8, 28, 28, 2048, 4096, 1, 1, 1),
+])
+def test_wgrad_large_tile_persistent_kernel(case, dtype):
+    """conv_wgrad_ws2_kernel (256x128 tile, persistent, 3-stage ring) forced on small and medium problems: against the CPU
+    autograd weight gradient on identically rounded operands, and against the 128x128 kernel (same products, f32 atomics in a
+    different order)."""
+    from pistoseg_amd import _lib, ops
+
+    lib = _lib.load()
+    n, h, w, cin, cout, k, s, d = case
+    g = torch.Generator().manual_seed(cin + cout + k)
+    q = quant(dtype)
+    x = q(torch.randn(n, cin, h, w, generator=g))
+    wt = (torch.randn(cout, cin, k, k, generator=g) * 0.05).requires_grad_(True)
+    y = F.conv2d(x, wt, stride=s, padding=d if k == 3 else 0, dilation=d)
+    gy = q(torch.randn(y.shape, generator=g))
+    y.backward(gy)
+    spec = ops.ConvSpec(cin, cout, k, s, d)
+    D = dev()
+    xd, gyd = nhwc(x).to(D, dtype), nhwc(gy).to(D, dtype)
+    try:
+        lib.ps_debug_set_wgrad_ws2(2)
+        got = []
+        for _ in range(3):  # race screen: repeated launches agree up to f32 atomic ordering
+            dw = torch.zeros((cout, k, k, cin), device=D, dtype=torch.float32)
+            ops.conv2d_wgrad(spec, xd, gyd, dw)
+            got.append(dw)
+        lib.ps_debug_set_wgrad_ws2(0)
+        old = torch.zeros((cout, k, k, cin), device=D, dtype=torch.float32)
+        ops.conv2d_wgrad(spec, xd, gyd, old)
+    finally:
+        lib.ps_debug_set_wgrad_ws2(1)
+    ref = w_fwd_layout(wt.grad)
+    for dw in got:
+        assert rel_err(dw.cpu(), ref) < 1e-4   # exact products, f32 accumulation
+        assert rel_err(dw.cpu(), old.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("bm", [112, 128, 224, 256])
 @pytest.mark.parametrize("case", [(128, 256, 3, 2, 1), (256, 256, 3, 1, 2), (512, 128, 1, 1, 1)])

@@ -55,7 +55,10 @@ def main():
                     lib.ps_debug_set_3stage(0)
                     lib.ps_debug_set_pp(0)
                     lib.ps_debug_set_ws(1)
-                    lib.ps_debug_set_ws2(0)
+                    lib.ps_debug_set_ws2(1)
+                    lib.ps_debug_set_wgrad_ws2(1)
+                    lib.ps_debug_set_wgrad_ablate(0)
+                    lib.ps_debug_set_wgrad_ovh(16)
                     lib.ps_debug_set_supertile(4)
                     getattr(lib, "ps_debug_set_" + vn)(int(vv))
                     fns[what]()
@@ -78,7 +81,9 @@ def main():
     lib.ps_debug_set_ablate(0)
     lib.ps_debug_set_pp(0)
     lib.ps_debug_set_ws(1)
-    lib.ps_debug_set_ws2(0)
+    lib.ps_debug_set_ws2(1)
+    lib.ps_debug_set_wgrad_ws2(1)
+    lib.ps_debug_set_wgrad_ablate(0)
     lib.ps_debug_set_wgrad_raster(-1)
 
 if __name__ == "__main__":
