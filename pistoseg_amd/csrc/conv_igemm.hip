@@ -98,7 +98,9 @@ constexpr unsigned PAD_ROW = 0x80000000u;
 
 // Epilogue shared by the conv kernels: lane (frow = lane&15, g = lane>>4) owns pixels mbase + mi*16 + frow and the
 // CH = 4*WI contiguous produced channels cbase + CH*g .. (acc[mi][i][r] = channel 4*i + r of that group).
-template <typename T, int MI, int WI>
+// COLMAP (halo kernel): fragment mi holds an 8-row x 2-column patch of the tile instead of 16 consecutive pixels:
+// pixel = mbase + (frow & 7) * Wo + 2 * mi + (frow >> 3).
+template <typename T, int MI, int WI, bool COLMAP = false>
 __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[MI][WI], int mbase, int cbase, int lane) {
   constexpr int CH = 4 * WI;  // 16 or 8
   const int frow = lane & 15, g = lane >> 4;
@@ -122,7 +124,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
   };
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
-    const int m = mbase + mi * 16 + frow;
+    const int m = COLMAP ? mbase + (frow & 7) * a.Wo + 2 * mi + (frow >> 3) : mbase + mi * 16 + frow;
     if (m >= a.M) continue;
     float v[CH];
 #pragma unroll
@@ -967,6 +969,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
     tile_setup(tile);
     auto issue_next = [&]() -> bool {  // stages the next K-step of the flat sequence (exactly NLD loads per wave)
       if (issued >= total_steps) return false;
+      if (a.ablate == 1 && issued >= 3) { ++issued; return false; }  // timing experiment: consumers run on stale LDS contents
       unsigned char* sa = smem + slot * STAGE;
       unsigned char* sb = sa + A_BYTES;
       const int ko = kl * 128;
@@ -1023,34 +1026,46 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
 #pragma unroll
       for (int i = 0; i < WI; ++i) acc[mi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     u32x4 wf0[WI], xf0[MI], wf1[WI], xf1[MI];  // fragments of the first / second K-half of a step
-    for (int s = 0; s < nsteps; ++s) {
-      const unsigned char* st = smem + cur * STAGE;
-      // reads of this step's first K-half ...
+    // One K-half: issue the NR = WI + MI fragment reads of (stage st, chunk offset coff) into (wfn, xfn) INTERLEAVED with the
+    // MFMAs on (wfo, xfo), whose operands are already in registers: read, 2 MFMAs, read, 2 MFMAs, ... so the matrix pipe
+    // starts right behind the barrier / the wait instead of idling through a burst of 11-12 LDS instructions (the order is
+    // pinned with scheduling barriers; hipcc otherwise hoists all reads to the top).
+    auto half = [&](const unsigned char* st, int coff, u32x4 (&wfn)[WI], u32x4 (&xfn)[MI], const u32x4 (&wfo)[WI], const u32x4 (&xfo)[MI],
+                    bool do_mma) {
+      constexpr int NR = WI + MI, NM = MI * WI, PER = 2;
 #pragma unroll
-      for (int i = 0; i < WI; ++i) wf0[i] = *reinterpret_cast<const u32x4*>(st + wfrag + i * 2048 + coff0);
+      for (int r = 0; r < NR; ++r) {
+        if (r < WI) wfn[r] = *reinterpret_cast<const u32x4*>(st + wfrag + r * 2048 + coff);
+        else xfn[r - WI] = *reinterpret_cast<const u32x4*>(st + xfrag + (r - WI) * 2048 + coff);
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_mma) {
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) xf0[mi] = *reinterpret_cast<const u32x4*>(st + xfrag + mi * 2048 + coff0);
-      __builtin_amdgcn_sched_barrier(0);
-      // ... hidden behind the MFMAs of the previous step's second K-half (operands already in registers)
-      if (s > 0) {
+          for (int q = r * PER; q < (r + 1) * PER && q < NM; ++q) Tr::mma(wfo[q % WI], xfo[q / WI], acc[q / WI][q % WI]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (do_mma) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int i = 0; i < WI; ++i) Tr::mma(wf1[i], xf1[mi], acc[mi][i]);
+        for (int q = NR * PER; q < NM; ++q) Tr::mma(wfo[q % WI], xfo[q / WI], acc[q / WI][q % WI]);
       }
       __builtin_amdgcn_sched_barrier(0);
+    };
+    {  // first K-step of the tile: nothing to overlap the first reads with
+      const unsigned char* st = smem + cur * STAGE;
+      half(st, coff0, wf0, xf0, wf1, xf1, false);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < WI; ++i) wf1[i] = *reinterpret_cast<const u32x4*>(st + wfrag + i * 2048 + coff1);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) xf1[mi] = *reinterpret_cast<const u32x4*>(st + xfrag + mi * 2048 + coff1);
+      half(st, coff1, wf1, xf1, wf0, xf0, true);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      cur = (cur == 2) ? 0 : cur + 1;
+    }
+    for (int s = 1; s < nsteps; ++s) {
+      const unsigned char* st = smem + cur * STAGE;
+      half(st, coff0, wf0, xf0, wf1, xf1, true);  // this step's first K-half is read behind the previous step's second-half MFMAs
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int i = 0; i < WI; ++i) Tr::mma(wf0[i], xf0[mi], acc[mi][i]);
-      __builtin_amdgcn_sched_barrier(0);
+      half(st, coff1, wf1, xf1, wf0, xf0, true);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads of this slot are done: the loaders may refill it
       __builtin_amdgcn_s_barrier();
       cur = (cur == 2) ? 0 : cur + 1;
@@ -1065,10 +1080,246 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Halo kernel: 3x3 STRIDE-1 convolutions on 28-wide feature maps (any dilation <= 4; forward and data gradient), persistent
+// 224 x 128 tiles, 4 consumer + 4 loader waves as conv_igemm_ws2_kernel -- but the pixel operand is staged as a WINDOW with
+// its halo instead of one gathered tile per tap.
+//   The ws2 kernel is bound by L2 -> LDS fill bandwidth, not by the matrix pipe (r01: with the loads ablated the consumers
+//   run 26-35 % faster; every CU pulls (224 + 128) x 128 B per K-step = ~64 GB/s, ~16.5 TB/s chip-wide, the measured ceiling
+//   of LDS gathers from L2): each input row is fetched nine times, once per tap.  Here a tile is 8 whole feature-map rows
+//   (global rows n*H + p, 224 = 8 x 28 pixels); for one 64-channel K-line and one tap ROW ty the loaders stage the
+//   8 x (28 + 2d) window  rows [R0 + (ty-1)d, +8) x cols [-d, 28 + d)  once (zero-filled outside the image), and the three
+//   taps tx = 0..2 of that row are three K-steps whose pixel fragments are read from the same window at a column shift of
+//   (tx-1)d: fill traffic per K-step drops from 45 KiB to 26-28 KiB.
+//   * K order is (K-line, ty, tx) instead of (tap, K-line): sums are re-associated relative to the other kernels.
+//   * for a given tap row, window row wr serves exactly one produced row (global row R0 + wr), so vertical padding -- and rows
+//     that would come from the neighbouring image when a tile straddles two images (28 % 8 != 0) -- are zero-filled by the
+//     LOADER per window row.
+//   * the window is stored COLUMN-major (one 1-KiB DMA instruction = one window column of 8 rows) and a fragment is an
+//     8-row x 2-column patch: the swizzle term row & 7 is then the window ROW, independent of the tap column, so a lane's
+//     fragment address for tap tx is a kernel-constant centre address + a scalar -- no per-step address arithmetic.
+//   * LDS: 2 windows x 36 KiB + 3 weight stages x 16 KiB; the window for (K-line, ty) + 1 is issued during the first K-step
+//     of the current one (behind that step's weights, so the in-order vmcnt lets it stay in flight for two steps); weights
+//     run two K-steps ahead.
+// ------------------------------------------------------------------------------------------------
+template <typename Tr>
+__global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs a) {
+  typedef typename Tr::elem T;
+  constexpr int BM = 224, BN = 128, MI = 7, WI = 4, WN = 64, W = 28, TR = 8;
+  constexpr int WJ = 9, WIN_BYTES = WJ * 4 * 1024, B_BYTES = BN * 128;
+  constexpr int W_OFF = 2 * WIN_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = gridDim.x;
+  const int first = ps_xcd_remap(blockIdx.x, G);
+  const int ntiles = a.ntm * a.ntn;
+  const int nwin = 3 * a.klines;             // windows (K-line, ty) per tile, three K-steps each
+  const int my_tiles = (ntiles - first + G - 1) / G;
+  const int total_steps = my_tiles * nwin * 3;
+  const int H = a.Hs, NH = a.M / W;          // stride 1: produced grid == source grid; NH = global rows n*H + p
+  const int dabs = a.dstep < 0 ? -a.dstep : a.dstep;
+  const int WP = W + 2 * dabs;               // window columns (<= 36)
+
+  if (wave >= 4) {
+    // ================= loader =================
+    const int lw = wave - 4;
+    const int srow = lane >> 3;              // window row this lane stages (of every window column)
+    const int chunk_off = ((lane & 7) ^ srow) << 4;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, (int)a.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, 0, (int)a.wgt_bytes, 0x00020000);
+    // DMA instruction t = 4j + lw stages window COLUMN t (8 rows x 128 B = the instruction's 1 KiB): source column t - d
+    int rel[WJ];
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+      const int t = j * 4 + lw, col = t - dabs;
+      rel[j] = (t < WP && col >= 0 && col < W) ? (srow * W + col) * (int)a.pix_bytes + chunk_off : -1;
+    }
+    // --- cursor of the next WINDOW to stage: (tile, K-line, ty).  Window row wr of tap row ty serves exactly ONE produced row,
+    // global row R0 + wr: it holds source row p + (ty-1)*dstep of the SAME image, or zeros (vertical padding; produced rows
+    // past the tensor's end; rows that would come from the neighbouring image when a tile straddles two images).
+    int a_tile = first, a_kl = 0, a_ty = 0, a_buf = 0, a_left = my_tiles * nwin;
+    int a_R0 = 0, prow = 0;  // prow: image row p of the produced row this lane's window row serves (per tile)
+    auto window_tile_setup = [&](int tile) {
+      int tm, tn;
+      ps_tile_of_block(tile, a.ntn, a.ntm, tm, tn, a.supertile);
+      a_R0 = tm * TR;
+      const int gr = a_R0 + srow;
+      prow = gr < NH ? gr - (gr / H) * H : -(1 << 20);
+    };
+    window_tile_setup(a_tile);
+    auto issue_window = [&]() -> bool {
+      if (a_left == 0) return false;
+      const int shift = (a_ty - 1) * a.dstep;
+      const int base = (a_R0 + shift) * W * (int)a.pix_bytes;
+      const bool row_ok = (unsigned)(prow + shift) < (unsigned)H;
+      unsigned char* dst = smem + a_buf * WIN_BYTES;
+      const int ko = a_kl * 128;
+#pragma unroll
+      for (int j = 0; j < WJ; ++j)
+        BLDS16(rsA, dst + (j * 4 + lw) * 1024, (row_ok && rel[j] >= 0) ? (unsigned)(base + rel[j]) : PAD_ROW, ko);
+      --a_left;
+      a_buf ^= 1;
+      if (++a_ty == 3) {
+        a_ty = 0;
+        if (++a_kl == a.klines) {
+          a_kl = 0;
+          a_tile += G;
+          if (a_left) window_tile_setup(a_tile);
+        }
+      }
+      return true;
+    };
+    // --- cursor of the next WEIGHT tile to stage: (tile, K-line, tap)
+    int b_tile = first, b_kl = 0, b_tap = 0, b_slot = 0, b_left = total_steps;
+    unsigned woff[4];
+    auto weights_setup = [&](int tile) {
+      int tm, tn;
+      ps_tile_of_block(tile, a.ntn, a.ntm, tm, tn, a.supertile);
+      const int n0 = tn * BN;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int rb = (j * 4 + lw) * 8 + srow;
+        const int wg = rb / WN, within = rb % WN, fi = within >> 4, rho = within & 15;
+        const int cout = n0 + wg * WN + 4 * WI * (rho >> 2) + 4 * fi + (rho & 3);
+        woff[j] = (unsigned)(cout * a.wrow_bytes) + chunk_off;
+      }
+    };
+    weights_setup(b_tile);
+    const int tap_bytes = a.klines * 128;  // Cs * esize
+    auto issue_weights = [&]() -> bool {
+      if (b_left == 0) return false;
+      unsigned char* dst = smem + W_OFF + b_slot * B_BYTES;
+      const int wk = b_tap * tap_bytes + b_kl * 128;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) BLDS16(rsB, dst + (j * 4 + lw) * 1024, woff[j], wk);
+      --b_left;
+      b_slot = (b_slot == 2) ? 0 : b_slot + 1;
+      if (++b_tap == 9) {
+        b_tap = 0;
+        if (++b_kl == a.klines) {
+          b_kl = 0;
+          b_tile += G;
+          if (b_left) weights_setup(b_tile);
+        }
+      }
+      return true;
+    };
+    auto wait_allow = [&](int n) {  // all but the n newest DMAs of this wave have landed (n in {0, 4, 9, 13})
+      if (n == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+      else if (n == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    issue_window();
+    issue_weights();
+    wait_allow(issue_weights() ? 4 : 0);
+    __builtin_amdgcn_s_barrier();  // window 0 and the weights of step 0 are visible
+    int r = 0, win_pending = 0;
+    for (int gs = 0; gs < total_steps; ++gs) {
+      // issue order inside a step: weights of step gs+2 first, then (first step of a window) the NEXT window -- the in-order
+      // vmcnt then lets the window stay in flight until the end of the current window's third step
+      const int wA = issue_weights() ? 4 : 0;
+      int allow;
+      if (r == 0) {
+        win_pending = issue_window() ? 9 : 0;
+        allow = wA + win_pending;
+      } else if (r == 1) {
+        allow = wA + win_pending;
+      } else {
+        allow = wA;
+      }
+      wait_allow(allow);
+      __builtin_amdgcn_s_barrier();
+      r = (r == 2) ? 0 : r + 1;
+    }
+    return;
+  }
+
+  // ================= consumer =================
+  // waves 2x2: wm = column half of the tile (14 columns = 7 fragments of 8 rows x 2 columns), wn = cout half
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 15, g = lane >> 4;
+  const int wfrag = W_OFF + (wn * WN + frow) * 128;
+  const int sw = lane & 7;
+  const int coff0 = (g ^ sw) << 4, coff1 = ((g + 4) ^ sw) << 4;
+  // The window is stored COLUMN-major (LDS row = 8 * window column + window row): a fragment's 16 lanes read 8 rows of 2
+  // adjacent columns -- conflict-free with the usual chunk ^ (row & 7) swizzle, whose row & 7 is the WINDOW ROW and therefore
+  // does not change with the tap column: the address for tap tx is the centre address + (tx-1)*dstep KiB, a scalar.
+  const int tr = frow & 7;
+  int xa[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int c = wm * 14 + 2 * mi + (frow >> 3) + dabs;  // window column of the centre tap
+    xa[mi] = c * 1024 + tr * 128 + ((g ^ tr) << 4);
+  }
+  __builtin_amdgcn_s_barrier();  // window 0 / weights of step 0 visible
+
+  int cur = 0, wbuf = 0;
+  for (int tile = first; tile < ntiles; tile += G) {
+    f32x4 acc[MI][WI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int i = 0; i < WI; ++i) acc[mi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 wf0[WI], xf0[MI], wf1[WI], xf1[MI];
+    // One K-half: the NR = WI + MI fragment reads interleaved with the MFMAs whose operands are already in registers
+    // (see conv_igemm_ws2_kernel); a pixel fragment address = centre address + scalar (window buffer, tap column) [^ K-half].
+    auto half = [&](const unsigned char* wst, int wcoff, int soff, int flip, u32x4 (&wfn)[WI], u32x4 (&xfn)[MI], const u32x4 (&wfo)[WI],
+                    const u32x4 (&xfo)[MI], bool do_mma) {
+      constexpr int NR = WI + MI, NM = MI * WI, PER = 2;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        if (r < WI) wfn[r] = *reinterpret_cast<const u32x4*>(wst + r * 2048 + wcoff);
+        else xfn[r - WI] = *reinterpret_cast<const u32x4*>(smem + ((xa[r - WI] ^ flip) + soff));
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_mma) {
+#pragma unroll
+          for (int q = r * PER; q < (r + 1) * PER && q < NM; ++q) Tr::mma(wfo[q % WI], xfo[q / WI], acc[q / WI][q % WI]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (do_mma) {
+#pragma unroll
+        for (int q = NR * PER; q < NM; ++q) Tr::mma(wfo[q % WI], xfo[q / WI], acc[q / WI][q % WI]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto kstep = [&](int tx, bool first_of_tile) {
+      const unsigned char* wst = smem + cur * B_BYTES + wfrag;
+      const int soff = wbuf * WIN_BYTES + (tx - 1) * a.dstep * 1024;
+      half(wst, coff0, soff, 0, wf0, xf0, wf1, xf1, !first_of_tile);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      half(wst, coff1, soff, 64, wf1, xf1, wf0, xf0, true);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      cur = (cur == 2) ? 0 : cur + 1;
+    };
+    // first K-step of the tile peeled (no previous MFMAs to overlap its reads with), then tx = 1, 2, 0, 1, 2, ...
+    kstep(0, true);
+    int tx = 1;
+    for (int s = 1; s < 3 * nwin; ++s) {
+      kstep(tx, false);
+      if (++tx == 3) { tx = 0; wbuf ^= 1; }
+    }
+    // (after the last step tx wrapped to 0 and wbuf moved on to the next tile's first window)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int i = 0; i < WI; ++i) Tr::mma(wf1[i], xf1[mi], acc[mi][i]);
+    int tm, tn;
+    ps_tile_of_block(tile, a.ntn, a.ntm, tm, tn, a.supertile);
+    conv_epilogue<T, MI, WI, true>(a, acc, tm * BM + wm * 14, tn * BN + wn * WN, lane);
+  }
+}
+
 static int g_use_glds = 2;  // staging mode: 0 registers, 1 global_load_lds, 2 buffer_load ... lds
 static int g_use_pp = 0;       // experimental ping-pong kernel (correct, slower: r01 measurements)
 static int g_use_ws = 1;       // wave-specialised (loader/consumer) kernel for big problems
-static int g_use_ws2 = 1;      // large-tile wave-specialised kernel: 0 off, 1 by cost model, 256 / 224 force that pixel tile
+static int g_use_ws2 = 1;
+static int g_use_halo = 1;     // window + halo staging for 3x3 stride-1 layers on 28-wide maps: 0 off, 1 where the large tile would be chosen, 2 forced      // large-tile wave-specialised kernel: 0 off, 1 by cost model, 256 / 224 force that pixel tile
 static int g_use_3stage = 0;  // experimental 256x128 three-stage kernel: correct but slower than two 128x128 blocks per CU (r01 measurements)
 static int g_ablate = 0;
 static int g_supertile = 4;  // measured best of {0,4,8,16} on the wide 28x28 layers (r01)
@@ -1146,9 +1397,11 @@ int set_extents(IgemmArgs& a, long long src_bytes, long long wgt_bytes) {
 //   * it beats the two-blocks-per-CU kernel whenever there are >= 2 cout tiles (r01: +5..+12 % on the 28x28 layers, equal on
 //     256-channel 56x56); single-cout-tile layers (128 channels @112x112, 18 K-steps) keep the small tile, whose second
 //     resident block hides the epilogue.
-static int pick_ws_variant(long long M, int Cd, int esize) {
+static int pick_ws_variant(long long M, int Cd, int esize, bool halo_ok) {
   if (g_use_glds != 2 || Cd % 128 != 0) return 0;
   const long long n128 = Cd / 128;
+  // 3x3 stride-1 layers whose 224-pixel tiles are whole feature-map rows: window + halo staging (less LDS fill traffic)
+  if (halo_ok && g_use_halo && (g_use_halo > 1 || (g_use_ws2 == 1 && esize == 2 && n128 >= 2 && ((M + 223) / 224) * n128 >= 256))) return PS_CONV_HALO;
   if (g_use_ws2 && (g_use_ws2 > 1 || (esize == 2 && n128 >= 2 && ((M + 255) / 256) * n128 >= 256))) {
     const long long t256 = (M + 255) / 256, t224 = (M + 223) / 224;
     const long long c256 = ((t256 * n128 + 255) / 256) * 256, c224 = ((t224 * n128 + 255) / 256) * 224;
@@ -1195,9 +1448,18 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
       return PS_OK;
     }
   }
-  if (const int v = pick_ws_variant(a.M, a.Cd, (int)sizeof(typename Tr::elem))) {
+  const int adil = a.dstep < 0 ? -a.dstep : a.dstep;
+  const bool halo_ok = a.taps == 9 && a.mul == 1 && a.div_shift == 0 && a.Hs == a.Ho && a.Ws == a.Wo && a.Ws == 28 && adil <= 4;
+  if (const int v = pick_ws_variant(a.M, a.Cd, (int)sizeof(typename Tr::elem), halo_ok)) {
     IgemmArgs b = a;
     b.ntn = a.Cd / 128;
+    if (v == PS_CONV_HALO) {
+      b.ntm = (a.M + 223) / 224;
+      const dim3 hgrid((unsigned)std::min<long long>((long long)b.ntm * b.ntn, ps_num_cus()));
+      hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr>), hgrid, dim3(512), 2 * 36864 + 3 * 16384, s, b);
+      PS_CHECK_LAUNCH("conv_igemm_halo");
+      return PS_OK;
+    }
     const int bm = v == PS_CONV_WS2_256 ? 256 : v == PS_CONV_WS2_224 ? 224 : v == PS_CONV_WS_128 ? 128 : 112;
     b.ntm = (a.M + bm - 1) / bm;
     const dim3 grid((unsigned)(b.ntm * b.ntn));
@@ -1234,6 +1496,7 @@ extern "C" void ps_debug_set_ablate(int v) { g_ablate = v; }
 extern "C" void ps_debug_set_pp(int v) { g_use_pp = v; }
 extern "C" void ps_debug_set_ws(int v) { g_use_ws = v; }
 extern "C" void ps_debug_set_ws2(int v) { g_use_ws2 = v; }
+extern "C" void ps_debug_set_halo(int v) { g_use_halo = v; }
 extern "C" void ps_debug_set_supertile(int v) { g_supertile = v; }
 
 extern "C" int ps_conv_supported(const ps_conv_geom* g) { return check_geom(g) == PS_OK ? 1 : 0; }
@@ -1243,7 +1506,9 @@ extern "C" int ps_conv_variant(const ps_conv_geom* g, int32_t dgrad) {
   const long long ho = (g->h - 1) / g->stride + 1, wo = (g->w - 1) / g->stride + 1;
   const long long M = dgrad ? (long long)g->n * g->h * g->w : (long long)g->n * ho * wo;
   if (g_use_3stage || g_use_pp) return PS_CONV_OTHER;
-  const int v = pick_ws_variant(M, dgrad ? g->cin : g->cout, ps_esize(g->dtype));
+  // both directions of a stride-1 3x3 layer gather on the input grid h x w
+  const bool halo_ok = g->ksize == 3 && g->stride == 1 && g->w == 28 && g->dilation <= 4;
+  const int v = pick_ws_variant(M, dgrad ? g->cin : g->cout, ps_esize(g->dtype), halo_ok);
   return v ? v : PS_CONV_4WAVE;
 }
 

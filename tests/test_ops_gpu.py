@@ -406,6 +406,7 @@ def test_conv_pipelined_kernels_are_bit_identical_to_two_stage(case, dtype):
         lib.ps_debug_set_pp(0)
         lib.ps_debug_set_ws(0)
         lib.ps_debug_set_ws2(0)
+        lib.ps_debug_set_halo(0)  # the halo kernel re-associates the K sum: covered by test_conv_halo_window_kernel
         ref = run()
         # (3stage, ping-pong, forced group height, wave-specialised, large-tile wave-specialised)
         for setup in ((1, 0, 0, 0, 0), (0, 2, 0, 0, 0), (0, 2, 112, 0, 0), (0, 2, 128, 0, 0), (0, 0, 0, 2, 0), (0, 0, 112, 2, 0), (0, 0, 128, 2, 0),
@@ -425,9 +426,63 @@ def test_conv_pipelined_kernels_are_bit_identical_to_two_stage(case, dtype):
         lib.ps_debug_set_bm(0)
         lib.ps_debug_set_ws(1)
         lib.ps_debug_set_ws2(WS2_DEFAULT)
+        lib.ps_debug_set_halo(1)
     cpu = F.conv2d(x[:1].permute(0, 3, 1, 2), wt, stride=s, padding=d if k == 3 else 0, dilation=d) + res[:1].float().cpu().permute(0, 3, 1, 2)
     tol = TOL[dtype]
     assert rel_err(ref[0][:1].float().cpu(), nhwc(cpu)) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [
+    # (n, h, w, cin, cout, d): 3x3 stride 1 on 28x28 maps: 224-pixel tiles are 8 rows and straddle images (784 = 3.5 tiles), the
+    # last tile is ragged for odd n; every dilation of the net; 1 .. 4 K-lines; 1 .. 3 cout tiles
+    (3, 28, 28, 128, 128, 1), (2, 28, 28, 64, 256, 2), (3, 28, 28, 256, 128, 4), (1, 28, 28, 128, 256, 4), (5, 28, 28, 64, 128, 1),
+    (7, 28, 28, 192, 384, 2),
+])
+def test_conv_halo_window_kernel(case, dtype):
+    """conv_igemm_halo_kernel (pixel window + halo staged once per tap row, K order (K-line, ty, tx)) forced on small problems:
+    forward with the full epilogue and the data gradient against the CPU, plus agreement with the gathered-tile kernels."""
+    from pistoseg_amd import _lib, ops
+
+    lib = _lib.load()
+    n, h, w, cin, cout, d = case
+    g = torch.Generator().manual_seed(h + cin + cout + d)
+    q = quant(dtype)
+    x = q(torch.randn(n, cin, h, w, generator=g)).requires_grad_(True)
+    wt = q(torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5)
+    y = F.conv2d(x, wt, padding=d, dilation=d)
+    res = q(torch.randn(y.shape, generator=g))
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    act = F.relu((y + res) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    gy = q(torch.randn(y.shape, generator=g))
+    y.backward(gy)
+    tol = TOL[dtype]
+    spec = ops.ConvSpec(cin, cout, 3, 1, d)
+    D = dev()
+    xd, wf, wd = nhwc(x.detach()).to(D, dtype), w_fwd_layout(wt).to(D, dtype), w_dgrad_layout(wt).to(D, dtype)
+    resd, gyd = nhwc(res).to(D, dtype), nhwc(gy).to(D, dtype)
+
+    def run():
+        out_raw = torch.full((n, h, w, cout), float("nan"), device=D, dtype=dtype)
+        out_act = torch.full((n, h, w, cout), float("nan"), device=D, dtype=dtype)
+        ops.conv2d_fwd(spec, xd, wf, add0=resd, out_raw=out_raw, bn_scale=scale.to(D), bn_shift=shift.to(D), out_act=out_act)
+        gx = torch.full((n, h, w, cin), float("nan"), device=D, dtype=dtype)
+        ops.conv2d_dgrad(spec, gyd, wd, (h, w), out_raw=gx)
+        return out_raw, out_act, gx
+
+    try:
+        lib.ps_debug_set_halo(2)
+        got = [run() for _ in range(2)]
+        lib.ps_debug_set_halo(0)
+        other = run()
+    finally:
+        lib.ps_debug_set_halo(1)
+    refs = (nhwc((y + res).detach()), nhwc(act.detach()), nhwc(x.grad))
+    for trial in got:
+        for a_, r_, o_ in zip(trial, refs, other):
+            assert rel_err(a_.float().cpu(), r_) < tol
+            assert rel_err(a_.float().cpu(), o_.float().cpu()) < max(tol, 1e-5)
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(got[0], got[1]))  # deterministic (race screen)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

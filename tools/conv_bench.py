@@ -56,6 +56,8 @@ def main():
                     lib.ps_debug_set_pp(0)
                     lib.ps_debug_set_ws(1)
                     lib.ps_debug_set_ws2(1)
+                    lib.ps_debug_set_halo(1)
+                    lib.ps_debug_set_ablate(0)
                     lib.ps_debug_set_wgrad_ws2(1)
                     lib.ps_debug_set_wgrad_ablate(0)
                     lib.ps_debug_set_wgrad_ovh(16)
@@ -82,6 +84,7 @@ def main():
     lib.ps_debug_set_pp(0)
     lib.ps_debug_set_ws(1)
     lib.ps_debug_set_ws2(1)
+    lib.ps_debug_set_halo(1)
     lib.ps_debug_set_wgrad_ws2(1)
     lib.ps_debug_set_wgrad_ablate(0)
     lib.ps_debug_set_wgrad_raster(-1)
