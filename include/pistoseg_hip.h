@@ -128,6 +128,11 @@ int ps_conv1a_fwd(int32_t out_dtype, const float* x_nchw, const float* w_oihw, c
  *   cam[m,c] = sum_k x[m,k] * (drop ? drop[n(m),k] : 1) * w[c,k]      cam: f32 [M, C] (pixel-major)   */
 int ps_fc8_fwd(int32_t dtype, const void* x, int32_t ldc_x, const float* w, const float* drop, float* cam, int32_t m_total,
                int32_t pix_per_image, int32_t k, int32_t c, void* stream);
+/* General narrow 1x1 head: cam[m, c] (=|+=) sum_k x[m, k] * drop[n, k] * w[c * ldw + k] + bias[c]  (bias / drop may be NULL).
+ * Lets a head over concatenated features run as one call per feature map without materialising the concat:
+ * replaces `fc_cam(torch.cat([conv4, conv5, conv6], dim=1))` (OEEM/classification/network/wide_resnet.py:166-186). */
+int ps_fc_head_fwd(int32_t dtype, const void* x, int32_t ldc_x, const float* w, int32_t ldw, const float* bias, const float* drop,
+                   float* cam, int32_t accumulate, int32_t m_total, int32_t ppi, int32_t k, int32_t c, void* stream);
 /* backward of ps_fc8_fwd fused with the ReLU(bn7) mask:  dx[m,k] = (x[m,k] > 0) * scale7[k] * drop * sum_c dcam[m,c] w[c,k]
  * (dx typed like x, written with stride ldc_dx), and dw[c,k] += sum_m dcam[m,c] * x[m,k]*drop (f32 atomics). */
 int ps_fc8_bwd(int32_t dtype, const void* x, int32_t ldc_x, const float* w, const float* drop, const float* scale7,
@@ -266,6 +271,50 @@ int ps_sgd_step(float* p, const float* g, float* buf, void* p_bf16, int64_t n, f
 /* Same, with the gradient multiplied by grad_inv_scale first and a 16-bit shadow of dtype shadow_dtype in {PS_BF16, PS_F16}. */
 int ps_sgd_step_scaled(float* p, const float* g, float* buf, void* p_shadow, int32_t shadow_dtype, int64_t n, float lr,
                        float momentum, float weight_decay, int32_t first_step, float grad_inv_scale, void* stream);
+
+/* ---- sliding-window evaluation ------------------------------------------------------------------ */
+/* Where one tile of a batch lands: its valid (un-padded) region [0, vh) x [0, vw) is added at (y0, x0) of a per-image f64 canvas.
+ * canvas: [canvas_h, canvas_w, C] if channels_last (models/segmentation_module.py:156: np.zeros((h_, w_, 3))) else
+ * [C, canvas_h, canvas_w] (OEEM/classification/prepare_seg_inputs.py:121: np.zeros((num_of_class, w_, h_))); count: [canvas_h, canvas_w].
+ * An array of these lives in DEVICE memory. */
+typedef struct ps_tile_dst {
+  double* canvas;
+  double* count;
+  int32_t canvas_h, canvas_w;
+  int32_t y0, x0, vh, vw;
+  int32_t channels_last, _pad;
+} ps_tile_dst;
+
+/* For every tile j < n: p = apply_softmax ? softmax_C(scores[j]) : scores[j] (f32, [n, C, h, w]);
+ * canvas_j[y0 + y, x0 + x, :] += p[:, y, x] and count_j[y0 + y, x0 + x] += 1 for y < vh, x < vw (f64 atomics: tiles of one launch may overlap).
+ * replaces: the per-sample loop `probs = torch.softmax(output_, dim=0).cpu().numpy(); pred_big_mask_dict_ms[key][...] += probs;
+ * cnt_big_mask_dict_ms[key][...] += 1` (models/segmentation_module.py:141-161, segmentation_test.py:141-183) and
+ * `sum_cam[:, y:y+side, x:x+side] += crop; sum_counter[...] += 1` (prepare_seg_inputs.py:124-130).  The caller checks bounds. */
+int ps_softmax_scatter_accum(const float* scores, int32_t n, int32_t c, int32_t h, int32_t w, const ps_tile_dst* tiles_dev,
+                             int32_t apply_softmax, void* stream);
+
+/* dst (=|+=) bilinear_{align_corners=False}(src / d) in f64, d = src_count (per pixel) or the scalar src_div when src_count is NULL;
+ * zero_uncovered: counts < 1 become 1 (prepare_seg_inputs.py:131), otherwise 0/0 = NaN as in numpy; dst_count (optional) (=|+=) 1.
+ * replaces: `mask /= cnt; mask = F.interpolate(torch.from_numpy(mask...), (h, w), mode='bilinear'); pred_big_mask_dict[idx] += mask;
+ * cnt_big_mask_dict[idx] += 1` (segmentation_module.py:166-178) and the three F.interpolate calls of prepare_seg_inputs.py:133-138. */
+int ps_canvas_resize_accum(const double* src, const double* src_count, double src_div, int32_t hs, int32_t ws, double* dst,
+                           double* dst_count, int32_t hd, int32_t wd, int32_t c, int32_t channels_last, int32_t zero_uncovered,
+                           int32_t accumulate, void* stream);
+
+/* pred[y, x] = argmax_C(canvas / count) (first maximum; NaN is the maximum, as torch.argmax), then pred = bg_value where
+ * gt == bg_value (gt may be NULL / bg_value < 0: no overwrite).
+ * replaces: `mask_pred /= cnt; big_mask_iou(torch.from_numpy(mask_pred...), ..., probs=True)` (segmentation_module.py:181-185,
+ * loss.py:55-57) and `mask_pred[mask == 3] = 3` (segmentation_test.py:201). */
+int ps_canvas_argmax(const double* canvas, const double* count, int32_t h, int32_t w, int32_t c, int32_t channels_last,
+                     const uint8_t* gt, int32_t bg_value, uint8_t* pred, void* stream);
+
+/* One view of the d4 group on `planes` square side x side f32 planes: forward dst = rot90(hflip ? flip_W(src) : src, k);
+ * inverse dst (=|+=) (hflip ? flip_W : id)(rot90(src, 4 - k)).  replaces: ttach d4_transform()'s augment_image / deaugment_mask
+ * (tta.SegmentationTTAWrapper, infer_pseudo_masks.py:96, mosaic_module.py:76; third-party ttach==0.0.3: parity unpinned). */
+int ps_d4_view(const float* src, float* dst, int64_t planes, int32_t side, int32_t hflip, int32_t k, int32_t inverse,
+               int32_t accumulate, void* stream);
+/* x /= divisor (the 'mean' merge of the eight views). */
+int ps_scale_inplace(float* x, int64_t n, float divisor, void* stream);
 
 /* *count += number of inf/nan elements of g[0..n) (caller zeroes count).  Used by fp16 dynamic loss scaling: an overflowed
  * activation gradient reaches the f32 gradient arena as inf/nan, and the step is then skipped. */

@@ -205,14 +205,14 @@ def _bot_unit(sd, name, cin, cout, stride, dil, x, drop1, drop2, collect=None):
     return shortcut + h, a
 
 
-def forward_as_dict(sd: Dict[str, Tensor], x: Tensor, drop: Optional[Dict[str, Tensor]] = None, collect=None) -> Dict[str, Tensor]:
+def forward_as_dict(sd: Dict[str, Tensor], x: Tensor, drop: Optional[Dict[str, Tensor]] = None, collect=None, blocks=None) -> Dict[str, Tensor]:
     """Net.forward_as_dict, resnet38d.py:159-188.  `drop` maps
     {'b6.dropout_2b1','b6.dropout_2b2','b7.dropout_2b1','b7.dropout_2b2'} -> [N, C] multipliers.
     `collect` (optional dict) receives every unit's post-ReLU activations (for ReLU-pattern checks in tests)."""
     drop = drop or {}
     out: Dict[str, Tensor] = {}
     x = F.conv2d(x, sd["conv1a.weight"], padding=1)
-    for name, kind, cin, cmid, cout, stride, fdil, dil, _p in BLOCKS:
+    for name, kind, cin, cmid, cout, stride, fdil, dil, _p in (BLOCKS if blocks is None else blocks):
         if kind == "res":
             x, a = _res_unit(sd, name, cin, cmid, cout, stride, fdil, dil, x, collect)
         else:
@@ -494,3 +494,151 @@ def trainable_keys(sd: Dict[str, Tensor], not_training: Sequence[str] = RFM_NOT_
             continue
         keys.append(k)
     return keys
+
+
+# --------------------------------------------------------------------------------------
+# Sliding-window evaluation.  These restate host-side numpy / torch-builtin code of the
+# reference statement by statement; the arithmetic is numpy float64 adds/divides, torch.softmax and F.interpolate
+# (builtins: the same functions on both sides), so the restatement is pinned by construction (as for CE).
+# --------------------------------------------------------------------------------------
+def sliding_window_big_masks(batches, image_sizes: Dict[str, Tuple[int, int]], num_classes: int = 3):
+    """models/segmentation_module.py:127-178 (== segmentation_test.py:141-196): `batches` yields
+    (logits [N,C,S,S] f32, names, original_h, original_w); image_sizes[image_idx] = (w, h) (PIL's Image.size).
+    Returns {image_idx: (pred_big_mask [h,w,C] f64 -- the SUM over scales --, cnt_big_mask [h,w,1])}."""
+    pred_ms: Dict[str, np.ndarray] = {}
+    cnt_ms: Dict[str, np.ndarray] = {}
+    for output, name_batch, original_h_batch, original_w_batch in batches:
+        for j in range(output.shape[0]):
+            original_w, original_h = int(original_w_batch[j]), int(original_h_batch[j])
+            output_ = output[j][:, :original_h, :original_w]
+            probs = torch.softmax(output_, dim=0).numpy().transpose(1, 2, 0)
+            name = name_batch[j]
+            image_idx = name.split("_")[0]
+            scale = float(name.split("_")[1])
+            position = (int(name.split("_")[2]), int(name.split("_")[3].split("-")[0]))
+            dict_key = f"{image_idx}_{scale}"
+            if dict_key not in pred_ms:
+                w, h = image_sizes[image_idx]
+                w_, h_ = int(w * scale), int(h * scale)
+                pred_ms[dict_key] = np.zeros((h_, w_, num_classes))
+                cnt_ms[dict_key] = np.zeros((h_, w_, 1))
+            pred_ms[dict_key][position[0]:position[0] + output_.shape[1], position[1]:position[1] + output_.shape[2], :] += probs
+            cnt_ms[dict_key][position[0]:position[0] + output_.shape[1], position[1]:position[1] + output_.shape[2], :] += 1
+    pred_big: Dict[str, np.ndarray] = {}
+    cnt_big: Dict[str, np.ndarray] = {}
+    for k, mask in pred_ms.items():
+        with np.errstate(divide="ignore", invalid="ignore"):
+            mask = mask / cnt_ms[k]
+        image_idx = k.split("_")[0]
+        w, h = image_sizes[image_idx]
+        if image_idx not in pred_big:
+            pred_big[image_idx] = np.zeros((h, w, num_classes))
+            cnt_big[image_idx] = np.zeros((h, w, 1))
+        mask = F.interpolate(torch.from_numpy(mask.transpose(2, 0, 1)).unsqueeze(0), (h, w), mode="bilinear")[0].numpy().transpose(1, 2, 0)
+        pred_big[image_idx][:, :, :] += mask
+        cnt_big[image_idx][:, :, :] += 1
+    return {k: (pred_big[k], cnt_big[k]) for k in pred_big}
+
+
+def big_mask_predictions(big: Dict[str, Tuple[np.ndarray, np.ndarray]], gt: Optional[Dict[str, np.ndarray]] = None, bg_value: int = -1):
+    """segmentation_module.py:180-185 + loss.py:55-57 (probs=True): mask_pred /= cnt; argmax over classes (uint8);
+    with gt: `mask_pred[mask == 3] = 3` (segmentation_test.py:199-201)."""
+    out = {}
+    for k, (pred, cnt) in big.items():
+        with np.errstate(divide="ignore", invalid="ignore"):
+            p = pred / cnt
+        m = torch.argmax(torch.from_numpy(p.transpose(2, 0, 1)).unsqueeze(0), dim=1).byte()[0].numpy()
+        if gt is not None and bg_value >= 0:
+            m = m.copy()
+            m[gt[k] == bg_value] = bg_value
+        out[k] = m
+    return out
+
+
+def multi_scale_cam(cam_crops_per_scale, positions_per_scale, scaled_sizes, image_wh: Tuple[int, int], num_of_class: int, side_length: int):
+    """OEEM/classification/prepare_seg_inputs.py:96-138 for one image, starting from the per-crop CAM scores that
+    `F.interpolate(cam_scores, (interpolatex, interpolatey))` produced (:117): sum_cam / sum_counter per scale, resize to (w, h),
+    mean over scales, resize to 32 x 32.  image_wh = (w, h) in the reference's naming (orig_img.shape[:2])."""
+    w, h = image_wh
+    ensemble_cam = np.zeros((num_of_class, w, h))
+    for cam_list, position_list, (w_, h_) in zip(cam_crops_per_scale, positions_per_scale, scaled_sizes):
+        cam_list = cam_list.numpy()
+        sum_cam = np.zeros((num_of_class, w_, h_))
+        sum_counter = np.zeros_like(sum_cam)
+        for k in range(cam_list.shape[0]):
+            y, x = position_list[k][0], position_list[k][1]
+            crop = cam_list[k]
+            sum_cam[:, y:y + side_length, x:x + side_length] += crop
+            sum_counter[:, y:y + side_length, x:x + side_length] += 1
+        sum_counter[sum_counter < 1] = 1
+        norm_cam = sum_cam / sum_counter
+        norm_cam = F.interpolate(torch.unsqueeze(torch.tensor(norm_cam), 0), (w, h), mode="bilinear", align_corners=False).numpy()[0]
+        ensemble_cam += norm_cam
+    ensemble_cam /= len(scaled_sizes)
+    return F.interpolate(torch.unsqueeze(torch.tensor(ensemble_cam), 0), (32, 32), mode="bilinear", align_corners=False).numpy()[0]
+
+
+def d4_tta(model_fn, image: Tensor) -> Tensor:
+    """ttach.SegmentationTTAWrapper(model, d4_transform(), merge_mode='mean') (infer_pseudo_masks.py:96) restated from the
+    package's public definition -- third-party ttach==0.0.3, absent here: PARITY UNPINNED.
+    d4_transform = Compose([HorizontalFlip(), Rotate90(angles=[0, 90, 180, 270])]); views in itertools.product order."""
+    import itertools
+
+    total = None
+    for hflip, angle in itertools.product([False, True], [0, 90, 180, 270]):
+        x = image.flip(3) if hflip else image                 # HorizontalFlip.apply_aug_image
+        x = torch.rot90(x, angle // 90, (2, 3))               # Rotate90.apply_aug_image
+        y = model_fn(x)
+        y = torch.rot90(y, ((-angle) % 360) // 90, (2, 3))    # deaugment in reverse order: Rotate90.apply_deaug_mask(-angle) ...
+        y = y.flip(3) if hflip else y                         # ... then HorizontalFlip.apply_deaug_mask
+        total = y if total is None else total + y             # Merger('mean').append
+    return total / 8                                          # Merger.result
+
+
+# --------------------------------------------------------------------------------------
+# OEEM stage 0 (SURVEY.md 8f row 4): OEEM/classification/network/wide_resnet.py -- the same ResNet38-d with b7 dilated by 2
+# (:129) and two heads over cat[conv4, conv5, conv6] (5632 channels, :166-186).  Pinned by tests/golden/oeem_cam.npz, minted
+# by oracle/make_golden_oeem.py from the reference's own Net.forward_cam.
+# --------------------------------------------------------------------------------------
+WIDE_BLOCKS = [b if b[0] != "b7" else ("b7", "bot", 2048, 1024, 4096, 1, 2, 2, 0.5) for b in BLOCKS]
+
+
+def wide_state_dict(num_class: int = 3, seed: int = 42) -> Dict[str, Tensor]:
+    """Backbone weights of make_state_dict + fc_cls / fc_cam, in the reference's key order (wide_resnet.py:131-139)."""
+    sd = make_state_dict(num_classes=None, rfm_heads=False, seed=seed)
+    for key, shape in (("fc_cls.weight", (num_class, 5632)), ("fc_cls.bias", (num_class,)), ("fc_cam.weight", (num_class, 5632, 1, 1)),
+                       ("fc_cam.bias", (num_class,))):
+        rs = np.random.RandomState((zlib.crc32(key.encode()) ^ seed) & 0x7FFFFFFF)
+        scale = math.sqrt(1.0 / 5632) if key.endswith("weight") else 0.1
+        sd[key] = torch.from_numpy(rs.standard_normal(shape).astype(np.float32) * np.float32(scale))
+    return sd
+
+
+def wide_features(sd: Dict[str, Tensor], x: Tensor) -> Tensor:
+    """Net._shared_forward, wide_resnet.py:143-172."""
+    d = forward_as_dict(sd, x, blocks=WIDE_BLOCKS)
+    return torch.cat([d["conv4"], d["conv5"], d["conv6"]], dim=1)
+
+
+def wide_forward_cam(sd: Dict[str, Tensor], x: Tensor) -> Tensor:
+    """Net.forward_cam, wide_resnet.py:182-186."""
+    return F.conv2d(wide_features(sd, x), sd["fc_cam.weight"], sd["fc_cam.bias"])
+
+
+def wide_forward_cls(sd: Dict[str, Tensor], x: Tensor) -> Tensor:
+    """Net.forward, wide_resnet.py:174-180."""
+    f = F.adaptive_avg_pool2d(wide_features(sd, x), (1, 1)).flatten(1)
+    return F.linear(f, sd["fc_cls.weight"], sd["fc_cls.bias"])
+
+
+def image_cam_32x32(sd, scaled_im_list, scaled_position_list, scales, image_wh, side_length: int, num_of_class: int):
+    """prepare_seg_inputs.py:96-138 for one image, model included (forward_cam -> F.interpolate to the crop size -> multi_scale_cam)."""
+    w, h = image_wh
+    crops, sizes = [], []
+    for s in range(len(scales)):
+        w_, h_ = int(w * scales[s]), int(h * scales[s])
+        ix, iy = min(side_length, w_), min(side_length, h_)
+        cam_scores = wide_forward_cam(sd, scaled_im_list[s])
+        crops.append(F.interpolate(cam_scores, (ix, iy), mode="bilinear", align_corners=False))
+        sizes.append((w_, h_))
+    return multi_scale_cam(crops, scaled_position_list, sizes, (w, h), num_of_class, side_length)

@@ -45,6 +45,13 @@ class Epilogue(C.Structure):
     ]
 
 
+class TileDst(C.Structure):
+    _fields_ = [
+        ("canvas", C.c_void_p), ("count", C.c_void_p), ("canvas_h", C.c_int32), ("canvas_w", C.c_int32),
+        ("y0", C.c_int32), ("x0", C.c_int32), ("vh", C.c_int32), ("vw", C.c_int32), ("channels_last", C.c_int32), ("_pad", C.c_int32),
+    ]
+
+
 class Tensor4(C.Structure):
     _fields_ = [
         ("ptr", C.c_void_p), ("dtype", C.c_int32), ("n", C.c_int32), ("c", C.c_int32), ("h", C.c_int32),
@@ -56,6 +63,7 @@ _P = C.c_void_p
 _I = C.c_int32
 _L = C.c_int64
 _F = C.c_float
+_D = C.c_double
 
 # name -> (restype, argtypes); every symbol include/pistoseg_hip.h declares
 PROTOTYPES = {
@@ -72,6 +80,7 @@ PROTOTYPES = {
     "ps_cast_f32_lowp": (C.c_int, [_P, _P, _I, _L, _P]),
     "ps_conv1a_fwd": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ps_fc8_fwd": (C.c_int, [_I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ps_fc_head_fwd": (C.c_int, [_I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ps_fc8_bwd": (C.c_int, [_I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "ps_bilinear_fwd": (C.c_int, [C.POINTER(Tensor4), C.POINTER(Tensor4), _I, _P]),
     "ps_bilinear_bwd": (C.c_int, [C.POINTER(Tensor4), C.POINTER(Tensor4), _I, _P]),
@@ -85,6 +94,11 @@ PROTOTYPES = {
     "ps_sgd_step": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _I, _P]),
     "ps_adamw_step_scaled": (C.c_int, [_P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
     "ps_sgd_step_scaled": (C.c_int, [_P, _P, _P, _P, _I, _L, _F, _F, _F, _I, _F, _P]),
+    "ps_softmax_scatter_accum": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _P]),
+    "ps_canvas_resize_accum": (C.c_int, [_P, _P, _D, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "ps_canvas_argmax": (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "ps_d4_view": (C.c_int, [_P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "ps_scale_inplace": (C.c_int, [_P, _L, _F, _P]),
     "ps_nonfinite_count": (C.c_int, [_P, _L, _P, _P]),
     "ps_debug_set_glds": (None, [C.c_int]),
     "ps_debug_set_3stage": (None, [C.c_int]),

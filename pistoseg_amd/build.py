@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpistoseg_hip.so")
-SOURCES = ["api.cpp", "conv_igemm.hip", "conv_wgrad.hip", "small_ops.hip", "pixel_ops.hip", "rfm_ops.hip"]
+SOURCES = ["api.cpp", "conv_igemm.hip", "conv_wgrad.hip", "small_ops.hip", "pixel_ops.hip", "rfm_ops.hip", "sliding_ops.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 

@@ -85,9 +85,9 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const float* __restrict__ x
 // ------------------------------------------------------------------------------------------------
 constexpr int FC8_MAXC = 8;
 template <typename T>
-__global__ __launch_bounds__(256) void fc8_fwd_kernel(const T* __restrict__ x, int ldc, const float* __restrict__ w,
-                                                      const float* __restrict__ drop, float* __restrict__ cam, int M, int ppi,
-                                                      int K, int C) {
+__global__ __launch_bounds__(256) void fc8_fwd_kernel(const T* __restrict__ x, int ldc, const float* __restrict__ w, int ldw,
+                                                      const float* __restrict__ bias, const float* __restrict__ drop,
+                                                      float* __restrict__ cam, int accumulate, int M, int ppi, int K, int C) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m0 = (blockIdx.x * 4 + wave) * 8;
   if (m0 >= M) return;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void fc8_fwd_kernel(const T* __restrict__ x, i
     float wv[FC8_MAXC][8];
 #pragma unroll
     for (int c = 0; c < FC8_MAXC; ++c) {
-      if (c < C) ps_load8<float>(w + (long long)c * K + k0, wv[c]);
+      if (c < C) ps_load8<float>(w + (long long)c * ldw + k0, wv[c]);
     }
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
@@ -129,7 +129,10 @@ __global__ __launch_bounds__(256) void fc8_fwd_kernel(const T* __restrict__ x, i
     for (int c = 0; c < FC8_MAXC; ++c) {
       if (c < C) {
         const float s = ps_wave_sum(acc[p][c]);
-        if (lane == 0 && m0 + p < M) cam[(long long)(m0 + p) * C + c] = s;
+        if (lane == 0 && m0 + p < M) {
+          float* o = cam + (long long)(m0 + p) * C + c;
+          *o = (accumulate ? *o : 0.f) + s + (bias ? bias[c] : 0.f);
+        }
       }
     }
   }
@@ -363,24 +366,30 @@ extern "C" int ps_conv1a_fwd(int32_t out_dtype, const float* x, const float* w, 
   return PS_OK;
 }
 
-extern "C" int ps_fc8_fwd(int32_t dtype, const void* x, int32_t ldc_x, const float* w, const float* drop, float* cam,
-                          int32_t m_total, int32_t ppi, int32_t k, int32_t c, void* stream) {
-  PS_REQUIRE(x && w && cam, "fc8_fwd: null argument");
-  PS_REQUIRE(c >= 1 && c <= FC8_MAXC, "fc8_fwd: C=%d unsupported (1..%d)", c, FC8_MAXC);
-  PS_REQUIRE(k % 512 == 0 && m_total > 0 && ppi > 0, "fc8_fwd: K=%d must be a multiple of 512", k);
-  PS_REQUIRE(ps_aligned16(x) && ps_aligned16(w) && (ldc_x * ps_esize(dtype)) % 16 == 0, "fc8_fwd: misaligned input");
+extern "C" int ps_fc_head_fwd(int32_t dtype, const void* x, int32_t ldc_x, const float* w, int32_t ldw, const float* bias, const float* drop,
+                              float* cam, int32_t accumulate, int32_t m_total, int32_t ppi, int32_t k, int32_t c, void* stream) {
+  PS_REQUIRE(x && w && cam, "fc_head_fwd: null argument");
+  PS_REQUIRE(c >= 1 && c <= FC8_MAXC, "fc_head_fwd: C=%d unsupported (1..%d)", c, FC8_MAXC);
+  PS_REQUIRE(k % 512 == 0 && m_total > 0 && ppi > 0, "fc_head_fwd: K=%d must be a multiple of 512", k);
+  PS_REQUIRE(ldw >= k && ldw % 4 == 0, "fc_head_fwd: weight row stride %d must be >= K and a multiple of 4", ldw);
+  PS_REQUIRE(ps_aligned16(x) && ps_aligned16(w) && (ldc_x * ps_esize(dtype)) % 16 == 0, "fc_head_fwd: misaligned input");
   const int grid = (m_total + 31) / 32;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == PS_BF16)
-    hipLaunchKernelGGL(fc8_fwd_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, ldc_x, w, drop, cam, m_total, ppi, k, c);
+    hipLaunchKernelGGL(fc8_fwd_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, ldc_x, w, ldw, bias, drop, cam, accumulate, m_total, ppi, k, c);
   else if (dtype == PS_F16)
-    hipLaunchKernelGGL(fc8_fwd_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)x, ldc_x, w, drop, cam, m_total, ppi, k, c);
+    hipLaunchKernelGGL(fc8_fwd_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)x, ldc_x, w, ldw, bias, drop, cam, accumulate, m_total, ppi, k, c);
   else if (dtype == PS_F32)
-    hipLaunchKernelGGL(fc8_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ldc_x, w, drop, cam, m_total, ppi, k, c);
+    hipLaunchKernelGGL(fc8_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ldc_x, w, ldw, bias, drop, cam, accumulate, m_total, ppi, k, c);
   else
-    PS_REQUIRE(false, "fc8_fwd: dtype %d unsupported", dtype);
-  PS_CHECK_LAUNCH("fc8_fwd");
+    PS_REQUIRE(false, "fc_head_fwd: dtype %d unsupported", dtype);
+  PS_CHECK_LAUNCH("fc_head_fwd");
   return PS_OK;
+}
+
+extern "C" int ps_fc8_fwd(int32_t dtype, const void* x, int32_t ldc_x, const float* w, const float* drop, float* cam,
+                          int32_t m_total, int32_t ppi, int32_t k, int32_t c, void* stream) {
+  return ps_fc_head_fwd(dtype, x, ldc_x, w, k, nullptr, drop, cam, 0, m_total, ppi, k, c, stream);
 }
 
 extern "C" int ps_fc8_bwd(int32_t dtype, const void* x, int32_t ldc_x, const float* w, const float* drop, const float* scale7,

@@ -33,10 +33,15 @@ def get_mask_pred_and_entropy(logits: Tensor, tissue: Optional[Tensor], patch_la
 
 @torch.no_grad()
 def infer_pseudo_masks(model, images: Tensor, patch_label: Tensor, tissue: Optional[Tensor] = None, batch_size: int = 64,
-                       rank: int = 0, world: int = 1):
+                       rank: int = 0, world: int = 1, tta: bool = False):
     """Stage 2 over this rank's contiguous shard of `images` ([T,3,H,W], host or device).  Returns
-    (lo, hi, logits_32x32 [t,C,32,32], mask uint8 [t,H,W], entropy [t,H,W])."""
+    (lo, hi, logits_32x32 [t,C,32,32], mask uint8 [t,H,W], entropy [t,H,W]).  tta=True wraps the model in the d4
+    test-time augmentation exactly where the reference does (infer_pseudo_masks.py:96)."""
     dev = next(model.parameters()).device
+    if tta:
+        from .tta import SegmentationTTAWrapper
+
+        model = SegmentationTTAWrapper(model, merge_mode="mean")
     lo, hi = shard_range(images.shape[0], rank, world)
     small, masks, ents = [], [], []
     model.eval()

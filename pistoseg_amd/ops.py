@@ -210,6 +210,17 @@ def fc8_fwd(x: Tensor, w: Tensor, drop: Optional[Tensor], cam: Tensor) -> None:
     _lib.check(lib.ps_fc8_fwd(_dt(x), x.data_ptr(), _ldc(x), w.data_ptr(), _ptr(drop), cam.data_ptr(), n * h * wd, h * wd, k, c, _stream()), "ps_fc8_fwd")
 
 
+def fc_head_fwd(x: Tensor, w: Tensor, ldw: int, bias: Optional[Tensor], drop: Optional[Tensor], cam: Tensor, accumulate: bool) -> None:
+    """cam[N,g,g,C] (f32) (=|+=) x @ w[:, :K]^T + bias; w: f32 view whose rows are ldw floats apart (a column slice of a wider head)."""
+    _require_gpu(x, w, cam)
+    n, h, wd, k = x.shape
+    c = cam.shape[3]
+    assert w.dtype == torch.float32 and cam.dtype == torch.float32 and cam.is_contiguous() and tuple(cam.shape) == (n, h, wd, c)
+    lib = _lib.load()
+    _lib.check(lib.ps_fc_head_fwd(_dt(x), x.data_ptr(), _ldc(x), w.data_ptr(), int(ldw), _ptr(bias), _ptr(drop), cam.data_ptr(), int(accumulate),
+                                  n * h * wd, h * wd, k, c, _stream()), "ps_fc_head_fwd")
+
+
 def fc8_bwd(x: Tensor, w: Tensor, drop: Optional[Tensor], scale7: Tensor, dcam: Tensor, dx: Tensor, dw: Tensor) -> None:
     _require_gpu(x, w, dcam, dx, dw)
     n, h, wd, k = x.shape
@@ -472,3 +483,66 @@ def minpool_bwd(m, arg, label, thr, take, dx, grad_scale: float) -> None:
     lib = _lib.load()
     _lib.check(lib.ps_minpool_bwd(m.data_ptr(), arg.data_ptr(), label.data_ptr(), thr.data_ptr(), take.data_ptr(), counter.data_ptr(), dx.data_ptr(),
                                   grad_scale, n, c, h, w, _stream()), "ps_minpool_bwd")
+
+
+# ---------------------------------------------------------------------------------------------------
+# sliding-window evaluation + d4 test-time augmentation (csrc/sliding_ops.hip)
+# ---------------------------------------------------------------------------------------------------
+def softmax_scatter_accum(scores: Tensor, tiles_dev: Tensor, apply_softmax: bool) -> None:
+    """scores [N,C,H,W] f32; tiles_dev: uint8 device tensor holding N packed `_lib.TileDst` records."""
+    _require_gpu(scores, tiles_dev)
+    n, c, h, w = scores.shape
+    assert scores.is_contiguous() and scores.dtype == torch.float32
+    assert tiles_dev.dtype == torch.uint8 and tiles_dev.numel() == n * C.sizeof(_lib.TileDst)
+    lib = _lib.load()
+    _lib.check(lib.ps_softmax_scatter_accum(scores.data_ptr(), n, c, h, w, tiles_dev.data_ptr(), int(apply_softmax), _stream()),
+               "ps_softmax_scatter_accum")
+
+
+def canvas_resize_accum(src: Tensor, src_count: Optional[Tensor], src_div: float, dst: Tensor, dst_count: Optional[Tensor], channels_last: bool,
+                        zero_uncovered: bool, accumulate: bool) -> None:
+    """f64 canvases [H,W,C] (channels_last) or [C,H,W]; dst (=|+=) bilinear(src / count-or-div), align_corners=False."""
+    _require_gpu(src, dst)
+    assert src.dtype == torch.float64 and dst.dtype == torch.float64 and src.is_contiguous() and dst.is_contiguous()
+    if channels_last:
+        (hs, ws, c), (hd, wd, c2) = src.shape, dst.shape
+    else:
+        (c, hs, ws), (c2, hd, wd) = src.shape, dst.shape
+    assert c == c2
+    lib = _lib.load()
+    _lib.check(lib.ps_canvas_resize_accum(src.data_ptr(), _ptr(src_count), float(src_div), hs, ws, dst.data_ptr(), _ptr(dst_count), hd, wd, c,
+                                          int(channels_last), int(zero_uncovered), int(accumulate), _stream()), "ps_canvas_resize_accum")
+
+
+def canvas_argmax(canvas: Tensor, count: Optional[Tensor], channels_last: bool, gt: Optional[Tensor] = None, bg_value: int = -1) -> Tensor:
+    _require_gpu(canvas)
+    assert canvas.dtype == torch.float64 and canvas.is_contiguous()
+    if channels_last:
+        h, w, c = canvas.shape
+    else:
+        c, h, w = canvas.shape
+    if gt is not None:
+        assert gt.dtype == torch.uint8 and gt.is_contiguous() and tuple(gt.shape) == (h, w)
+    pred = torch.empty((h, w), device=canvas.device, dtype=torch.uint8)
+    lib = _lib.load()
+    _lib.check(lib.ps_canvas_argmax(canvas.data_ptr(), _ptr(count), h, w, c, int(channels_last), _ptr(gt), int(bg_value), pred.data_ptr(), _stream()),
+               "ps_canvas_argmax")
+    return pred
+
+
+def d4_view(src: Tensor, dst: Tensor, hflip: bool, k: int, inverse: bool, accumulate: bool) -> None:
+    """src/dst: [..., S, S] f32 contiguous, same shape."""
+    _require_gpu(src, dst)
+    assert src.dtype == torch.float32 and dst.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous()
+    assert src.shape == dst.shape and src.shape[-1] == src.shape[-2], "d4 views need square tiles"
+    s = src.shape[-1]
+    lib = _lib.load()
+    _lib.check(lib.ps_d4_view(src.data_ptr(), dst.data_ptr(), src.numel() // (s * s), s, int(hflip), int(k), int(inverse), int(accumulate), _stream()),
+               "ps_d4_view")
+
+
+def scale_inplace_(x: Tensor, divisor: float) -> None:
+    _require_gpu(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    lib = _lib.load()
+    _lib.check(lib.ps_scale_inplace(x.data_ptr(), x.numel(), float(divisor), _stream()), "ps_scale_inplace")

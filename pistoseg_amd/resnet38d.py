@@ -101,12 +101,13 @@ class _Saved:
 class Net(nn.Module):
     """Drop-in for the reference's `models.resnet38d.Net` (same constructor, keys and methods)."""
 
-    def __init__(self, precision: str = "bf16"):
+    def __init__(self, precision: str = "bf16", units=None):
         super().__init__()
         assert precision in ("bf16", "fp16", "fp32")
         self.precision = precision
+        self.units = list(UNITS if units is None else units)  # the OEEM stage-0 net differs in b7's dilation only (oeem.py)
         self.conv1a = nn.Conv2d(3, 64, 3, padding=1, bias=False)
-        for name, kind, cin, cmid, cout, stride, fdil, dil, p in UNITS:
+        for name, kind, cin, cmid, cout, stride, fdil, dil, p in self.units:
             if kind == "res":
                 unit = ResBlock(cin, cmid, cout, stride=stride, first_dilation=fdil, dilation=dil)
             else:
@@ -213,7 +214,7 @@ class Net(nn.Module):
     def sample_dropout(self, n: int, device) -> Dict[str, Tensor]:
         """Per-(sample, channel) Dropout2d multipliers for a training forward (resnet38d.py:63,67,85,90)."""
         out = {}
-        for name, kind, cin, cmid, cout, stride, fdil, dil, p in UNITS:
+        for name, kind, cin, cmid, cout, stride, fdil, dil, p in self.units:
             if kind != "bot":
                 continue
             for tag, c in (("dropout_2b1", cout // 4), ("dropout_2b2", cout // 2)):
@@ -251,18 +252,18 @@ class Net(nn.Module):
         def new(hh, ww, c):
             return torch.empty((n, hh, ww, c), device=dev, dtype=dt)
 
-        first = getattr(self, UNITS[0][0])
-        sc0, sh0 = self.bn_affine(first.bn_branch2a, UNITS[0][0] + ".bn_branch2a")
+        first = getattr(self, self.units[0][0])
+        sc0, sh0 = self.bn_affine(first.bn_branch2a, self.units[0][0] + ".bn_branch2a")
         a = new(h, w, 64)
         ops.conv1a_fwd(x, self.conv1a.weight.detach().contiguous(), sc0, sh0, a)
         xraw = None
-        for i, (name, kind, cin, cmid, cout, stride, fdil, dil, _p) in enumerate(UNITS):
+        for i, (name, kind, cin, cmid, cout, stride, fdil, dil, _p) in enumerate(self.units):
             unit = getattr(self, name)
             specs = self.unit_specs(name, kind, cin, cmid, cout, stride, fdil, dil)
-            if i + 1 < len(UNITS):
-                nxt_name, nxt = UNITS[i + 1][0], getattr(self, UNITS[i + 1][0])
+            if i + 1 < len(self.units):
+                nxt_name, nxt = self.units[i + 1][0], getattr(self, self.units[i + 1][0])
                 nscale, nshift = self.bn_affine(nxt.bn_branch2a, nxt_name + ".bn_branch2a")
-                need_raw = UNITS[i + 1][1] == "res" and nxt.same_shape
+                need_raw = self.units[i + 1][1] == "res" and nxt.same_shape
             else:
                 nscale, nshift = self.bn_affine(self.bn7, "bn7")
                 need_raw = False
@@ -310,11 +311,11 @@ class Net(nn.Module):
 
     # ------------------------------------------------------------------ backward plan
     def first_trainable_unit(self) -> int:
-        for i, u in enumerate(UNITS):
+        for i, u in enumerate(self.units):
             unit = getattr(self, u[0])
             if any(p.requires_grad for p in unit.parameters()):
                 return i
-        return len(UNITS)
+        return len(self.units)
 
     def backward_backbone(self, saved: _Saved, g_x7: Tensor, grads: Dict[str, Tensor], g_taps: Optional[Dict[str, Tensor]] = None,
                           after_unit=None) -> None:
@@ -326,8 +327,8 @@ class Net(nn.Module):
         first = self.first_trainable_unit()
         G = g_x7
         dt, dev, n = G.dtype, G.device, saved.n
-        for i in range(len(UNITS) - 1, -1, -1):
-            name, kind, cin, cmid, cout, stride, fdil, dil, _p = UNITS[i]
+        for i in range(len(self.units) - 1, -1, -1):
+            name, kind, cin, cmid, cout, stride, fdil, dil, _p = self.units[i]
             if i < first:
                 break
             unit = getattr(self, name)

@@ -14,10 +14,15 @@ import torch
 from torch.optim import AdamW
 from torch.optim.lr_scheduler import ExponentialLR
 
+import os
+from functools import partial
+
 from . import ops
 from .lightning_shim import LightningModule
 from .metrics import mIoUMask
 from .seg_model import create_model
+from .sliding import SlidingWindowAccumulator
+from .tta import SegmentationTTAWrapper
 
 
 class _PixelLoss(torch.autograd.Function):
@@ -56,7 +61,68 @@ class _Shell(LightningModule):
         self.test_iou = mIoUMask(num_classes=args.num_classes)
         self.model = create_model(args.model, encoder_name=getattr(args, "encoder", None), in_channels=3, classes=args.num_classes,
                                   precision=getattr(args, "precision", "bf16"))
+        if getattr(args, "tta", False):  # mosaic_module.py:75-76 / segmentation_module.py keep a factory, applied by the scripts
+            self.tta_wrapper = partial(SegmentationTTAWrapper, merge_mode="mean")
         self.save_hyperparameters()
+        self.sliding = None
+        # how the reference finds an image's size / ground truth: files next to args.val_data (segmentation_module.py:151,183);
+        # both are overridable so that no PIL / filesystem access is needed (tests, packed datasets)
+        self.image_size_fn = self._image_size_from_disk
+        self.gt_mask_fn = self._gt_mask_from_disk
+
+    # ------------------------------------------------------------------ validation (segmentation_module.py:118-214, mosaic_module.py:118-214)
+    def _val_root(self):
+        return "/".join(self.args.val_data.split("/")[:-1])
+
+    def _image_size_from_disk(self, image_idx):
+        from PIL import Image
+
+        return Image.open(os.path.join(self._val_root(), "img", image_idx + ".png")).size
+
+    def _gt_mask_from_disk(self, image_idx):
+        import numpy as np
+        from PIL import Image
+
+        return torch.from_numpy(np.asarray(Image.open(os.path.join(self._val_root(), "mask", image_idx + ".png"))).copy())
+
+    def on_validation_epoch_start(self):
+        if self.args.dataset == "wsss4luad":
+            dev = next(self.model.parameters()).device
+            self.sliding = SlidingWindowAccumulator(self.args.num_classes, dev, lambda idx: self.image_size_fn(idx))
+
+    def validation_step(self, batch, batch_idx):
+        image_batch, mask_batch, name_batch, original_h_batch, original_w_batch = batch
+        with torch.no_grad():
+            output = self(image_batch)
+        self.valid_iou(output, mask_batch)
+        if self.args.dataset == "wsss4luad":
+            if self.sliding is None:
+                self.on_validation_epoch_start()
+            # the reference's per-sample softmax -> .cpu().numpy() -> canvas += probs loop, as one scatter-add launch per batch
+            self.sliding.add_batch(output, list(name_batch), [int(v) for v in original_h_batch], [int(v) for v in original_w_batch])
+
+    def validation_epoch_end(self, validation_step_outputs=None):
+        out = {}
+        if self.args.dataset == "wsss4luad" and self.sliding is not None:
+            big_mask_iou = self.sliding.big_mask_iou(lambda idx: self.gt_mask_fn(idx))
+            tissue_iou = self.valid_iou.Tissue_Intersection_over_Union()
+            big_tissue = big_mask_iou.Tissue_Intersection_over_Union()
+            out = {
+                "validation_tiou_patch_epoch": tissue_iou[0], "validation_siou_patch_epoch": tissue_iou[1], "validation_niou_patch_epoch": tissue_iou[2],
+                "validation_miou_patch_epoch": self.valid_iou.Mean_Intersection_over_Union(),
+                "validation_fwiou_patch_epoch": self.valid_iou.Frequency_Weighted_Intersection_over_Union(),
+                "validation_tiou_epoch": big_tissue[0], "validation_siou_epoch": big_tissue[1], "validation_niou_epoch": big_tissue[2],
+                "validation_miou_epoch": big_mask_iou.Mean_Intersection_over_Union(),
+                "validation_fwiou_epoch": big_mask_iou.Frequency_Weighted_Intersection_over_Union(),
+            }
+        else:
+            out = {"validation_miou_epoch": self.valid_iou.Mean_Intersection_over_Union(),
+                   "validation_fwiou_epoch": self.valid_iou.Frequency_Weighted_Intersection_over_Union()}
+        for k, v in out.items():
+            self.log(k, v, prog_bar=False)
+        self.valid_iou.reset()
+        self.sliding = None
+        return out
 
     def configure_optimizers(self):
         params = [p for p in self.model.parameters() if p.requires_grad]

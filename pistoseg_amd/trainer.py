@@ -57,10 +57,11 @@ def arena_order(model: ResNet38dSeg) -> List[Tuple[str, torch.nn.Parameter]]:
     (fc8, b7, b6, ... ) so that all-reduce buckets are contiguous arena slices."""
     named = dict(model.trainable_conv_params())
     out: List[Tuple[str, torch.nn.Parameter]] = []
+    units = getattr(model, "units", UNITS)
     for k in list(named):
-        if k.split(".")[0] not in {u[0] for u in UNITS}:
+        if k.split(".")[0] not in {u[0] for u in units}:
             out.append((k, named.pop(k)))  # heads (fc8, ...) finish first
-    for u in reversed(UNITS):
+    for u in reversed(units):
         for k in list(named):
             if k.split(".")[0] == u[0]:
                 out.append((k, named.pop(k)))

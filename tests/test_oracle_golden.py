@@ -143,3 +143,21 @@ def test_seg_ce_mean_counts_ignored_pixels():
     ce = torch.nn.CrossEntropyLoss(reduction="none", ignore_index=3)(logits, tgt)
     assert torch.equal(ref_cpu.seg_ce_loss(logits, tgt, 3), ce.mean())
     assert (ce[tgt == 3] == 0).all() and ce.numel() == tgt.numel()
+
+
+def test_oeem_wide_resnet_forward_cam_and_cls(golden_dir):
+    """Oracle restatement of OEEM/classification/network/wide_resnet.py (b7 dilated by 2, 5632-channel heads) against the
+    reference's own outputs (oracle/make_golden_oeem.py)."""
+    g = np.load(os.path.join(golden_dir, "oeem_cam.npz"))
+    from oracle.make_golden import make_inputs
+
+    c, n, s, seed = 3, 2, 64, 301
+    sd = ref_cpu.wide_state_dict(c, seed=42)
+    x, *_ = make_inputs(n, s, 4, seed)
+    with torch.no_grad():
+        cam = ref_cpu.wide_forward_cam(sd, x)
+        cls = ref_cpu.wide_forward_cls(sd, x)
+    assert tuple(cam.shape) == tuple(g[f"cam_c{c}_s{s}.shape"])
+    got = cam.reshape(-1)[torch.from_numpy(g[f"cam_c{c}_s{s}.idx"])]
+    assert torch.allclose(got, torch.from_numpy(g[f"cam_c{c}_s{s}.val"]), rtol=1e-5, atol=1e-6)
+    assert np.allclose(cls.numpy(), g[f"cls_c{c}_s{s}"], rtol=1e-5, atol=1e-6)
