@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void fc8_fwd_kernel(const T* __restrict__ x, i
 }
 
 // fc8 backward (+ ReLU(bn7) mask): a thread owns 8 channels and walks a pixel range, four pixels per iteration so
-// that four 16-byte activation loads are in flight per lane (the kernel is a pure stream: read x, write dx).
+// that four 16-byte activation loads are in flight per lane (eight per lane / shorter ranges measured slower: 750 vs 437 us) (the kernel is a pure stream: read x, write dx).
 template <typename T>
 __global__ __launch_bounds__(256) void fc8_bwd_kernel(const T* __restrict__ x, int ldc, const float* __restrict__ w,
                                                       const float* __restrict__ drop, const float* __restrict__ scale7,

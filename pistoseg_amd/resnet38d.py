@@ -157,8 +157,11 @@ class Net(nn.Module):
     def compute_dtype(self):
         return {"bf16": torch.bfloat16, "fp16": torch.float16}.get(self.precision, torch.float32)
 
-    def _cached(self, key: str, deps: Tuple[Tensor, ...], make):
-        sig = tuple((t.data_ptr(), t._version) for t in deps) + (self.precision, self._weights_epoch)
+    def _cached(self, key: str, deps: Tuple[Tensor, ...], make, raw_pointer_updates: bool = True):
+        # raw_pointer_updates: the tensors may be rewritten behind torch's back by the fused optimiser (conv weights in the
+        # training arena) -> also key on the weights epoch.  BatchNorm tensors are frozen (resnet38d.py:206-211) and only
+        # ever change through torch (load_state_dict bumps _version), so their affine maps survive optimiser steps.
+        sig = tuple((t.data_ptr(), t._version) for t in deps) + (self.precision, self._weights_epoch if raw_pointer_updates else 0)
         hit = self._cache.get(key)
         if hit is not None and hit[0] == sig:
             return hit[1]
@@ -209,7 +212,7 @@ class Net(nn.Module):
                 shift = bn.bias.float() - bn.running_mean.float() * scale
             return scale.contiguous(), shift.contiguous()
 
-        return self._cached("bn:" + key, (bn.weight, bn.bias, bn.running_mean, bn.running_var), make)
+        return self._cached("bn:" + key, (bn.weight, bn.bias, bn.running_mean, bn.running_var), make, raw_pointer_updates=False)
 
     def sample_dropout(self, n: int, device) -> Dict[str, Tensor]:
         """Per-(sample, channel) Dropout2d multipliers for a training forward (resnet38d.py:63,67,85,90)."""
