@@ -94,7 +94,7 @@ enum {
   PS_CONV_WS2_256 = 4,  /* conv_igemm_ws2_kernel<256>: 256x128 tile, one block per CU, 3-stage ring */
   PS_CONV_WS2_224 = 5,  /* conv_igemm_ws2_kernel<224> */
   PS_CONV_OTHER = 6,    /* an experimental kernel forced through the testing hooks */
-  PS_CONV_HALO = 7      /* conv_igemm_halo_kernel: 3x3 stride-1 on 28-wide maps, 224x128 tile of 8 whole rows, pixel window + halo staged once per tap row */
+  PS_CONV_HALO = 7      /* conv_igemm_halo_kernel: 3x3 stride-1, width % 28 == 0, 224x128 tile of 8 rows x 28 columns, pixel window + halo staged once per tap row */
 };
 int ps_conv_variant(const ps_conv_geom* g, int32_t dgrad);
 
@@ -339,7 +339,7 @@ void ps_debug_set_pp(int v);
 void ps_debug_set_ws(int v);
 /* Testing hook: large-tile (256|224 x 128, one block per CU) wave-specialised kernel: 0 off, 1 (default) chosen by the cost model, 256 / 224 forced. */
 void ps_debug_set_ws2(int v);
-/* Testing hook: window + halo kernel for 3x3 stride-1 layers on 28-wide maps: 0 off, 1 (default) where the large tile is chosen, 2 forced. */
+/* Testing hook: window + halo kernel for 3x3 stride-1 layers (width a multiple of 28): 0 off, 1 (default) for big 16-bit problems, 2 forced. */
 void ps_debug_set_halo(int v);
 /* Testing hook: 1 (default) = 128x128 weight-gradient tiles use the wave-specialised variant, 0 = the 4-wave kernel. */
 void ps_debug_set_wgrad_ws(int v);

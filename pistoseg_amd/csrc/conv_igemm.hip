@@ -1081,13 +1081,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Halo kernel: 3x3 STRIDE-1 convolutions on 28-wide feature maps (any dilation <= 4; forward and data gradient), persistent
+// Halo kernel: 3x3 STRIDE-1 convolutions on feature maps whose width is a multiple of 28 (28 / 56 / 112; dilation <= 4; forward and
+// data gradient), persistent
 // 224 x 128 tiles, 4 consumer + 4 loader waves as conv_igemm_ws2_kernel -- but the pixel operand is staged as a WINDOW with
 // its halo instead of one gathered tile per tap.
 //   The ws2 kernel is bound by L2 -> LDS fill bandwidth, not by the matrix pipe (r01: with the loads ablated the consumers
 //   run 26-35 % faster; every CU pulls (224 + 128) x 128 B per K-step = ~64 GB/s, ~16.5 TB/s chip-wide, the measured ceiling
-//   of LDS gathers from L2): each input row is fetched nine times, once per tap.  Here a tile is 8 whole feature-map rows
-//   (global rows n*H + p, 224 = 8 x 28 pixels); for one 64-channel K-line and one tap ROW ty the loaders stage the
+//   of LDS gathers from L2): each input row is fetched nine times, once per tap.  Here a tile is an 8-row x 28-column block
+//   (global rows n*H + p; whole rows on the 28-wide maps); for one 64-channel K-line and one tap ROW ty the loaders stage the
 //   8 x (28 + 2d) window  rows [R0 + (ty-1)d, +8) x cols [-d, 28 + d)  once (zero-filled outside the image), and the three
 //   taps tx = 0..2 of that row are three K-steps whose pixel fragments are read from the same window at a column shift of
 //   (tx-1)d: fill traffic per K-step drops from 45 KiB to 26-28 KiB.
@@ -1105,7 +1106,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
 template <typename Tr>
 __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs a) {
   typedef typename Tr::elem T;
-  constexpr int BM = 224, BN = 128, MI = 7, WI = 4, WN = 64, W = 28, TR = 8;
+  constexpr int BM = 224, BN = 128, MI = 7, WI = 4, WN = 64, TW = 28, TR = 8;  // tile = 8 rows x 28 columns
   constexpr int WJ = 9, WIN_BYTES = WJ * 4 * 1024, B_BYTES = BN * 128;
   constexpr int W_OFF = 2 * WIN_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1118,9 +1119,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
   const int nwin = 3 * a.klines;             // windows (K-line, ty) per tile, three K-steps each
   const int my_tiles = (ntiles - first + G - 1) / G;
   const int total_steps = my_tiles * nwin * 3;
-  const int H = a.Hs, NH = a.M / W;          // stride 1: produced grid == source grid; NH = global rows n*H + p
+  const int H = a.Hs, W = a.Ws, NH = a.M / W;  // stride 1: produced grid == source grid; NH = global rows n*H + p
+  const int ncb = W / TW;                    // column blocks per row (W is a multiple of 28: 28, 56, 112)
   const int dabs = a.dstep < 0 ? -a.dstep : a.dstep;
-  const int WP = W + 2 * dabs;               // window columns (<= 36)
+  const int WP = TW + 2 * dabs;              // window columns (<= 36)
 
   if (wave >= 4) {
     // ================= loader =================
@@ -1129,22 +1131,25 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
     const int chunk_off = ((lane & 7) ^ srow) << 4;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, (int)a.src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, 0, (int)a.wgt_bytes, 0x00020000);
-    // DMA instruction t = 4j + lw stages window COLUMN t (8 rows x 128 B = the instruction's 1 KiB): source column t - d
-    int rel[WJ];
+    // DMA instruction t = 4j + lw stages window COLUMN t (8 rows x 128 B = the instruction's 1 KiB): source column X0 + t - d
+    int tcol[WJ];
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
-      const int t = j * 4 + lw, col = t - dabs;
-      rel[j] = (t < WP && col >= 0 && col < W) ? (srow * W + col) * (int)a.pix_bytes + chunk_off : -1;
+      const int t = j * 4 + lw;
+      tcol[j] = t < WP ? t - dabs : -(1 << 20);
     }
+    const int lane_off = srow * W * (int)a.pix_bytes + chunk_off;
     // --- cursor of the next WINDOW to stage: (tile, K-line, ty).  Window row wr of tap row ty serves exactly ONE produced row,
     // global row R0 + wr: it holds source row p + (ty-1)*dstep of the SAME image, or zeros (vertical padding; produced rows
     // past the tensor's end; rows that would come from the neighbouring image when a tile straddles two images).
     int a_tile = first, a_kl = 0, a_ty = 0, a_buf = 0, a_left = my_tiles * nwin;
-    int a_R0 = 0, prow = 0;  // prow: image row p of the produced row this lane's window row serves (per tile)
+    int a_R0 = 0, a_X0 = 0, prow = 0;  // prow: image row p of the produced row this lane's window row serves (per tile)
     auto window_tile_setup = [&](int tile) {
       int tm, tn;
       ps_tile_of_block(tile, a.ntn, a.ntm, tm, tn, a.supertile);
-      a_R0 = tm * TR;
+      const int rb = tm / ncb;
+      a_R0 = rb * TR;
+      a_X0 = (tm - rb * ncb) * TW;
       const int gr = a_R0 + srow;
       prow = gr < NH ? gr - (gr / H) * H : -(1 << 20);
     };
@@ -1152,13 +1157,15 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
     auto issue_window = [&]() -> bool {
       if (a_left == 0) return false;
       const int shift = (a_ty - 1) * a.dstep;
-      const int base = (a_R0 + shift) * W * (int)a.pix_bytes;
+      const int base = ((a_R0 + shift) * W + a_X0) * (int)a.pix_bytes + lane_off;
       const bool row_ok = (unsigned)(prow + shift) < (unsigned)H;
       unsigned char* dst = smem + a_buf * WIN_BYTES;
       const int ko = a_kl * 128;
 #pragma unroll
-      for (int j = 0; j < WJ; ++j)
-        BLDS16(rsA, dst + (j * 4 + lw) * 1024, (row_ok && rel[j] >= 0) ? (unsigned)(base + rel[j]) : PAD_ROW, ko);
+      for (int j = 0; j < WJ; ++j) {
+        const bool ok = row_ok && (unsigned)(a_X0 + tcol[j]) < (unsigned)W;  // left / right of the image: zero padding
+        BLDS16(rsA, dst + (j * 4 + lw) * 1024, ok ? (unsigned)(base + tcol[j] * (int)a.pix_bytes) : PAD_ROW, ko);
+      }
       --a_left;
       a_buf ^= 1;
       if (++a_ty == 3) {
@@ -1311,7 +1318,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
       for (int i = 0; i < WI; ++i) Tr::mma(wf1[i], xf1[mi], acc[mi][i]);
     int tm, tn;
     ps_tile_of_block(tile, a.ntn, a.ntm, tm, tn, a.supertile);
-    conv_epilogue<T, MI, WI, true>(a, acc, tm * BM + wm * 14, tn * BN + wn * WN, lane);
+    const int rb = tm / ncb;
+    conv_epilogue<T, MI, WI, true>(a, acc, rb * TR * W + (tm - rb * ncb) * TW + wm * 14, tn * BN + wn * WN, lane);
   }
 }
 
@@ -1319,7 +1327,7 @@ static int g_use_glds = 2;  // staging mode: 0 registers, 1 global_load_lds, 2 b
 static int g_use_pp = 0;       // experimental ping-pong kernel (correct, slower: r01 measurements)
 static int g_use_ws = 1;       // wave-specialised (loader/consumer) kernel for big problems
 static int g_use_ws2 = 1;
-static int g_use_halo = 1;     // window + halo staging for 3x3 stride-1 layers on 28-wide maps: 0 off, 1 where the large tile would be chosen, 2 forced      // large-tile wave-specialised kernel: 0 off, 1 by cost model, 256 / 224 force that pixel tile
+static int g_use_halo = 1;     // window + halo staging for 3x3 stride-1 layers (width a multiple of 28): 0 off, 1 for big 16-bit problems, 2 forced      // large-tile wave-specialised kernel: 0 off, 1 by cost model, 256 / 224 force that pixel tile
 static int g_use_3stage = 0;  // experimental 256x128 three-stage kernel: correct but slower than two 128x128 blocks per CU (r01 measurements)
 static int g_ablate = 0;
 static int g_supertile = 4;  // measured best of {0,4,8,16} on the wide 28x28 layers (r01)
@@ -1401,7 +1409,7 @@ static int pick_ws_variant(long long M, int Cd, int esize, bool halo_ok) {
   if (g_use_glds != 2 || Cd % 128 != 0) return 0;
   const long long n128 = Cd / 128;
   // 3x3 stride-1 layers whose 224-pixel tiles are whole feature-map rows: window + halo staging (less LDS fill traffic)
-  if (halo_ok && g_use_halo && (g_use_halo > 1 || (g_use_ws2 == 1 && esize == 2 && n128 >= 2 && ((M + 223) / 224) * n128 >= 256))) return PS_CONV_HALO;
+  if (halo_ok && g_use_halo && (g_use_halo == 2 || (g_use_ws2 == 1 && esize == 2 && ((M + 223) / 224) * n128 >= 256))) return PS_CONV_HALO;
   if (g_use_ws2 && (g_use_ws2 > 1 || (esize == 2 && n128 >= 2 && ((M + 255) / 256) * n128 >= 256))) {
     const long long t256 = (M + 255) / 256, t224 = (M + 223) / 224;
     const long long c256 = ((t256 * n128 + 255) / 256) * 256, c224 = ((t224 * n128 + 255) / 256) * 224;
@@ -1449,12 +1457,12 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
     }
   }
   const int adil = a.dstep < 0 ? -a.dstep : a.dstep;
-  const bool halo_ok = a.taps == 9 && a.mul == 1 && a.div_shift == 0 && a.Hs == a.Ho && a.Ws == a.Wo && a.Ws == 28 && adil <= 4;
+  const bool halo_ok = a.taps == 9 && a.mul == 1 && a.div_shift == 0 && a.Hs == a.Ho && a.Ws == a.Wo && a.Ws % 28 == 0 && a.Ws <= 224 && adil <= 4;
   if (const int v = pick_ws_variant(a.M, a.Cd, (int)sizeof(typename Tr::elem), halo_ok)) {
     IgemmArgs b = a;
     b.ntn = a.Cd / 128;
     if (v == PS_CONV_HALO) {
-      b.ntm = (a.M + 223) / 224;
+      b.ntm = (a.M / a.Ws + 7) / 8 * (a.Ws / 28);  // blocks of 8 global rows x column blocks of 28
       const dim3 hgrid((unsigned)std::min<long long>((long long)b.ntm * b.ntn, ps_num_cus()));
       hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr>), hgrid, dim3(512), 2 * 36864 + 3 * 16384, s, b);
       PS_CHECK_LAUNCH("conv_igemm_halo");
@@ -1507,7 +1515,7 @@ extern "C" int ps_conv_variant(const ps_conv_geom* g, int32_t dgrad) {
   const long long M = dgrad ? (long long)g->n * g->h * g->w : (long long)g->n * ho * wo;
   if (g_use_3stage || g_use_pp) return PS_CONV_OTHER;
   // both directions of a stride-1 3x3 layer gather on the input grid h x w
-  const bool halo_ok = g->ksize == 3 && g->stride == 1 && g->w == 28 && g->dilation <= 4;
+  const bool halo_ok = g->ksize == 3 && g->stride == 1 && g->w % 28 == 0 && g->w <= 224 && g->dilation <= 4;
   const int v = pick_ws_variant(M, dgrad ? g->cin : g->cout, ps_esize(g->dtype), halo_ok);
   return v ? v : PS_CONV_4WAVE;
 }

@@ -434,10 +434,11 @@ def test_conv_pipelined_kernels_are_bit_identical_to_two_stage(case, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", [
-    # (n, h, w, cin, cout, d): 3x3 stride 1 on 28x28 maps: 224-pixel tiles are 8 rows and straddle images (784 = 3.5 tiles), the
-    # last tile is ragged for odd n; every dilation of the net; 1 .. 4 K-lines; 1 .. 3 cout tiles
+    # (n, h, w, cin, cout, d): 3x3 stride 1, width a multiple of 28.  Tiles are 8 rows x 28 columns: on 28x28 maps they straddle
+    # images (784 = 3.5 tiles) and the last tile is ragged for odd n; 56 / 84 / 112-wide maps have 2-4 column blocks whose halos
+    # are real neighbour columns; h = 12 is not a multiple of 8; every dilation of the net; 1 .. 4 K-lines; 1 .. 3 cout tiles
     (3, 28, 28, 128, 128, 1), (2, 28, 28, 64, 256, 2), (3, 28, 28, 256, 128, 4), (1, 28, 28, 128, 256, 4), (5, 28, 28, 64, 128, 1),
-    (7, 28, 28, 192, 384, 2),
+    (7, 28, 28, 192, 384, 2), (2, 56, 56, 64, 128, 1), (1, 112, 112, 64, 128, 1), (1, 56, 84, 128, 128, 2), (1, 12, 56, 64, 256, 4),
 ])
 def test_conv_halo_window_kernel(case, dtype):
     """conv_igemm_halo_kernel (pixel window + halo staged once per tap row, K order (K-line, ty, tx)) forced on small problems:
