@@ -320,6 +320,15 @@ int ps_scale_inplace(float* x, int64_t n, float divisor, void* stream);
  * activation gradient reaches the f32 gradient arena as inf/nan, and the step is then skipped. */
 int ps_nonfinite_count(const float* g, int64_t n, int32_t* count, void* stream);
 
+/* Work items per block of the persistent conv kernels: 0 (default) = one block per CU lives for the whole launch (best when the
+ * GPU runs nothing else); n > 0 = blocks are dispatched in batches and take n items each, so the hardware re-balances when another
+ * kernel (an RCCL all-reduce overlapping the backward) holds some CUs.  Process-wide; set by the trainers. */
+void ps_set_tiles_per_block(int32_t n);
+
+/* Testing hook: `blocks` workgroups of 256 threads each occupy a CU slot (and `lds_bytes` of its LDS: >= 40 KiB keeps the persistent
+ * conv blocks off that CU) for `usec` microseconds -- a stand-in for a communication kernel sharing the GPU (tools/hog_probe.py). */
+int ps_debug_hog(int32_t blocks, int32_t usec, int32_t lds_bytes, void* stream);
+
 /* Testing hook: how conv operands are staged into LDS: 2 (default) LDS-DMA through buffer descriptors
  * (buffer_load ... lds; padding rows are out-of-range lanes, which the DMA zero-fills), 1 LDS-DMA with flat
  * addresses (global_load_lds; padding rows read a zero page), 0 through registers.  All variants compute identical

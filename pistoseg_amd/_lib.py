@@ -100,6 +100,8 @@ PROTOTYPES = {
     "ps_d4_view": (C.c_int, [_P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "ps_scale_inplace": (C.c_int, [_P, _L, _F, _P]),
     "ps_nonfinite_count": (C.c_int, [_P, _L, _P, _P]),
+    "ps_set_tiles_per_block": (None, [_I]),
+    "ps_debug_hog": (C.c_int, [_I, _I, _I, _P]),
     "ps_debug_set_glds": (None, [C.c_int]),
     "ps_debug_set_3stage": (None, [C.c_int]),
     "ps_debug_set_bn": (None, [C.c_int]),

@@ -34,6 +34,7 @@ struct IgemmArgs {
   unsigned src_bytes;         // extent of the gathered tensor / of the weights (buffer descriptors' num_records)
   unsigned wgt_bytes;
   int ablate;                 // timing experiments only (results WRONG): 1 = stage the first two K-steps only; 2 = also no per-step barriers (ws kernel)
+  int nb, tpb;                // persistent kernels: blocks per batch (#CUs), tiles per block (0 = one batch), see ps_block_items
   ps_epilogue epi;
 };
 
@@ -906,11 +907,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
   // the consumers are still in the epilogue, and the epilogue's global stores drain behind the next tile's main loop (with
   // one block per CU and equal tiles, every CU reaches its epilogue at the same time: as separate blocks the stores of a
   // whole round -- tens of MB -- were exposed at HBM speed before any CU could start its next tile).
-  const int G = gridDim.x;
-  const int first = ps_xcd_remap(blockIdx.x, G);
-  const int ntiles = a.ntm * a.ntn;
+  int first, G, ntiles;  // this block's tiles: first, first + G, ... < ntiles
+  ps_block_items(blockIdx.x, gridDim.x, a.ntm * a.ntn, a.nb, a.tpb, first, G, ntiles);
   const int nsteps = a.taps * a.klines;
-  const int my_tiles = (ntiles - first + G - 1) / G;  // >= 1 (G <= ntiles)
+  const int my_tiles = (ntiles - first + G - 1) / G;  // >= 1
   const int total_steps = my_tiles * nsteps;
 
   if (wave >= 4) {
@@ -1113,9 +1113,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int G = gridDim.x;
-  const int first = ps_xcd_remap(blockIdx.x, G);
-  const int ntiles = a.ntm * a.ntn;
+  int first, G, ntiles;  // this block's tiles: first, first + G, ... < ntiles
+  ps_block_items(blockIdx.x, gridDim.x, a.ntm * a.ntn, a.nb, a.tpb, first, G, ntiles);
   const int nwin = 3 * a.klines;             // windows (K-line, ty) per tile, three K-steps each
   const int my_tiles = (ntiles - first + G - 1) / G;
   const int total_steps = my_tiles * nwin * 3;
@@ -1463,7 +1462,9 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
     b.ntn = a.Cd / 128;
     if (v == PS_CONV_HALO) {
       b.ntm = (a.M / a.Ws + 7) / 8 * (a.Ws / 28);  // blocks of 8 global rows x column blocks of 28
-      const dim3 hgrid((unsigned)std::min<long long>((long long)b.ntm * b.ntn, ps_num_cus()));
+      b.nb = ps_num_cus();
+      b.tpb = ps_tiles_per_block();
+      const dim3 hgrid(ps_persistent_grid((long long)b.ntm * b.ntn, b.nb, b.tpb));
       hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr>), hgrid, dim3(512), 2 * 36864 + 3 * 16384, s, b);
       PS_CHECK_LAUNCH("conv_igemm_halo");
       return PS_OK;
@@ -1471,7 +1472,9 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
     const int bm = v == PS_CONV_WS2_256 ? 256 : v == PS_CONV_WS2_224 ? 224 : v == PS_CONV_WS_128 ? 128 : 112;
     b.ntm = (a.M + bm - 1) / bm;
     const dim3 grid((unsigned)(b.ntm * b.ntn));
-    const dim3 pgrid((unsigned)std::min<long long>((long long)b.ntm * b.ntn, ps_num_cus()));  // persistent: one block per CU
+    b.nb = ps_num_cus();
+    b.tpb = ps_tiles_per_block();
+    const dim3 pgrid(ps_persistent_grid((long long)b.ntm * b.ntn, b.nb, b.tpb));  // persistent: one block per CU (per batch)
     if (v == PS_CONV_WS2_256) hipLaunchKernelGGL((conv_igemm_ws2_kernel<Tr, 256>), pgrid, dim3(512), 3 * (256 * 128 + 128 * 128), s, b);
     else if (v == PS_CONV_WS2_224) hipLaunchKernelGGL((conv_igemm_ws2_kernel<Tr, 224>), pgrid, dim3(512), 3 * (224 * 128 + 128 * 128), s, b);
     else if (v == PS_CONV_WS_112) hipLaunchKernelGGL((conv_igemm_ws_kernel<Tr, 112>), grid, dim3(512), 2 * (112 * 128 + 128 * 128) + 1024, s, b);

@@ -47,6 +47,7 @@ struct WgradArgs {
   int dq, dp, dn;              // how (q, p, n) of a pixel advance when its index grows by KP
   int raster;                  // block order (see kernel)
   int ablate;                  // timing experiments only (results WRONG): 1 = no atomics, 2 = plain stores instead of atomics
+  int nb, tpb;                 // persistent kernel: blocks per batch (#CUs), items per block (0 = one batch), see ps_block_items
 };
 
 struct WTraitsBF16 {
@@ -311,10 +312,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
   // blocks that share an XCD (= an L2) get CONSECUTIVE items: with the pixel range slowest in the item order they then stream the
   // same dY / X pixel rows (measured before the remap: every XCD pulled every pixel range through its L2, ~1 GB per launch
   // on the memory side of L2 for a 100 MB working set)
-  const int G = gridDim.x, first = ps_xcd_remap(blockIdx.x, G);
   const int per = (a.ksteps + a.splits - 1) / a.splits;           // K-steps per pixel range
   const int live = (a.ksteps + per - 1) / per;                    // ranges that get work
-  const int nitems = a.tiles_co * a.tiles_ci * a.taps * live;
+  int first, G, nitems;  // this block's items: first, first + G, ... < nitems
+  ps_block_items(blockIdx.x, gridDim.x, a.tiles_co * a.tiles_ci * a.taps * live, a.nb, a.tpb, first, G, nitems);
   // item -> (ci tile, co tile, tap, pixel range), pixel range slowest (co-running blocks share their dY / X chunks in L2)
   auto decode = [&](int item, int& tci, int& tco, int& tap, int& ks0, int& ks1) {
     tci = item % a.tiles_ci; item /= a.tiles_ci;
@@ -575,7 +576,9 @@ int launch_wgrad_ws2(WgradArgs a, hipStream_t s) {
   a.splits = (int)splits;
   const long long per = (a.ksteps + splits - 1) / splits, live = (a.ksteps + per - 1) / per;
   const long long items = tiles * live;
-  const unsigned grid = (unsigned)std::min<long long>(items, ncu);
+  a.nb = ncu;
+  a.tpb = ps_tiles_per_block();
+  const unsigned grid = ps_persistent_grid(items, a.nb, a.tpb);
   hipLaunchKernelGGL((conv_wgrad_ws2_kernel<Tr::F16>), dim3(grid), dim3(512), 3 * 64 * (256 + 128) * 2, s, a);
   PS_CHECK_LAUNCH("conv_wgrad_ws2");
   return PS_OK;

@@ -16,6 +16,13 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 void ps_set_error(const char* fmt, ...);
 int ps_num_cus(void);  // compute units of the current device (api.cpp)
+int ps_tiles_per_block(void);  // ps_set_tiles_per_block()'s value (api.cpp)
+// grid of a persistent kernel over nitems work items (see ps_block_items)
+static inline unsigned ps_persistent_grid(long long nitems, int nb, int tpb) {
+  if (tpb <= 0) return (unsigned)(nitems < nb ? nitems : nb);
+  const long long per_batch = (long long)nb * tpb, full = nitems / per_batch, rem = nitems - full * per_batch;
+  return (unsigned)(full * nb + (rem < nb ? rem : nb));
+}
 
 #define PS_REQUIRE(cond, ...)            \
   do {                                   \
@@ -129,4 +136,26 @@ __device__ __forceinline__ int ps_xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + idx;
+}
+
+// Work split of the persistent kernels.  tpb <= 0: ONE batch -- block b takes items remap(b), remap(b) + nblocks, ... (a block
+// lives for the whole launch: best when the GPU is ours alone).  tpb > 0: blocks come in batches of nb (= #CUs); a batch covers
+// nb * tpb consecutive items and each of its blocks takes tpb of them, so the hardware dispatcher re-balances every tpb items when
+// some CUs are held by another kernel (a communication kernel beside the backward: a block that starts late would otherwise
+// serialise its whole static share behind the others, tools/hog_probe.py).
+__device__ __forceinline__ void ps_block_items(int bid, int nblocks, int nitems, int nb, int tpb, int& first, int& stride, int& end) {
+  if (tpb <= 0) {
+    stride = nblocks;
+    first = ps_xcd_remap(bid, nblocks);
+    end = nitems;
+    return;
+  }
+  const int per_batch = nb * tpb;
+  const int batch = bid / nb, lane = bid - batch * nb;
+  const int base = batch * per_batch;
+  const int left = nitems - base;
+  const int in_batch = left < per_batch ? left : per_batch;
+  stride = in_batch < nb ? in_batch : nb;
+  first = base + ps_xcd_remap(lane, stride);
+  end = base + in_batch;
 }

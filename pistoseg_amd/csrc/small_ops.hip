@@ -510,3 +510,26 @@ extern "C" int ps_sgd_step(float* p, const float* g, float* buf, void* p_bf16, i
                            float weight_decay, int32_t first_step, void* stream) {
   return ps_sgd_step_scaled(p, g, buf, p_bf16, PS_BF16, n, lr, momentum, weight_decay, first_step, 1.0f, stream);
 }
+
+// Testing hook: `blocks` workgroups of 256 threads that each hold a CU slot for `usec` microseconds (spin on the 100 MHz real-time
+// counter) -- stands in for a communication kernel running beside the persistent conv kernels (tools/hog_probe.py).
+namespace {
+__global__ __launch_bounds__(256) void hog_kernel(long long ticks, int* sink) {
+  extern __shared__ int hog_lds[];  // dynamic LDS only serves to keep other workgroups off this CU
+  if (sink) hog_lds[threadIdx.x] = 0;
+  const long long t0 = __builtin_amdgcn_s_memrealtime();
+  int n = 0;
+  while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+    __builtin_amdgcn_s_sleep(32);
+    ++n;
+  }
+  if (sink && n < 0) *sink = n;
+}
+}  // namespace
+
+extern "C" int ps_debug_hog(int32_t blocks, int32_t usec, int32_t lds_bytes, void* stream) {
+  PS_REQUIRE(blocks > 0 && usec > 0 && usec <= 2000000 && lds_bytes >= 0 && lds_bytes <= 160 * 1024, "debug_hog: bad argument");
+  hipLaunchKernelGGL(hog_kernel, dim3(blocks), dim3(256), (size_t)lds_bytes, static_cast<hipStream_t>(stream), (long long)usec * 100, (int*)nullptr);
+  PS_CHECK_LAUNCH("debug_hog");
+  return PS_OK;
+}

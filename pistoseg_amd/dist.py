@@ -37,18 +37,35 @@ def plan_buckets(entries: Sequence[Tuple[str, int]], limit_elems: int) -> List[T
 
 
 class BucketedAllReduce:
-    """SUM all-reduce of a flat gradient arena in buckets, driven by 'unit finished' notifications."""
+    """SUM all-reduce of a flat gradient arena in buckets, driven by 'unit finished' notifications.
 
-    def __init__(self, flat: Tensor, buckets: List[Tuple[str, int, int]], group=None):
+    While buckets are in flight the communication kernels hold some CUs: the conv kernels' persistent blocks (one per CU, each
+    with a static share of the tiles) would then serialise the share of every block that cannot start (measured with a CU hog,
+    tools/hog_probe.py: +63 % on a launch that loses 16 CUs, +0..29 % with 1-2 tiles per block), so from the first bucket launch to
+    `finish()` the conv launches are told to cut their work into `shared_tiles_per_block`-tile blocks that the hardware
+    dispatcher re-balances (ps_set_tiles_per_block); forward passes and single-GPU runs keep the fully persistent schedule."""
+
+    def __init__(self, flat: Tensor, buckets: List[Tuple[str, int, int]], group=None, shared_tiles_per_block: int = 1):
         self.flat, self.buckets, self.group = flat, buckets, group
         self.comm_stream = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None
+        self.shared_tiles_per_block = shared_tiles_per_block
         self._next = 0
         self._pending = []
+        self._sharing = False
+
+    def _share_gpu(self, on: bool) -> None:
+        if self.comm_stream is None or on == self._sharing:
+            return
+        from . import _lib  # device path only: the CPU (gloo) tests never load the HIP library
+
+        _lib.load().ps_set_tiles_per_block(self.shared_tiles_per_block if on else 0)
+        self._sharing = on
 
     def begin_step(self) -> None:
         self._next, self._pending = 0, []
 
     def _launch(self, start: int, end: int) -> None:
+        self._share_gpu(True)
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
@@ -74,6 +91,7 @@ class BucketedAllReduce:
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         self._pending = []
+        self._share_gpu(False)
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:

@@ -528,6 +528,48 @@ def test_wgrad_large_tile_persistent_kernel(case, dtype):
         assert rel_err(dw.cpu(), old.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("tpb", [1, 2, 5])
+def test_persistent_kernels_batched_work_split_is_exact(tpb):
+    """ps_set_tiles_per_block(n): the persistent kernels' blocks are dispatched in batches and take n work items each (used while
+    an all-reduce shares the GPU).  Only the item -> block assignment changes: forward / data gradient are bit-identical to the
+    one-batch schedule, the weight gradient up to f32 atomic ordering."""
+    from pistoseg_amd import _lib, ops
+
+    lib = _lib.load()
+    D = dev()
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(31 + tpb)
+    # > 256 tiles / items each: halo (3x3 on 28x28), ws2 (1x1), wgrad ws2
+    cases = [(40, 28, 28, 256, 256, 3, 2), (36, 28, 28, 512, 256, 1, 1)]
+    for n, h, w, cin, cout, k, d in cases:
+        x = torch.randn(n, h, w, cin, generator=g).to(D, dtype)
+        wt = (torch.randn(cout, cin, k, k, generator=g) * 0.03)
+        wf, wd = w_fwd_layout(wt).to(D, dtype), w_dgrad_layout(wt).to(D, dtype)
+        gy = torch.randn(n, h, w, cout, generator=g).to(D, dtype)
+        spec = ops.ConvSpec(cin, cout, k, 1, d)
+
+        def run():
+            y = torch.empty((n, h, w, cout), device=D, dtype=dtype)
+            ops.conv2d_fwd(spec, x, wf, out_raw=y)
+            gx = torch.empty((n, h, w, cin), device=D, dtype=dtype)
+            ops.conv2d_dgrad(spec, gy, wd, (h, w), out_raw=gx)
+            dw = torch.zeros((cout, k, k, cin), device=D, dtype=torch.float32)
+            ops.conv2d_wgrad(spec, x, gy, dw)
+            return y, gx, dw
+
+        try:
+            lib.ps_set_tiles_per_block(0)
+            lib.ps_debug_set_wgrad_ws2(2)
+            ref = run()
+            lib.ps_set_tiles_per_block(tpb)
+            got = run()
+        finally:
+            lib.ps_set_tiles_per_block(0)
+            lib.ps_debug_set_wgrad_ws2(1)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+        assert rel_err(got[2].cpu(), ref[2].cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("bm", [112, 128, 224, 256])
 @pytest.mark.parametrize("case", [(128, 256, 3, 2, 1), (256, 256, 3, 1, 2), (512, 128, 1, 1, 1)])
