@@ -72,6 +72,7 @@ PROTOTYPES = {
     "ps_device_count": (C.c_int, []),
     "ps_conv_supported": (C.c_int, [C.POINTER(ConvGeom)]),
     "ps_conv_variant": (C.c_int, [C.POINTER(ConvGeom), _I]),
+    "ps_conv_wgrad_variant": (C.c_int, [C.POINTER(ConvGeom)]),
     "ps_conv2d_fwd": (C.c_int, [C.POINTER(ConvGeom), _P, _P, C.POINTER(Epilogue), _P]),
     "ps_conv2d_dgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _P, C.POINTER(Epilogue), _P]),
     "ps_conv2d_wgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _P, _P, _P]),

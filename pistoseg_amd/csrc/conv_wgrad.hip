@@ -584,10 +584,13 @@ int launch_wgrad_ws2(WgradArgs a, hipStream_t s) {
   return PS_OK;
 }
 
+static bool use_wgrad_ws2(int esize, long long M, int cout, int cin, int taps) {
+  return g_wgrad_ws2 && esize == 2 && cout % 256 == 0 && cin % 128 == 0 && (g_wgrad_ws2 > 1 || M * cout * cin * taps >= (1LL << 31));
+}
+
 template <typename Tr>
 int dispatch_wgrad(const WgradArgs& a, hipStream_t s) {
-  if (g_wgrad_ws2 && Tr::ES == 2 && a.cout % 256 == 0 && a.cin % 128 == 0 && (g_wgrad_ws2 > 1 || (long long)a.M * a.cout * a.cin * a.taps >= (1LL << 31)))
-    return launch_wgrad_ws2<Tr>(a, s);
+  if (use_wgrad_ws2(Tr::ES, a.M, a.cout, a.cin, a.taps)) return launch_wgrad_ws2<Tr>(a, s);
   const bool co128 = a.cout % 128 == 0, ci128 = a.cin % 128 == 0;
   if (co128 && ci128) return launch_wgrad<Tr, 128, 128>(a, s);
   if (co128) return launch_wgrad<Tr, 128, 64>(a, s);
@@ -602,6 +605,12 @@ extern "C" void ps_debug_set_wgrad_ws2(int v) { g_wgrad_ws2 = v; }
 extern "C" void ps_debug_set_wgrad_ablate(int v) { g_wgrad_ablate = v; }
 extern "C" void ps_debug_set_wgrad_ovh(int v) { g_wgrad_ovh = v; }
 extern "C" void ps_debug_set_wgrad_raster(int v) { g_wgrad_raster = v; }
+
+extern "C" int ps_conv_wgrad_variant(const ps_conv_geom* g) {
+  if (!g || !ps_conv_supported(g)) return -1;
+  const long long ho = (g->h - 1) / g->stride + 1, wo = (g->w - 1) / g->stride + 1;
+  return use_wgrad_ws2(ps_esize(g->dtype), (long long)g->n * ho * wo, g->cout, g->cin, g->ksize * g->ksize) ? 1 : 0;
+}
 
 extern "C" int ps_conv2d_wgrad(const ps_conv_geom* g, const void* x, const void* dy, float* dw, void* stream) {
   PS_REQUIRE(g && x && dy && dw, "conv2d_wgrad: null argument");
