@@ -115,6 +115,10 @@ int ps_conv2d_wgrad(const ps_conv_geom* g, const void* x, const void* dy, float*
 /* dst[cin][taps][cout] = src[cout][taps][cin]; same 16-bit dtype on both sides, f32 -> f32, or f32 -> bf16/f16 (cast). */
 int ps_weight_transpose(int32_t src_dtype, int32_t dst_dtype, const void* src, void* dst, int32_t cout, int32_t taps,
                         int32_t cin, void* stream);
+/* Strided row copy: dst[r][0..row_bytes) = src[r][0..row_bytes), r < rows (pitches in bytes; everything a multiple of 16).  Used to lay
+ * two weight matrices side by side along K, so that a bottleneck unit's shortcut conv and its last 1x1 conv (and their data gradients)
+ * run as ONE GEMM over concatenated channels (models/resnet38d.py:76-97: `branch1 + branch2`). */
+int ps_copy_rows(const void* src, int64_t src_ld_bytes, void* dst, int64_t dst_ld_bytes, int64_t rows, int64_t row_bytes, void* stream);
 /* dst = (bf16)src, n elements.  (per-step refresh of the bf16 forward weights from the f32 master arena) */
 int ps_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* dst = (dst_dtype)src for dst_dtype in {PS_BF16, PS_F16}. */

@@ -77,6 +77,7 @@ PROTOTYPES = {
     "ps_conv2d_dgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _P, C.POINTER(Epilogue), _P]),
     "ps_conv2d_wgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _P, _P, _P]),
     "ps_weight_transpose": (C.c_int, [_I, _I, _P, _P, _I, _I, _I, _P]),
+    "ps_copy_rows": (C.c_int, [_P, _L, _P, _L, _L, _L, _P]),
     "ps_cast_f32_bf16": (C.c_int, [_P, _P, _L, _P]),
     "ps_cast_f32_lowp": (C.c_int, [_P, _P, _I, _L, _P]),
     "ps_conv1a_fwd": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -511,6 +511,31 @@ extern "C" int ps_sgd_step(float* p, const float* g, float* buf, void* p_bf16, i
   return ps_sgd_step_scaled(p, g, buf, p_bf16, PS_BF16, n, lr, momentum, weight_decay, first_step, 1.0f, stream);
 }
 
+// dst[r][0 .. row_bytes) = src[r][0 .. row_bytes) for rows r with independent pitches (16-byte vectors): assembling K-concatenated weights
+namespace {
+__global__ __launch_bounds__(256) void copy_rows_kernel(const unsigned char* __restrict__ src, long long src_ld, unsigned char* __restrict__ dst,
+                                                        long long dst_ld, long long rows, int vec_per_row) {
+  const long long total = rows * vec_per_row;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / vec_per_row;
+    const int v = (int)(i - r * vec_per_row);
+    *reinterpret_cast<uint4*>(dst + r * dst_ld + v * 16) = *reinterpret_cast<const uint4*>(src + r * src_ld + v * 16);
+  }
+}
+}  // namespace
+
+extern "C" int ps_copy_rows(const void* src, int64_t src_ld_bytes, void* dst, int64_t dst_ld_bytes, int64_t rows, int64_t row_bytes, void* stream) {
+  PS_REQUIRE(src && dst && rows > 0 && row_bytes > 0, "copy_rows: bad argument");
+  PS_REQUIRE(row_bytes % 16 == 0 && src_ld_bytes % 16 == 0 && dst_ld_bytes % 16 == 0 && ps_aligned16(src) && ps_aligned16(dst),
+             "copy_rows: rows, pitches and pointers must be 16-byte multiples");
+  PS_REQUIRE(row_bytes <= src_ld_bytes && row_bytes <= dst_ld_bytes && row_bytes / 16 < (1LL << 31), "copy_rows: row longer than a pitch");
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(rows * (row_bytes / 16), 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     (const unsigned char*)src, (long long)src_ld_bytes, (unsigned char*)dst, (long long)dst_ld_bytes, (long long)rows,
+                     (int)(row_bytes / 16));
+  PS_CHECK_LAUNCH("copy_rows");
+  return PS_OK;
+}
+
 // Testing hook: `blocks` workgroups of 256 threads that each hold a CU slot for `usec` microseconds (spin on the 100 MHz real-time
 // counter) -- stands in for a communication kernel running beside the persistent conv kernels (tools/hog_probe.py).
 namespace {

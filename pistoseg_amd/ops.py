@@ -169,6 +169,16 @@ def weight_transpose(src: Tensor, dst: Tensor, cout: int, taps: int, cin: int) -
     _lib.check(lib.ps_weight_transpose(_dt(src), _dt(dst), src.data_ptr(), dst.data_ptr(), cout, taps, cin, _stream()), "ps_weight_transpose")
 
 
+def copy_rows(src: Tensor, dst: Tensor) -> None:
+    """dst[r, :] = src[r, :] for 2-d views with unit inner stride and arbitrary row pitches (same dtype, same shape)."""
+    _require_gpu(src, dst)
+    assert src.dim() == 2 and src.shape == dst.shape and src.dtype == dst.dtype and src.stride(1) == 1 and dst.stride(1) == 1
+    es = src.element_size()
+    lib = _lib.load()
+    _lib.check(lib.ps_copy_rows(src.data_ptr(), src.stride(0) * es, dst.data_ptr(), dst.stride(0) * es, src.shape[0], src.shape[1] * es, _stream()),
+               "ps_copy_rows")
+
+
 def cast_f32_bf16(src: Tensor, dst: Tensor) -> None:
     _require_gpu(src, dst)
     assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()

@@ -118,6 +118,8 @@ class Net(nn.Module):
         for m in self.modules():
             if isinstance(m, nn.Conv2d) and m is not self.conv1a:
                 _channels_last_(m)
+        self.fuse_bottleneck = True       # shortcut conv + last 1x1 of a bottleneck unit (and their dgrads) as one K-concatenated GEMM
+        self._out_grad_buf: Dict[str, Tensor] = {}  # unit name -> [N,H,W, cout + cout/4] buffer whose first cout channels hold dL/d(unit output)
         self._cache: Dict[str, Tuple] = {}
         self._weights_epoch = 0           # bumped by code that rewrites parameter memory behind torch's back
         self._bf16_shadow: Dict[str, Tensor] = {}  # param name -> bf16 W_fwd view kept fresh by the fused optimiser
@@ -203,6 +205,46 @@ class Net(nn.Module):
 
         return self._cached("wd:" + key, (w,), make)
 
+    def w_fwd_cat(self, unit: "ResBlock_bot", name: str) -> Tensor:
+        """[cout][cin + cout/2]: conv_branch1 and conv_branch2b2 side by side along K, so that
+        `branch1(a) + branch2b2(a3)` (resnet38d.py:76-97) is one 1x1 conv over the concatenated activation [a | a3]."""
+        w1, w2 = unit.conv_branch1.weight, unit.conv_branch2b2.weight
+        cout, cin, c2 = w1.shape[0], w1.shape[1], w2.shape[1]
+
+        def make():
+            out = torch.empty((cout, cin + c2), device=w1.device, dtype=self.compute_dtype)
+            ops.copy_rows(self.w_fwd(unit.conv_branch1, name + ".conv_branch1").reshape(cout, cin), out[:, :cin])
+            ops.copy_rows(self.w_fwd(unit.conv_branch2b2, name + ".conv_branch2b2").reshape(cout, c2), out[:, cin:])
+            return out
+
+        return self._cached("wfc:" + name, (w1, w2), make)
+
+    def w_dgrad_cat(self, unit: "ResBlock_bot", name: str) -> Tensor:
+        """[cin][cout + cout/4]: the transposed conv_branch1 and conv_branch2a side by side along K (both read the unit's activated
+        input): d/da = W1^T G + W2a^T g2 is one 1x1 data gradient over the concatenated gradient [G | g2]."""
+        w1, w2 = unit.conv_branch1.weight, unit.conv_branch2a.weight
+        cout, cin, c4 = w1.shape[0], w1.shape[1], w2.shape[0]
+
+        def make():
+            out = torch.empty((cin, cout + c4), device=w1.device, dtype=self.compute_dtype)
+            ops.copy_rows(self.w_dgrad(unit.conv_branch1, name + ".conv_branch1").reshape(cin, cout), out[:, :cout])
+            ops.copy_rows(self.w_dgrad(unit.conv_branch2a, name + ".conv_branch2a").reshape(cin, c4), out[:, cout:])
+            return out
+
+        return self._cached("wdc:" + name, (w1, w2), make)
+
+    def alloc_unit_out_grad(self, name: str, n: int, h: int, w: int, device, dtype) -> Tensor:
+        """Buffer for dL/d(output of unit `name`) [N,h,w,cout].  For a bottleneck unit it is the first cout channels of a wider
+        buffer that the reverse plan completes with the branch gradient g2, so the two data gradients into the unit's input run
+        as one GEMM (w_dgrad_cat).  Callers that produce the gradient of the LAST unit's output (head backward) should use this."""
+        u = next(x for x in self.units if x[0] == name)
+        cout = u[4]
+        if u[1] == "bot" and self.fuse_bottleneck:
+            buf = torch.empty((n, h, w, cout + cout // 4), device=device, dtype=dtype)
+            self._out_grad_buf[name] = buf
+            return buf[..., :cout]
+        return torch.empty((n, h, w, cout), device=device, dtype=dtype)
+
     def bn_affine(self, bn: nn.BatchNorm2d, key: str) -> Tuple[Tensor, Tensor]:
         """Eval-mode BN as y = x*scale + shift (f32 per-channel vectors; BN is frozen on this path)."""
 
@@ -255,9 +297,18 @@ class Net(nn.Module):
         def new(hh, ww, c):
             return torch.empty((n, hh, ww, c), device=dev, dtype=dt)
 
+        def new_unit_input(hh, ww, idx):
+            """Activated input of unit idx; for a fused bottleneck unit it is the first cin channels of [a | a3]."""
+            u = self.units[idx]
+            if u[1] == "bot" and self.fuse_bottleneck:
+                wide = new(hh, ww, u[2] + u[4] // 2)
+                return wide[..., :u[2]], wide
+            return new(hh, ww, u[2]), None
+
         first = getattr(self, self.units[0][0])
         sc0, sh0 = self.bn_affine(first.bn_branch2a, self.units[0][0] + ".bn_branch2a")
         a = new(h, w, 64)
+        a_wide = None
         ops.conv1a_fwd(x, self.conv1a.weight.detach().contiguous(), sc0, sh0, a)
         xraw = None
         for i, (name, kind, cin, cmid, cout, stride, fdil, dil, _p) in enumerate(self.units):
@@ -277,12 +328,16 @@ class Net(nn.Module):
                 saved.unit_in[name] = a
                 saved.hw[name] = (h, w)
             same = kind == "res" and unit.same_shape
+            fused = kind == "bot" and a_wide is not None and stride == 1
             if same:
                 shortcut = xraw
-            else:
+            elif not fused:
                 shortcut = new(ho, wo, cout)
                 ops.conv2d_fwd(specs["conv_branch1"], a, self.w_fwd(unit.conv_branch1, name + ".conv_branch1"), out_raw=shortcut)
-            a_next = new(ho, wo, cout)
+            if i + 1 < len(self.units):
+                a_next, a_wide_next = new_unit_input(ho, wo, i + 1)
+            else:
+                a_next, a_wide_next = new(ho, wo, cout), None
             xraw_next = new(ho, wo, cout) if need_raw else None
             if kind == "res":
                 s1, b1 = self.bn_affine(unit.bn_branch2b1, name + ".bn_branch2b1")
@@ -298,14 +353,18 @@ class Net(nn.Module):
                 s2, b2 = self.bn_affine(unit.bn_branch2b2, name + ".bn_branch2b2")
                 a2 = new(ho, wo, cout // 4)
                 ops.conv2d_fwd(specs["conv_branch2a"], a, self.w_fwd(unit.conv_branch2a, name + ".conv_branch2a"), bn_scale=s1, bn_shift=b1, drop=d1, out_act=a2)
-                a3 = new(ho, wo, cout // 2)
+                a3 = a_wide[..., cin:] if fused else new(ho, wo, cout // 2)
                 ops.conv2d_fwd(specs["conv_branch2b1"], a2, self.w_fwd(unit.conv_branch2b1, name + ".conv_branch2b1"), bn_scale=s2, bn_shift=b2, drop=d2, out_act=a3)
-                ops.conv2d_fwd(specs["conv_branch2b2"], a3, self.w_fwd(unit.conv_branch2b2, name + ".conv_branch2b2"), add0=shortcut,
-                               out_raw=xraw_next, bn_scale=nscale, bn_shift=nshift, out_act=a_next)
+                if fused:  # branch1(a) + branch2b2(a3) = one 1x1 conv over [a | a3]: no shortcut tensor, no residual read
+                    ops.conv2d_fwd(ConvSpec(cin + cout // 2, cout, 1), a_wide, self.w_fwd_cat(unit, name),
+                                   out_raw=xraw_next, bn_scale=nscale, bn_shift=nshift, out_act=a_next)
+                else:
+                    ops.conv2d_fwd(specs["conv_branch2b2"], a3, self.w_fwd(unit.conv_branch2b2, name + ".conv_branch2b2"), add0=shortcut,
+                                   out_raw=xraw_next, bn_scale=nscale, bn_shift=nshift, out_act=a_next)
                 if saved is not None:
                     saved.mid[name] = (a2, a3)
                     saved.drop[name + ".dropout_2b1"], saved.drop[name + ".dropout_2b2"] = d1, d2
-            a, xraw, h, w = a_next, xraw_next, ho, wo
+            a, a_wide, xraw, h, w = a_next, a_wide_next, xraw_next, ho, wo
         feats["conv6"] = a
         if saved is not None:
             saved.conv6 = a
@@ -329,6 +388,7 @@ class Net(nn.Module):
         g_taps = g_taps or {}
         first = self.first_trainable_unit()
         G = g_x7
+        self._out_grad_buf = {k: v for k, v in self._out_grad_buf.items() if k == self.units[-1][0]}  # drop stale buffers of aborted steps
         dt, dev, n = G.dtype, G.device, saved.n
         for i in range(len(self.units) - 1, -1, -1):
             name, kind, cin, cmid, cout, stride, fdil, dil, _p = self.units[i]
@@ -379,22 +439,31 @@ class Net(nn.Module):
                 d1, d2 = saved.drop[name + ".dropout_2b1"], saved.drop[name + ".dropout_2b2"]
                 s1, _ = self.bn_affine(unit.bn_branch2b1, name + ".bn_branch2b1")
                 s2, _ = self.bn_affine(unit.bn_branch2b2, name + ".bn_branch2b2")
+                # G may be the first cout channels of a [G | g2] buffer (alloc_unit_out_grad): then both data gradients into the
+                # unit's input run as one GEMM over the concatenated channels
+                GG = self._out_grad_buf.pop(name, None)
+                fused = GG is not None and GG.data_ptr() == G.data_ptr() and stride == 1 and tuple(GG.shape[:3]) == (n, ho, wo)
                 wgrad("conv_branch2b2", a3, G)
                 g3 = new(ho, wo, cout // 2)
                 ops.conv2d_dgrad(specs["conv_branch2b2"], G, self.w_dgrad(unit.conv_branch2b2, name + ".conv_branch2b2"), (ho, wo),
                                  mask_src=a3, bn_scale=s2, drop=d2, out=g3)
                 wgrad("conv_branch2b1", a2, g3)
-                g2 = new(ho, wo, cout // 4)
+                g2 = GG[..., cout:] if fused else new(ho, wo, cout // 4)
                 ops.conv2d_dgrad(specs["conv_branch2b1"], g3, self.w_dgrad(unit.conv_branch2b1, name + ".conv_branch2b1"), (ho, wo),
                                  mask_src=a2, bn_scale=s1, drop=d1, out=g2)
                 wgrad("conv_branch2a", a, g2)
                 wgrad("conv_branch1", a, G)
                 if need_dx:
-                    t = new(h, w, cin)
-                    ops.conv2d_dgrad(specs["conv_branch1"], G, self.w_dgrad(unit.conv_branch1, name + ".conv_branch1"), (h, w), add0=tap, out_raw=t)
-                    Gp = new(h, w, cin)
-                    ops.conv2d_dgrad(specs["conv_branch2a"], g2, self.w_dgrad(unit.conv_branch2a, name + ".conv_branch2a"), (h, w),
-                                     add0=t, mask_src=a, bn_scale=s_in, out=Gp)
+                    prev = self.units[i - 1][0]
+                    Gp = self.alloc_unit_out_grad(prev, n, h, w, dev, dt)
+                    if fused:
+                        ops.conv2d_dgrad(ConvSpec(cin, cout + cout // 4, 1), GG, self.w_dgrad_cat(unit, name), (h, w),
+                                         add0=tap, mask_src=a, bn_scale=s_in, out=Gp)
+                    else:
+                        t = new(h, w, cin)
+                        ops.conv2d_dgrad(specs["conv_branch1"], G, self.w_dgrad(unit.conv_branch1, name + ".conv_branch1"), (h, w), add0=tap, out_raw=t)
+                        ops.conv2d_dgrad(specs["conv_branch2a"], g2, self.w_dgrad(unit.conv_branch2a, name + ".conv_branch2a"), (h, w),
+                                         add0=t, mask_src=a, bn_scale=s_in, out=Gp)
                     G = Gp
             if after_unit is not None:
                 after_unit(name)

@@ -51,7 +51,7 @@ class ResNet38dSeg(resnet38d.Net):
         dcam = torch.empty((n, g1, g2, self.classes), device=conv6.device, dtype=torch.float32)
         ops.bilinear_bwd(dlogits.contiguous(), "nchw", dcam, "nhwc", True)
         scale7, _ = self.bn_affine(self.bn7, "bn7")
-        g_x7 = torch.empty_like(conv6)
+        g_x7 = self.alloc_unit_out_grad(self.units[-1][0], n, g1, g2, conv6.device, conv6.dtype)  # [G | g2] buffer of the last unit
         ops.fc8_bwd(conv6, self.fc8.weight.detach().reshape(self.classes, 4096), drop7, scale7, dcam, g_x7, dw8)
         return g_x7
 
