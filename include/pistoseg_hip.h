@@ -126,7 +126,9 @@ int ps_cast_f32_lowp(const float* src, void* dst, int32_t dst_dtype, int64_t n, 
 
 /* conv1a: 3x3, 3 -> 64, stride 1, pad 1, reads the reference's NCHW f32 image, writes channels-last
  * activation out[m,c] = max(conv*scale[c]+shift[c], 0) (b2.bn_branch2a fused) and/or the raw conv.
- * replaces: models/resnet38d.py:123,161 (+ :28-29 of the first ResBlock).  w: f32 [64][3][3][3] (OIHW). */
+ * replaces: models/resnet38d.py:123,161 (+ :28-29 of the first ResBlock).  w: f32 [64][3][3][3] (OIHW).
+ * PS_F32 output: exact-f32 MFMA; PS_BF16 / PS_F16 output: image and weights are rounded to the storage type (f32 accumulate), like every
+ * other convolution of the 16-bit paths. */
 int ps_conv1a_fwd(int32_t out_dtype, const float* x_nchw, const float* w_oihw, const float* scale, const float* shift,
                   void* out_act, void* out_raw, int32_t n, int32_t h, int32_t w, void* stream);
 

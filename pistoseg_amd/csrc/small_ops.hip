@@ -79,6 +79,83 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const float* __restrict__ x
   }
 }
 
+// conv1a for the 16-bit paths: ONE 16x16x32 MFMA per 16 pixels x 16 couts (K = 27 taps padded to 32) with operands rounded to the
+// storage type, instead of 7 exact-f32 16x16x4 MFMAs: the f32 form is matrix-pipe-bound (28 x 32 cycles per 16 pixels, 330 us at
+// bs = 64), this one leaves only the 64-channel store stream.  Lane (g, col) supplies k = 8g .. 8g+7 of weight row cout(f, col)
+// and of pixel col's im2col row.
+template <typename T, bool F16>
+__global__ __launch_bounds__(256) void conv1a_lowp_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          T* __restrict__ out_act, T* __restrict__ out_raw, int n, int h, int wd) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, col = lane & 15;
+  typedef T t8 __attribute__((ext_vector_type(8)));
+  t8 wa[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int co = 16 * (col >> 2) + 4 * f + (col & 3);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 8 * g + e;
+      wa[f][e] = static_cast<T>(k < 27 ? w[co * 27 + k] : 0.f);
+    }
+  }
+  float sc[16], sh[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    sc[i] = scale ? scale[16 * g + i] : 1.f;
+    sh[i] = shift ? shift[16 * g + i] : 0.f;
+  }
+  int toff[8], tdy[8], tdx[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 8 * g + e, c = k / 9, r = k - 9 * c, ky = r / 3, kx = r - 3 * ky;
+    tdy[e] = k < 27 ? ky - 1 : (1 << 20);
+    tdx[e] = kx - 1;
+    toff[e] = c * h * wd;
+  }
+  const long long total = (long long)n * h * wd;
+  const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+  for (long long p0 = wave_id * 16; p0 < total; p0 += nwaves * 16) {
+    const long long pix = p0 + col;
+    const bool live = pix < total;
+    const int img = live ? (int)(pix / ((long long)h * wd)) : 0;
+    const int rem = live ? (int)(pix - (long long)img * h * wd) : 0;
+    const int y = rem / wd, xx = rem - y * wd;
+    const float* xb = x + (long long)img * 3 * h * wd;
+    t8 bv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int yy = y + tdy[e], xs = xx + tdx[e];
+      float v = 0.f;
+      if (live && yy >= 0 && yy < h && xs >= 0 && xs < wd) v = xb[toff[e] + yy * wd + xs];
+      bv[e] = static_cast<T>(v);
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      acc[f] = f32x4{0, 0, 0, 0};
+      if constexpr (F16) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wa[f]), __builtin_bit_cast(f16x8, bv), acc[f], 0, 0, 0);
+      else acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[f]), __builtin_bit_cast(bf16x8, bv), acc[f], 0, 0, 0);
+    }
+    if (!live) continue;
+    float v[16];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[4 * f + r] = acc[f][r];
+    if (out_raw) {
+      ps_store8<T>(out_raw + pix * 64 + 16 * g, v);
+      ps_store8<T>(out_raw + pix * 64 + 16 * g + 8, v + 8);
+    }
+    if (out_act) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i] * sc[i] + sh[i], 0.f);
+      ps_store8<T>(out_act + pix * 64 + 16 * g, v);
+      ps_store8<T>(out_act + pix * 64 + 16 * g + 8, v + 8);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // fc8 forward: cam[m,c] = sum_k x[m,k]*drop[n,k]*w[c,k].  One wave per 8 pixels; a lane owns 8 channels
 // of every 512-channel chunk (weights for the chunk live in registers across the 8 pixels).
@@ -355,9 +432,9 @@ extern "C" int ps_conv1a_fwd(int32_t out_dtype, const float* x, const float* w, 
   const int grid = grid_for(pix, 64, 256 * 8);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (out_dtype == PS_BF16)
-    hipLaunchKernelGGL(conv1a_kernel<__bf16>, dim3(grid), dim3(256), 0, s, x, w, scale, shift, (__bf16*)out_act, (__bf16*)out_raw, n, h, wd);
+    hipLaunchKernelGGL((conv1a_lowp_kernel<__bf16, false>), dim3(grid), dim3(256), 0, s, x, w, scale, shift, (__bf16*)out_act, (__bf16*)out_raw, n, h, wd);
   else if (out_dtype == PS_F16)
-    hipLaunchKernelGGL(conv1a_kernel<_Float16>, dim3(grid), dim3(256), 0, s, x, w, scale, shift, (_Float16*)out_act, (_Float16*)out_raw, n, h, wd);
+    hipLaunchKernelGGL((conv1a_lowp_kernel<_Float16, true>), dim3(grid), dim3(256), 0, s, x, w, scale, shift, (_Float16*)out_act, (_Float16*)out_raw, n, h, wd);
   else if (out_dtype == PS_F32)
     hipLaunchKernelGGL(conv1a_kernel<float>, dim3(grid), dim3(256), 0, s, x, w, scale, shift, (float*)out_act, (float*)out_raw, n, h, wd);
   else

@@ -79,6 +79,9 @@ class BucketedAllReduce:
             _, s, e = self.buckets[self._next]
             self._launch(s, e)
             self._next += 1
+        # every earlier bucket already reduced (non-blocking query)?  then the conv kernels have the GPU to themselves again
+        if self._sharing and all(w.is_completed() for w in self._pending):
+            self._share_gpu(False)
 
     def finish(self) -> None:
         """Flush buckets whose closing unit was never reported (frozen units), then wait for everything."""
