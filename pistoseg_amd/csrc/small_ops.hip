@@ -161,24 +161,22 @@ __global__ __launch_bounds__(256) void conv1a_lowp_kernel(const float* __restric
 // of every 512-channel chunk (weights for the chunk live in registers across the 8 pixels).
 // ------------------------------------------------------------------------------------------------
 constexpr int FC8_MAXC = 8;
-template <typename T>
+template <typename T, int C>  // C = number of classes (compile time: the per-class accumulators and weights live in registers)
 __global__ __launch_bounds__(256) void fc8_fwd_kernel(const T* __restrict__ x, int ldc, const float* __restrict__ w, int ldw,
                                                       const float* __restrict__ bias, const float* __restrict__ drop,
-                                                      float* __restrict__ cam, int accumulate, int M, int ppi, int K, int C) {
+                                                      float* __restrict__ cam, int accumulate, int M, int ppi, int K) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m0 = (blockIdx.x * 4 + wave) * 8;
   if (m0 >= M) return;
-  float acc[8][FC8_MAXC];
+  float acc[8][C];
 #pragma unroll
   for (int p = 0; p < 8; ++p)
 #pragma unroll
-    for (int c = 0; c < FC8_MAXC; ++c) acc[p][c] = 0.f;
+    for (int c = 0; c < C; ++c) acc[p][c] = 0.f;
   for (int k0 = lane * 8; k0 < K; k0 += 512) {
-    float wv[FC8_MAXC][8];
+    float wv[C][8];
 #pragma unroll
-    for (int c = 0; c < FC8_MAXC; ++c) {
-      if (c < C) ps_load8<float>(w + (long long)c * ldw + k0, wv[c]);
-    }
+    for (int c = 0; c < C; ++c) ps_load8<float>(w + (long long)c * ldw + k0, wv[c]);
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const int m = m0 + p;
@@ -192,24 +190,20 @@ __global__ __launch_bounds__(256) void fc8_fwd_kernel(const T* __restrict__ x, i
         for (int i = 0; i < 8; ++i) xv[i] *= dv[i];
       }
 #pragma unroll
-      for (int c = 0; c < FC8_MAXC; ++c) {
-        if (c < C) {
+      for (int c = 0; c < C; ++c) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) acc[p][c] = fmaf(xv[i], wv[c][i], acc[p][c]);
-        }
+        for (int i = 0; i < 8; ++i) acc[p][c] = fmaf(xv[i], wv[c][i], acc[p][c]);
       }
     }
   }
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
 #pragma unroll
-    for (int c = 0; c < FC8_MAXC; ++c) {
-      if (c < C) {
-        const float s = ps_wave_sum(acc[p][c]);
-        if (lane == 0 && m0 + p < M) {
-          float* o = cam + (long long)(m0 + p) * C + c;
-          *o = (accumulate ? *o : 0.f) + s + (bias ? bias[c] : 0.f);
-        }
+    for (int c = 0; c < C; ++c) {
+      const float s = ps_wave_sum(acc[p][c]);
+      if (lane == 0 && m0 + p < M) {
+        float* o = cam + (long long)(m0 + p) * C + c;
+        *o = (accumulate ? *o : 0.f) + s + (bias ? bias[c] : 0.f);
       }
     }
   }
@@ -217,21 +211,21 @@ __global__ __launch_bounds__(256) void fc8_fwd_kernel(const T* __restrict__ x, i
 
 // fc8 backward (+ ReLU(bn7) mask): a thread owns 8 channels and walks a pixel range, four pixels per iteration so
 // that four 16-byte activation loads are in flight per lane (eight per lane / shorter ranges measured slower: 750 vs 437 us) (the kernel is a pure stream: read x, write dx).
-template <typename T>
+template <typename T, int C>
 __global__ __launch_bounds__(256) void fc8_bwd_kernel(const T* __restrict__ x, int ldc, const float* __restrict__ w,
                                                       const float* __restrict__ drop, const float* __restrict__ scale7,
                                                       const float* __restrict__ dcam, T* __restrict__ dx, int ldc_dx,
-                                                      float* __restrict__ dw, int M, int ppi, int K, int C, int pix_per_block) {
+                                                      float* __restrict__ dw, int M, int ppi, int K, int pix_per_block) {
   const int kblocks = K / 2048;
   const int kb = blockIdx.x % kblocks, mb = blockIdx.x / kblocks;
   const int k0 = kb * 2048 + threadIdx.x * 8;
   const int ma = mb * pix_per_block, me = min(M, ma + pix_per_block);
-  float wv[FC8_MAXC][8], gw[FC8_MAXC][8], s7[8];
+  float wv[C][8], gw[C][8], s7[8];
 #pragma unroll
-  for (int c = 0; c < FC8_MAXC; ++c) {
+  for (int c = 0; c < C; ++c) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) gw[c][i] = 0.f;
-    if (c < C) ps_load8<float>(w + (long long)c * K + k0, wv[c]);
+    ps_load8<float>(w + (long long)c * K + k0, wv[c]);
   }
   ps_load8<float>(scale7 + k0, s7);
   constexpr int U = 4;
@@ -255,14 +249,12 @@ __global__ __launch_bounds__(256) void fc8_bwd_kernel(const T* __restrict__ x, i
 #pragma unroll
       for (int i = 0; i < 8; ++i) g[i] = 0.f;
 #pragma unroll
-      for (int c = 0; c < FC8_MAXC; ++c) {
-        if (c < C) {
-          const float d = dcam[(long long)m * C + c];  // wave-uniform
+      for (int c = 0; c < C; ++c) {
+        const float d = dcam[(long long)m * C + c];  // wave-uniform
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            g[i] = fmaf(d, wv[c][i], g[i]);
-            gw[c][i] = fmaf(d, xv[u][i] * dv[u][i], gw[c][i]);
-          }
+        for (int i = 0; i < 8; ++i) {
+          g[i] = fmaf(d, wv[c][i], g[i]);
+          gw[c][i] = fmaf(d, xv[u][i] * dv[u][i], gw[c][i]);
         }
       }
 #pragma unroll
@@ -271,11 +263,9 @@ __global__ __launch_bounds__(256) void fc8_bwd_kernel(const T* __restrict__ x, i
     }
   }
 #pragma unroll
-  for (int c = 0; c < FC8_MAXC; ++c) {
-    if (c < C) {
+  for (int c = 0; c < C; ++c) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) atomicAdd(dw + (long long)c * K + k0 + i, gw[c][i]);
-    }
+    for (int i = 0; i < 8; ++i) atomicAdd(dw + (long long)c * K + k0 + i, gw[c][i]);
   }
 }
 
@@ -452,14 +442,15 @@ extern "C" int ps_fc_head_fwd(int32_t dtype, const void* x, int32_t ldc_x, const
   PS_REQUIRE(ps_aligned16(x) && ps_aligned16(w) && (ldc_x * ps_esize(dtype)) % 16 == 0, "fc_head_fwd: misaligned input");
   const int grid = (m_total + 31) / 32;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (dtype == PS_BF16)
-    hipLaunchKernelGGL(fc8_fwd_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, ldc_x, w, ldw, bias, drop, cam, accumulate, m_total, ppi, k, c);
-  else if (dtype == PS_F16)
-    hipLaunchKernelGGL(fc8_fwd_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)x, ldc_x, w, ldw, bias, drop, cam, accumulate, m_total, ppi, k, c);
-  else if (dtype == PS_F32)
-    hipLaunchKernelGGL(fc8_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ldc_x, w, ldw, bias, drop, cam, accumulate, m_total, ppi, k, c);
-  else
-    PS_REQUIRE(false, "fc_head_fwd: dtype %d unsupported", dtype);
+  PS_REQUIRE(ps_dtype_ok(dtype), "fc_head_fwd: dtype %d unsupported", dtype);
+#define PS_FC8_FWD(CC)                                                                                                                     \
+  case CC:                                                                                                                                 \
+    if (dtype == PS_BF16) hipLaunchKernelGGL((fc8_fwd_kernel<__bf16, CC>), dim3(grid), dim3(256), 0, s, (const __bf16*)x, ldc_x, w, ldw, bias, drop, cam, accumulate, m_total, ppi, k); \
+    else if (dtype == PS_F16) hipLaunchKernelGGL((fc8_fwd_kernel<_Float16, CC>), dim3(grid), dim3(256), 0, s, (const _Float16*)x, ldc_x, w, ldw, bias, drop, cam, accumulate, m_total, ppi, k); \
+    else hipLaunchKernelGGL((fc8_fwd_kernel<float, CC>), dim3(grid), dim3(256), 0, s, (const float*)x, ldc_x, w, ldw, bias, drop, cam, accumulate, m_total, ppi, k); \
+    break;
+  switch (c) { PS_FC8_FWD(1) PS_FC8_FWD(2) PS_FC8_FWD(3) PS_FC8_FWD(4) PS_FC8_FWD(5) PS_FC8_FWD(6) PS_FC8_FWD(7) PS_FC8_FWD(8) }
+#undef PS_FC8_FWD
   PS_CHECK_LAUNCH("fc_head_fwd");
   return PS_OK;
 }
@@ -480,17 +471,15 @@ extern "C" int ps_fc8_bwd(int32_t dtype, const void* x, int32_t ldc_x, const flo
   const int ppb = 64;
   const int grid = (k / 2048) * ((m_total + ppb - 1) / ppb);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (dtype == PS_BF16)
-    hipLaunchKernelGGL(fc8_bwd_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, ldc_x, w, drop, scale7, dcam, (__bf16*)dx,
-                       ldc_dx, dw, m_total, ppi, k, c, ppb);
-  else if (dtype == PS_F16)
-    hipLaunchKernelGGL(fc8_bwd_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)x, ldc_x, w, drop, scale7, dcam, (_Float16*)dx,
-                       ldc_dx, dw, m_total, ppi, k, c, ppb);
-  else if (dtype == PS_F32)
-    hipLaunchKernelGGL(fc8_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ldc_x, w, drop, scale7, dcam, (float*)dx,
-                       ldc_dx, dw, m_total, ppi, k, c, ppb);
-  else
-    PS_REQUIRE(false, "fc8_bwd: dtype %d unsupported", dtype);
+  PS_REQUIRE(ps_dtype_ok(dtype), "fc8_bwd: dtype %d unsupported", dtype);
+#define PS_FC8_BWD(CC)                                                                                                                     \
+  case CC:                                                                                                                                 \
+    if (dtype == PS_BF16) hipLaunchKernelGGL((fc8_bwd_kernel<__bf16, CC>), dim3(grid), dim3(256), 0, s, (const __bf16*)x, ldc_x, w, drop, scale7, dcam, (__bf16*)dx, ldc_dx, dw, m_total, ppi, k, ppb); \
+    else if (dtype == PS_F16) hipLaunchKernelGGL((fc8_bwd_kernel<_Float16, CC>), dim3(grid), dim3(256), 0, s, (const _Float16*)x, ldc_x, w, drop, scale7, dcam, (_Float16*)dx, ldc_dx, dw, m_total, ppi, k, ppb); \
+    else hipLaunchKernelGGL((fc8_bwd_kernel<float, CC>), dim3(grid), dim3(256), 0, s, (const float*)x, ldc_x, w, drop, scale7, dcam, (float*)dx, ldc_dx, dw, m_total, ppi, k, ppb); \
+    break;
+  switch (c) { PS_FC8_BWD(1) PS_FC8_BWD(2) PS_FC8_BWD(3) PS_FC8_BWD(4) PS_FC8_BWD(5) PS_FC8_BWD(6) PS_FC8_BWD(7) PS_FC8_BWD(8) }
+#undef PS_FC8_BWD
   PS_CHECK_LAUNCH("fc8_bwd");
   return PS_OK;
 }
