@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
     ap.add_argument("--cpu-tiles", type=int, default=2)
+    ap.add_argument("--workload", default="seg", choices=["seg", "rfm"],
+                    help="seg: BASELINE configs[1]/[4] (segmentation_train.py step, the headline metric); rfm: configs[3], the stage-3 step "
+                         "(revise_pseudo_labels.py train_epoch body: RFM net, cls + rfm + ecr losses, PolyOptimizer)")
     return ap.parse_args()
 
 
@@ -143,6 +146,40 @@ def cpu_baseline(tiles, tile, classes):
             "infer_value": round(tiles / dti, 4)}
 
 
+def rfm_bench(args, world, rank, dev, dist_on):
+    """BASELINE configs[3]: stage-3 training step (RFM net + feature-consistency losses + PolyOptimizer), DDP buckets as for seg."""
+    from pistoseg_amd.revise_net import Net
+    from pistoseg_amd.trainer import RFMTrainer, init_weights_he
+
+    c = args.classes + 1  # n_class + background (revise_pseudo_labels.py:169)
+    model = Net(c, precision=args.precision)
+    init_weights_he(model, seed=42)
+    model = model.to(dev)
+    tr = RFMTrainer(model, lr=0.01, wt_dec=5e-4, max_step=10 ** 6, process_group=torch.distributed.group.WORLD if dist_on else None)
+    g = torch.Generator(device="cpu").manual_seed(4321 + rank)
+    n = args.batch
+    x = torch.randn(n, 3, args.tile, args.tile, generator=g).to(dev)
+    pmask = torch.cat([torch.zeros(n, 1, 32, 32), torch.randn(n, c - 1, 32, 32, generator=g)], 1).to(dev)
+    pcam = torch.cat([torch.zeros(n, 1, 32, 32), torch.randn(n, c - 1, 32, 32, generator=g)], 1).to(dev)
+    lab = (torch.rand(n, c - 1, generator=g) < 0.5).float()
+    lab[torch.arange(n), torch.randint(0, c - 1, (n,), generator=g)] = 1.0
+    label = torch.cat([torch.ones(n, 1), lab], 1).to(dev)
+    step = lambda: tr.train_step(x, pmask, pcam, label)
+    for _ in range(args.warmup):
+        step()
+    dt = timed(step, args.steps, dist_on)
+    if dist_on:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "224x224 tiles/sec (RFM stage-3 train fwd+bwd+opt)", "value": round(world * n * args.steps / dt, 2), "unit": "tiles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[3]: revise_pseudo_labels.py train_epoch step, RFM net C={c}, cls+rfm+ecr losses, PolyOptimizer",
+                       "per_gpu_batch": n, "global_batch": n * world, "tile": args.tile, "parallelism": f"dp{world}"}}))
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -168,6 +205,8 @@ def main():
     from pistoseg_amd.trainer import SegTrainer, init_weights_he
 
     dev = torch.device("cuda", local_rank)
+    if args.workload == "rfm":
+        return rfm_bench(args, world, rank, dev, dist_on)
     model = ResNet38dSeg(classes=args.classes, precision=args.precision)
     init_weights_he(model, seed=42)
     model = model.to(dev)

@@ -409,9 +409,11 @@ __global__ __launch_bounds__(256) void minpool_bwd_kernel(const float* __restric
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long img = i / hw, pix = i - img * hw;
     const float v = m[i], th = thr[img];
+    if (!(v > 0.f)) continue;  // relu: no gradient -- and no tie ticket: the threshold is usually 0 with tens of thousands of ties, and a
+                               // returning atomic per tie on one address per image serialised the whole kernel (11 ms at bs = 32)
     bool sel = v < th;
     if (!sel && v == th) sel = atomicAdd(&tie_counter[img], 1) < take[img];
-    if (!sel || !(v > 0.f)) continue;
+    if (!sel) continue;
     const int k = arg[i];
     dx[(img * c + k) * hw + pix] += gscale * label[img * c + k];
   }
