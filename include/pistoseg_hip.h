@@ -348,7 +348,8 @@ void ps_debug_set_3stage(int on);
 void ps_debug_set_bn(int bn);
 /* Testing hook: 112 / 128 force the pixel-tile height of the 128-cout conv kernel, 0 (default) picks the better-balanced. */
 void ps_debug_set_bm(int bm);
-/* Timing experiments only (results become WRONG): 1 = the conv kernel stages its first two K-steps and then stops loading. */
+/* Timing experiments only (results become WRONG): 1 = the conv kernels stage their first K-steps and then stop loading (consumer-only
+ * rate); 3 = the epilogue touches no memory (per-tile store cost). */
 void ps_debug_set_ablate(int v);
 /* Testing hook: 1 = big problems use the experimental 8-wave ping-pong conv kernel, 0 (default) = never, 2 = always (cout % 128 == 0). */
 void ps_debug_set_pp(int v);

@@ -22,6 +22,7 @@ struct IgemmArgs {
   const unsigned char* src;   // gathered activation (forward: x, dgrad: dy)
   const unsigned char* wgt;   // [Cd][taps][Cs] rows of contiguous K
   int Hs, Ws, Ho, Wo, M;      // source dims, produced grid, produced pixels
+  int epi_M;                  // = M; the epilogue skips pixels >= epi_M (0 under ps_debug_set_ablate(3): timing without any epilogue traffic)
   int mul, dstep, div_shift;  // gather arithmetic (see file header)
   int taps, klines;           // 1|9, Cs*esize/128
   int ctr;                    // centre tap coordinate (0 for 1x1, 1 for 3x3)
@@ -126,7 +127,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = COLMAP ? mbase + (frow & 7) * a.Wo + 2 * mi + (frow >> 3) : mbase + mi * 16 + frow;
-    if (m >= a.M) continue;
+    if (m >= a.epi_M) continue;
     float v[CH];
 #pragma unroll
     for (int i = 0; i < WI; ++i)
@@ -664,7 +665,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const IgemmArgs& a, f32x4 (&ac
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int R = rbase + mi * 16 + frow, m = mbase + mi * 16 + frow;
-    if (m >= a.M) continue;
+    if (m >= a.epi_M) continue;
 #pragma unroll
     for (int o = 0; o < NV; ++o) {
       float v[8];
@@ -1393,6 +1394,7 @@ int set_extents(IgemmArgs& a, long long src_bytes, long long wgt_bytes) {
   a.src_bytes = (unsigned)src_bytes;
   a.wgt_bytes = (unsigned)wgt_bytes;
   a.ablate = g_ablate;
+  a.epi_M = g_ablate == 3 ? 0 : a.M;
   a.supertile = g_supertile;
   return PS_OK;
 }
