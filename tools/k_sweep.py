@@ -8,8 +8,8 @@ n, H = 64, 28
 import argparse
 ap = argparse.ArgumentParser(); ap.add_argument("--ablate", type=int, default=0); args = ap.parse_args()
 lib.ps_debug_set_ablate(args.ablate)
-for cout in (1024,):
-    for cin in (256, 1024, 4096):
+for cout in (1024, 4096):
+    for cin in (256, 512, 1024, 2048, 4096, 8192):
         spec = ops.ConvSpec(cin, cout, 1, 1, 1)
         x = torch.randn(n, H, H, cin, device=D).to(dt); wf = (torch.randn(cout, 1, 1, cin, device=D) * 0.02).to(dt)
         y = torch.empty(n, H, H, cout, device=D, dtype=dt)

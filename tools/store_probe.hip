@@ -39,10 +39,11 @@ __global__ __launch_bounds__(256) void k(unsigned char* out, long long ldc_bytes
 }
 int main() {
   const long long ldc_bytes = 1024;  // 512 channels bf16
-  const int reps = 4, tiles = 256;
-  size_t bytes = (size_t)reps * tiles * 224 * ldc_bytes;
+  const int reps = 4;
+  size_t bytes = (size_t)reps * 256 * 224 * ldc_bytes;
   unsigned char* d; hipMalloc(&d, bytes);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int tiles = 256; tiles >= 16; tiles /= 4)  // fewer blocks = fewer CUs storing at once: per-CU store path vs chip write bandwidth
   for (int shape = 0; shape < 3; ++shape) {
     float best = 1e9;
     for (int it = 0; it < 5; ++it) {
@@ -52,7 +53,7 @@ int main() {
       float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
     }
     double written = (double)reps * tiles * 4 * 14336;
-    printf("shape %d: %.1f us for %.1f MB -> %.2f TB/s, %.2f us per 56-KiB tile per CU\n", shape, best * 1e3, written / 1e6, written / best / 1e9, best * 1e3 / reps);
+    printf("blocks %3d shape %d: %.1f us for %.1f MB -> %.2f TB/s, %.2f us per 56-KiB tile per CU\n", tiles, shape, best * 1e3, written / 1e6, written / best / 1e9, best * 1e3 / reps);
   }
   return 0;
 }
