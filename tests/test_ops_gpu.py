@@ -532,6 +532,65 @@ def test_wgrad_large_tile_persistent_kernel(case, dtype):
         assert rel_err(dw.cpu(), old.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("case", [(512, 512, 3, 1, 28), (1024, 2048, 3, 4, 28), (256, 256, 3, 1, 56), (2048, 4096, 1, 1, 28)])
+def test_full_size_layers_kernel_families_agree(case):
+    """BASELINE-size layers (bs = 64, bf16), too big for a CPU reference inside the suite: size-independent checks instead.
+    (1) the production kernel for the layer (halo / large-tile) against the small-tile two-blocks-per-CU family on the same data --
+    different tilings, staging and (halo) K order, so agreement within bf16 output rounding is strong evidence for both;
+    (2) linearity of the forward in its input; (3) <dy, conv(x)> == <dgrad(dy), x> == <wgrad(x, dy), w> (adjoint identities, f32 sums)."""
+    from pistoseg_amd import _lib, ops
+
+    lib = _lib.load()
+    cin, cout, k, d, hw = case
+    n, dtype, D = 64, torch.bfloat16, dev()
+    g = torch.Generator(device="cpu").manual_seed(cin + cout + k)
+    x = torch.randn(n, hw, hw, cin, generator=g).to(D, dtype)
+    gy = torch.randn(n, hw, hw, cout, generator=g).to(D, dtype)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k)) ** 0.5
+    wf, wd = w_fwd_layout(wt).to(D, dtype), w_dgrad_layout(wt).to(D, dtype)
+    spec = ops.ConvSpec(cin, cout, k, 1, d)
+
+    def run(xin):
+        y = torch.empty((n, hw, hw, cout), device=D, dtype=dtype)
+        ops.conv2d_fwd(spec, xin, wf, out_raw=y)
+        return y
+
+    def run_bwd():
+        gx = torch.empty((n, hw, hw, cin), device=D, dtype=dtype)
+        ops.conv2d_dgrad(spec, gy, wd, (hw, hw), out_raw=gx)
+        dw = torch.zeros((cout, k, k, cin), device=D, dtype=torch.float32)
+        ops.conv2d_wgrad(spec, x, gy, dw)
+        return gx, dw
+
+    y, (gx, dw) = run(x), run_bwd()
+    try:
+        lib.ps_debug_set_halo(0)
+        lib.ps_debug_set_ws2(0)
+        lib.ps_debug_set_wgrad_ws2(0)
+        y_small, (gx_small, dw_small) = run(x), run_bwd()
+    finally:
+        lib.ps_debug_set_halo(1)
+        lib.ps_debug_set_ws2(WS2_DEFAULT)
+        lib.ps_debug_set_wgrad_ws2(1)
+    assert rel_err(y.float(), y_small.float()) < 8e-3 and rel_err(gx.float(), gx_small.float()) < 8e-3  # one bf16 ulp of the largest output
+    assert float((y.float() - y_small.float()).abs().mean() / y_small.float().abs().mean()) < 1e-3
+    assert rel_err(dw, dw_small) < 1e-4
+    # linearity: conv(x + 2 x2) == conv(x) + 2 conv(x2) up to output rounding
+    x2 = torch.randn(n, hw, hw, cin, generator=g).to(D, dtype)
+    lhs = run((x.float() + 2 * x2.float()).to(dtype)).float()
+    rhs = y.float() + 2 * run(x2).float()
+    assert float((lhs - rhs).abs().mean() / rhs.abs().mean()) < 2e-2
+    # adjoint identities <dy, conv(x)> == <dgrad(dy), x> == <wgrad(x, dy), w>, f64 sums of the stored results.  y and gx carry an
+    # independent bf16 rounding error per element (relative 2^-9 uniform): 6 sigma of the resulting error of each inner product
+    def ip(a_, b_):
+        p_ = a_.double() * b_.double()
+        return float(p_.sum()), float((p_ * p_).sum()) ** 0.5 * 2.0 ** -9
+    (a1, s1), (a2, s2) = ip(gy, y), ip(gx, x)
+    a3 = float((dw.double() * wf.double()).sum())  # dw is f32: no storage rounding
+    assert abs(a1 - a2) < 6 * (s1 + s2), (a1, a2, s1, s2)
+    assert abs(a1 - a3) < 6 * s1 + 1e-4 * abs(a3), (a1, a3, s1)
+
+
 @pytest.mark.parametrize("tpb", [1, 2, 5])
 def test_persistent_kernels_batched_work_split_is_exact(tpb):
     """ps_set_tiles_per_block(n): the persistent kernels' blocks are dispatched in batches and take n work items each (used while
