@@ -1,0 +1,39 @@
+"""bench.py's one-line JSON contract (driver-facing), on a tiny configuration: keys, types, the roofline / cpu_baseline objects."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args):
+    # a child process (bench.py initialises the GPU itself; never exec over an initialised parent)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_json_contract_small_config():
+    d = run_bench("--batch", "2", "--tile", "64", "--steps", "2", "--warmup", "1", "--cpu-tiles", "1")
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                 ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
+        assert isinstance(d[k], t), (k, d[k])
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["unit"] == "tiles/s" and d["value"] > 0 and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("mfma", "hbm") and r["unit"] in ("TFLOP/s", "GB/s") and r["peak"] > 0 and r["achieved"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r and "kernel" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["unit"] == "tiles/s" and c["value"] > 0 and c["cores"] >= 1 and isinstance(c["sample"], str)
+
+
+def test_bench_rfm_workload_runs():
+    d = run_bench("--workload", "rfm", "--batch", "2", "--tile", "64", "--steps", "2", "--warmup", "1")
+    assert d["value"] > 0 and "configs[3]" in d["config"]["workload"] and d["n_gpus"] == 1
