@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
 template <typename Tr>
 __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs a) {
   typedef typename Tr::elem T;
-  constexpr int BM = 224, BN = 128, MI = 7, WI = 4, WN = 64, TW = 28, TR = 8;  // tile = 8 rows x 28 columns
+  constexpr int BN = 128, MI = 7, WI = 4, WN = 64, TW = 28, TR = 8;  // tile = 8 rows x 28 columns = 224 pixels
   constexpr int WJ = 9, WIN_BYTES = WJ * 4 * 1024, B_BYTES = BN * 128;
   constexpr int W_OFF = 2 * WIN_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
