@@ -15,7 +15,7 @@ from typing import Optional
 import torch  # noqa: F401  (side effect: loads the HIP runtime torch uses)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpistoseg_hip.so")
+LIB_PATH = os.environ.get("PISTOSEG_HIP_LIB") or os.path.join(HERE, "libpistoseg_hip.so")  # override: A/B-testing another build
 
 PS_F32, PS_BF16, PS_F16 = 0, 1, 2
 PS_EPI_NONE, PS_EPI_BNRELU, PS_EPI_RELUBWD = 0, 1, 2

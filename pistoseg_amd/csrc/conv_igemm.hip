@@ -13,6 +13,7 @@
 //     operand, so a lane's 4 accumulator registers are 4 consecutive couts of ONE pixel; the cout rows
 //     are permuted while staging so that each lane ends up with 16 contiguous couts -> 16-byte stores.
 #include "ps_internal.h"
+#include <type_traits>
 
 namespace {
 
@@ -102,71 +103,191 @@ constexpr unsigned PAD_ROW = 0x80000000u;
 // CH = 4*WI contiguous produced channels cbase + CH*g .. (acc[mi][i][r] = channel 4*i + r of that group).
 // COLMAP (halo kernel): fragment mi holds an 8-row x 2-column patch of the tile instead of 16 consecutive pixels:
 // pixel = mbase + (frow & 7) * Wo + 2 * mi + (frow >> 3).
-template <typename T, int MI, int WI, bool COLMAP = false>
-__device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[MI][WI], int mbase, int cbase, int lane) {
-  constexpr int CH = 4 * WI;  // 16 or 8
-  const int frow = lane & 15, g = lane >> 4;
-  const ps_epilogue& e = a.epi;
-  const int cb = cbase + CH * g;
-  float sc[CH], sh[CH];
-  if (e.mode != PS_EPI_NONE) {
+// Eight consecutive tensor elements as loaded through a buffer descriptor (no conversion until they are needed).
+template <typename T>
+struct Raw8 {
+  static constexpr int NQ = sizeof(T) / 2;  // 16-byte quads
+  u32x4 q[NQ];
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int voff) {
 #pragma unroll
-    for (int i = 0; i < CH; ++i) {
-      sc[i] = e.scale ? e.scale[cb + i] : 1.f;
-      sh[i] = (e.shift && e.mode == PS_EPI_BNRELU) ? e.shift[cb + i] : 0.f;
+    for (int k = 0; k < NQ; ++k) q[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16 * k, 0, 0);
+  }
+  __device__ __forceinline__ void unpack(float* v) const {
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = __uint_as_float(q[i >> 2][i & 3]);
+    } else if constexpr (std::is_same<T, __bf16>::value) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(q[0][i] << 16);
+        v[2 * i + 1] = __uint_as_float(q[0][i] & 0xffff0000u);
+      }
+    } else {
+      const f16x8 h = __builtin_bit_cast(f16x8, q[0]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = static_cast<float>(h[i]);
     }
   }
-  auto ld = [&](const void* base, long long ldc, int m, float* v) {
+  static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rs, int voff, const float* v) {
+    if constexpr (sizeof(T) == 4) {
 #pragma unroll
-    for (int o = 0; o < CH; o += 8) ps_load8<T>(reinterpret_cast<const T*>(base) + (long long)m * ldc + cb + o, v + o);
-  };
-  auto st = [&](void* base, long long ldc, int m, const float* v) {
-#pragma unroll
-    for (int o = 0; o < CH; o += 8) ps_store8<T>(reinterpret_cast<T*>(base) + (long long)m * ldc + cb + o, v + o);
-  };
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    const int m = COLMAP ? mbase + (frow & 7) * a.Wo + 2 * mi + (frow >> 3) : mbase + mi * 16 + frow;
-    if (m >= a.epi_M) continue;
-    float v[CH];
-#pragma unroll
-    for (int i = 0; i < WI; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[mi][i][r];
-    if (e.add0) {
-      float t[CH];
-      ld(e.add0, e.ldc_add0, m, t);
-#pragma unroll
-      for (int i = 0; i < CH; ++i) v[i] += t[i];
-    }
-    if (e.out_raw) st(e.out_raw, e.ldc_raw, m, v);
-    if (e.mode == PS_EPI_NONE) continue;
-    float dm[CH];
-    if (e.drop) {
-      const int n = m / (a.Ho * a.Wo);
-      const float* d = e.drop + (long long)n * a.Cd + cb;
-#pragma unroll
-      for (int i = 0; i < CH; ++i) dm[i] = d[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < CH; ++i) dm[i] = 1.f;
-    }
-    if (e.mode == PS_EPI_BNRELU) {
-#pragma unroll
-      for (int i = 0; i < CH; ++i) v[i] = fmaxf(v[i] * sc[i] + sh[i], 0.f) * dm[i];
-    } else {  // PS_EPI_RELUBWD
-      float ms[CH];
-      ld(e.mask_src, e.ldc_mask, m, ms);
-#pragma unroll
-      for (int i = 0; i < CH; ++i) v[i] = ms[i] > 0.f ? v[i] * sc[i] * dm[i] : 0.f;
-      if (e.add1) {
-        float t[CH];
-        ld(e.add1, e.ldc_add1, m, t);
-#pragma unroll
-        for (int i = 0; i < CH; ++i) v[i] += t[i];
+      for (int k = 0; k < 2; ++k) {
+        const u32x4 d = {__float_as_uint(v[4 * k]), __float_as_uint(v[4 * k + 1]), __float_as_uint(v[4 * k + 2]), __float_as_uint(v[4 * k + 3])};
+        __builtin_amdgcn_raw_buffer_store_b128(d, rs, voff + 16 * k, 0, 0);
       }
+    } else if constexpr (std::is_same<T, __bf16>::value) {
+      u32x4 d;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) d[i] = ps_f32_to_bf16(v[2 * i]) | (static_cast<uint32_t>(ps_f32_to_bf16(v[2 * i + 1])) << 16);
+      __builtin_amdgcn_raw_buffer_store_b128(d, rs, voff, 0, 0);
+    } else {
+      f16x8 h;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) h[i] = static_cast<_Float16>(v[i]);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, h), rs, voff, 0, 0);
     }
-    st(e.out, e.ldc_out, m, v);
+  }
+};
+
+// Tile epilogue on a wave's MI x WI accumulator fragments: [+ add0] [-> out_raw], then BN+ReLU[+dropout] or the ReLU-backward mask
+// [+ add1] -> out.  Every global LOAD of the MI rows is issued before the first STORE and the arithmetic is done in place on the
+// accumulators: vmcnt counts loads and stores in one in-order queue, so a load issued behind a store cannot be consumed before that
+// store has been acknowledged by L2 -- with one row's loads behind the previous row's stores the epilogue took MI store round trips
+// per tile.  All tensors are addressed through buffer descriptors of epi_M rows: a lane's row offset is one VGPR + a scalar step,
+// rows past the end are dropped by the range check (no predication, no 64-bit address arithmetic), and no load is left pending on
+// any path, so the next tile's first MFMAs need no vmcnt wait.  Layers with dropout (per-row multipliers; b6 / b7 only) keep the
+// row-by-row order.  (f32 tensors: 8 channels at a time to bound the registers.)
+template <typename T, int MI, int WI, bool COLMAP = false, int CW = (sizeof(T) == 2 ? 4 * WI : 8)>
+__device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[MI][WI], int mbase, int cbase, int lane) {
+  constexpr int CH = 4 * WI;  // 16 or 8 channels per lane, handled CW at a time
+  constexpr int NO = CW / 8, ES = (int)sizeof(T);
+  static_assert(CW % 8 == 0 && CH % CW == 0, "channel chunk");
+  const int frow = lane & 15, g = lane >> 4;
+  const ps_epilogue& e = a.epi;
+  const int row0 = COLMAP ? mbase + (frow & 7) * a.Wo + (frow >> 3) : mbase + frow;  // row of fragment mi: row0 + mi * RSTEP
+  constexpr int RSTEP = COLMAP ? 2 : 16;
+  auto rsrc = [&](const void* base, int ldc) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, a.epi_M * ldc * ES, 0x00020000);
+  };
+#pragma unroll
+  for (int c0 = 0; c0 < CH; c0 += CW) {
+    const int cb = cbase + CH * g + c0;
+    float sc[CW], sh[CW];
+#pragma unroll
+    for (int i = 0; i < CW; ++i) {
+      sc[i] = (e.scale && e.mode != PS_EPI_NONE) ? e.scale[cb + i] : 1.f;
+      sh[i] = (e.shift && e.mode == PS_EPI_BNRELU) ? e.shift[cb + i] : 0.f;
+    }
+    // Row loads run LW rows ahead of their use (a row's registers are refilled with row + LW as soon as it has been consumed):
+    // every load still precedes every store, with LW instead of MI rows of operands live.
+    constexpr int LW = MI < 4 ? MI : 4;
+    auto add_rows = [&](const void* base, int ldc) {  // acc += tensor rows
+      const __amdgpu_buffer_rsrc_t rs = rsrc(base, ldc);
+      const int v0 = (row0 * ldc + cb) * ES, step = RSTEP * ldc * ES;
+      Raw8<T> t[LW][NO];
+#pragma unroll
+      for (int mi = 0; mi < LW; ++mi)
+#pragma unroll
+        for (int o = 0; o < NO; ++o) t[mi][o].load(rs, v0 + mi * step + 8 * o * ES);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+          float f[8];
+          t[mi % LW][o].unpack(f);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[mi][(c0 + 8 * o + i) / 4][i & 3] += f[i];
+          if (mi + LW < MI) t[mi % LW][o].load(rs, v0 + (mi + LW) * step + 8 * o * ES);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    auto store_rows = [&](void* base, int ldc, bool bnrelu) {  // bnrelu: max(acc * sc + sh, 0) on the way out (a select, not a branch)
+      const __amdgpu_buffer_rsrc_t rs = rsrc(base, ldc);
+      const int v0 = (row0 * ldc + cb) * ES, step = RSTEP * ldc * ES;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+          float f[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float x = acc[mi][(c0 + 8 * o + i) / 4][i & 3];
+            const float y = fmaxf(x * sc[8 * o + i] + sh[8 * o + i], 0.f);
+            f[i] = bnrelu ? y : x;
+          }
+          Raw8<T>::store(rs, v0 + mi * step + 8 * o * ES, f);
+        }
+    };
+    if (e.add0) add_rows(e.add0, e.ldc_add0);
+    __builtin_amdgcn_sched_barrier(0);  // keep the phases apart: a hoisted second batch of loads would double the live registers
+    // scale / shift have arrived by now; "use" them before the first store so that the compiler's wait for them does not become
+    // a vmcnt(0) behind the stores below
+#pragma unroll
+    for (int i = 0; i < CW; ++i) asm volatile("" ::"v"(sc[i]), "v"(sh[i]));
+    if (e.out_raw) store_rows(e.out_raw, e.ldc_raw, false);
+    if (e.mode == PS_EPI_NONE) continue;  // next channel chunk
+    if (e.drop) {
+      // dropout layers (b6 / b7 only): per-row multipliers, row by row
+      const int hw = a.Ho * a.Wo;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int m = row0 + mi * RSTEP;
+        if (m >= a.epi_M) continue;
+        const float* d = e.drop + (long long)(m / hw) * a.Cd + cb;
+        float v[CW];
+#pragma unroll
+        for (int i = 0; i < CW; ++i) v[i] = acc[mi][(c0 + i) / 4][i & 3];
+        if (e.mode == PS_EPI_BNRELU) {
+#pragma unroll
+          for (int i = 0; i < CW; ++i) v[i] = fmaxf(v[i] * sc[i] + sh[i], 0.f) * d[i];
+        } else {
+          float ms[CW];
+#pragma unroll
+          for (int o = 0; o < NO; ++o) ps_load8<T>(reinterpret_cast<const T*>(e.mask_src) + (long long)m * e.ldc_mask + cb + 8 * o, ms + 8 * o);
+#pragma unroll
+          for (int i = 0; i < CW; ++i) v[i] = ms[i] > 0.f ? v[i] * sc[i] * d[i] : 0.f;
+          if (e.add1) {
+            float t[CW];
+#pragma unroll
+            for (int o = 0; o < NO; ++o) ps_load8<T>(reinterpret_cast<const T*>(e.add1) + (long long)m * e.ldc_add1 + cb + 8 * o, t + 8 * o);
+#pragma unroll
+            for (int i = 0; i < CW; ++i) v[i] += t[i];
+          }
+        }
+#pragma unroll
+        for (int o = 0; o < NO; ++o) ps_store8<T>(reinterpret_cast<T*>(e.out) + (long long)m * e.ldc_out + cb + 8 * o, v + 8 * o);
+      }
+      continue;
+    }
+    if (e.mode == PS_EPI_RELUBWD) {  // in place: acc = mask > 0 ? acc * sc : 0 [+ add1]
+      const __amdgpu_buffer_rsrc_t rs = rsrc(e.mask_src, e.ldc_mask);
+      const int v0 = (row0 * e.ldc_mask + cb) * ES, step = RSTEP * e.ldc_mask * ES;
+      Raw8<T> t[LW][NO];
+#pragma unroll
+      for (int mi = 0; mi < LW; ++mi)
+#pragma unroll
+        for (int o = 0; o < NO; ++o) t[mi][o].load(rs, v0 + mi * step + 8 * o * ES);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+          float ms[8];
+          t[mi % LW][o].unpack(ms);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float x = acc[mi][(c0 + 8 * o + i) / 4][i & 3] * sc[8 * o + i];
+            acc[mi][(c0 + 8 * o + i) / 4][i & 3] = ms[i] > 0.f ? x : 0.f;
+          }
+          if (mi + LW < MI) t[mi % LW][o].load(rs, v0 + (mi + LW) * step + 8 * o * ES);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (e.add1) add_rows(e.add1, e.ldc_add1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    store_rows(e.out, e.ldc_out, e.mode == PS_EPI_BNRELU);
   }
 }
 
@@ -1388,11 +1509,21 @@ int check_epilogue(const ps_epilogue* e, int dtype, const char* who) {
   return PS_OK;
 }
 
-int set_extents(IgemmArgs& a, long long src_bytes, long long wgt_bytes) {
+int set_extents(IgemmArgs& a, long long src_bytes, long long wgt_bytes, int es) {
   // 32-bit buffer offsets; bit 31 marks padding rows
   PS_REQUIRE(src_bytes < (1LL << 31) && wgt_bytes < (1LL << 31), "conv: tensor larger than 2 GiB (%lld / %lld bytes)", src_bytes, wgt_bytes);
   a.src_bytes = (unsigned)src_bytes;
   a.wgt_bytes = (unsigned)wgt_bytes;
+  {  // the epilogue addresses its tensors through buffer descriptors of M rows with 32-bit byte offsets
+    const ps_epilogue& e = a.epi;
+    long long ld = 0;
+    if (e.add0 && e.ldc_add0 > ld) ld = e.ldc_add0;
+    if (e.out_raw && e.ldc_raw > ld) ld = e.ldc_raw;
+    if (e.mask_src && e.ldc_mask > ld) ld = e.ldc_mask;
+    if (e.add1 && e.ldc_add1 > ld) ld = e.ldc_add1;
+    if (e.out && e.ldc_out > ld) ld = e.ldc_out;
+    PS_REQUIRE((long long)a.M * ld * es < (1LL << 31), "conv: epilogue tensor larger than 2 GiB (%lld rows x %lld channels)", (long long)a.M, ld);
+  }
   a.ablate = g_ablate;
   a.epi_M = g_ablate == 3 ? 0 : a.M;
   a.supertile = g_supertile;
@@ -1543,7 +1674,7 @@ extern "C" int ps_conv2d_fwd(const ps_conv_geom* g, const void* x, const void* w
   a.wrow_bytes = (long long)a.taps * g->cin * es;
   a.Cd = g->cout;
   a.epi = *epi;
-  if (int rc = set_extents(a, (long long)g->n * g->h * g->w * a.pix_bytes, (long long)g->cout * a.wrow_bytes)) return rc;
+  if (int rc = set_extents(a, (long long)g->n * g->h * g->w * a.pix_bytes, (long long)g->cout * a.wrow_bytes, es)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (g->dtype == PS_BF16) return dispatch_bn<TraitsBF16>(a, s);
   if (g->dtype == PS_F16) return dispatch_bn<TraitsF16>(a, s);
@@ -1568,7 +1699,7 @@ extern "C" int ps_conv2d_dgrad(const ps_conv_geom* g, const void* dy, const void
   a.wrow_bytes = (long long)a.taps * g->cout * es;
   a.Cd = g->cin;
   a.epi = *epi;
-  if (int rc = set_extents(a, (long long)g->n * a.Hs * a.Ws * a.pix_bytes, (long long)g->cin * a.wrow_bytes)) return rc;
+  if (int rc = set_extents(a, (long long)g->n * a.Hs * a.Ws * a.pix_bytes, (long long)g->cin * a.wrow_bytes, es)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (g->dtype == PS_BF16) return dispatch_bn<TraitsBF16>(a, s);
   if (g->dtype == PS_F16) return dispatch_bn<TraitsF16>(a, s);

@@ -17,6 +17,9 @@ LAYERS = [  # name, cin, cout, k, s, d, H (input), count in net
     ("b7.b1 2048->4096 1x1", 2048, 4096, 1, 1, 1, 28, 2),
     ("b7.2a 2048->1024 1x1", 2048, 1024, 1, 1, 1, 28, 1),
     ("b6.b1 1024->2048 1x1", 1024, 2048, 1, 1, 1, 28, 2),
+    ("b7 fused 4096->4096 1x1", 4096, 4096, 1, 1, 1, 28, 1),
+    ("b7 fused dgrad 5120->2048", 2048, 5120, 1, 1, 1, 28, 1),
+    ("b5.b1 512->1024 1x1", 512, 1024, 1, 1, 1, 28, 1),
 ]
 
 def main():
@@ -26,6 +29,7 @@ def main():
     ap.add_argument("--what", default="fwd,dgrad,wgrad")
     ap.add_argument("--variants", default="3stage=0,3stage=1")
     ap.add_argument("--layers", default="")
+    ap.add_argument("--epi", default="raw", help="raw: store only | full: fwd = +residual -> raw + BN/ReLU out, dgrad = ReLU mask + add1 -> out")
     args = ap.parse_args()
     lib = _lib.load()
     D = torch.device("cuda:0")
@@ -45,7 +49,18 @@ def main():
         gx = torch.empty(n, H, H, cin, device=D, dtype=dt)
         dw = torch.zeros(cout, k, k, cin, device=D)
         flops = 2.0 * n * ho * wo * cout * cin * k * k
-        fns = {"fwd": lambda: ops.conv2d_fwd(spec, x, wf, out_raw=y), "dgrad": lambda: ops.conv2d_dgrad(spec, gy, wd, (H, H), out_raw=gx),
+        if args.epi == "full":
+            res_in = torch.randn(n, ho, wo, cout, device=D).to(dt)
+            y2 = torch.empty_like(y)
+            bsc, bsh = torch.rand(cout, device=D) + 0.5, torch.randn(cout, device=D)
+            gadd = torch.randn(n, H, H, cin, device=D).to(dt)
+            isc = torch.rand(cin, device=D) + 0.5
+            f_fwd = lambda: ops.conv2d_fwd(spec, x, wf, add0=res_in, out_raw=y, bn_scale=bsc, bn_shift=bsh, out_act=y2)
+            f_dg = lambda: ops.conv2d_dgrad(spec, gy, wd, (H, H), mask_src=x, bn_scale=isc, add1=gadd, out=gx)
+        else:
+            f_fwd = lambda: ops.conv2d_fwd(spec, x, wf, out_raw=y)
+            f_dg = lambda: ops.conv2d_dgrad(spec, gy, wd, (H, H), out_raw=gx)
+        fns = {"fwd": f_fwd, "dgrad": f_dg,
                "wgrad": lambda: ops.conv2d_wgrad(spec, x, gy, dw)}
         line = f"{name:28s}"
         for what in args.what.split(","):
