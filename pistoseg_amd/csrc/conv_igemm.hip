@@ -173,11 +173,17 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
   for (int c0 = 0; c0 < CH; c0 += CW) {
     const int cb = cbase + CH * g + c0;
     float sc[CW], sh[CW];
+    auto load_vec = [&](const float* p, float* v) {  // CW consecutive floats (16-byte aligned: cb is a multiple of 8)
 #pragma unroll
-    for (int i = 0; i < CW; ++i) {
-      sc[i] = (e.scale && e.mode != PS_EPI_NONE) ? e.scale[cb + i] : 1.f;
-      sh[i] = (e.shift && e.mode == PS_EPI_BNRELU) ? e.shift[cb + i] : 0.f;
-    }
+      for (int i = 0; i < CW; i += 4) {
+        const float4 q = *reinterpret_cast<const float4*>(p + i);
+        v[i] = q.x; v[i + 1] = q.y; v[i + 2] = q.z; v[i + 3] = q.w;
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < CW; ++i) sc[i] = 1.f, sh[i] = 0.f;
+    if (e.scale && e.mode != PS_EPI_NONE) load_vec(e.scale + cb, sc);
+    if (e.shift && e.mode == PS_EPI_BNRELU) load_vec(e.shift + cb, sh);
     // Row loads run LW rows ahead of their use (a row's registers are refilled with row + LW as soon as it has been consumed):
     // every load still precedes every store, with LW instead of MI rows of operands live.
     constexpr int LW = MI < 4 ? MI : 4;
