@@ -84,6 +84,8 @@ PROTOTYPES = {
     "ps_fc8_fwd": (C.c_int, [_I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ps_fc_head_fwd": (C.c_int, [_I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ps_fc8_bwd": (C.c_int, [_I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "ps_fc8_bwd_workspace_floats": (C.c_int64, [_I, _I, _I, _I]),
+    "ps_fc8_bwd_ws": (C.c_int, [_I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, C.c_int64, _P]),
     "ps_bilinear_fwd": (C.c_int, [C.POINTER(Tensor4), C.POINTER(Tensor4), _I, _P]),
     "ps_bilinear_bwd": (C.c_int, [C.POINTER(Tensor4), C.POINTER(Tensor4), _I, _P]),
     "ps_ce_workspace_floats": (C.c_int64, []),

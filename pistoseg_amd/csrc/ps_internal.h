@@ -114,6 +114,31 @@ __device__ __forceinline__ void ps_store8<__bf16>(__bf16* p, const float* v) {
   *reinterpret_cast<uint4*>(p) = a;
 }
 
+// Eight consecutive elements held as loaded (no conversion): lets a kernel issue loads well ahead of their use.
+template <typename T>
+struct PsRaw8 {
+  uint4 q[sizeof(T) / 2];
+  __device__ __forceinline__ void load(const T* p) {
+#pragma unroll
+    for (int k = 0; k < (int)sizeof(T) / 2; ++k) q[k] = reinterpret_cast<const uint4*>(p)[k];
+  }
+  __device__ __forceinline__ void unpack(float* v) const {
+    if constexpr (sizeof(T) == 4) {
+      v[0] = __uint_as_float(q[0].x); v[1] = __uint_as_float(q[0].y); v[2] = __uint_as_float(q[0].z); v[3] = __uint_as_float(q[0].w);
+      v[4] = __uint_as_float(q[1].x); v[5] = __uint_as_float(q[1].y); v[6] = __uint_as_float(q[1].z); v[7] = __uint_as_float(q[1].w);
+    } else if constexpr (sizeof(T) == 2 && !__is_same(T, _Float16)) {
+      v[0] = __uint_as_float(q[0].x << 16); v[1] = __uint_as_float(q[0].x & 0xffff0000u);
+      v[2] = __uint_as_float(q[0].y << 16); v[3] = __uint_as_float(q[0].y & 0xffff0000u);
+      v[4] = __uint_as_float(q[0].z << 16); v[5] = __uint_as_float(q[0].z & 0xffff0000u);
+      v[6] = __uint_as_float(q[0].w << 16); v[7] = __uint_as_float(q[0].w & 0xffff0000u);
+    } else {
+      const f16x8 h = __builtin_bit_cast(f16x8, q[0]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = static_cast<float>(h[i]);
+    }
+  }
+};
+
 __device__ __forceinline__ float ps_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -174,9 +174,11 @@ __global__ __launch_bounds__(256) void fc8_fwd_kernel(const T* __restrict__ x, i
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[p][c] = 0.f;
   for (int k0 = lane * 8; k0 < K; k0 += 512) {
-    float wv[C][8];
+    float wv[C][8], dv[8];
 #pragma unroll
     for (int c = 0; c < C; ++c) ps_load8<float>(w + (long long)c * ldw + k0, wv[c]);
+    int ncur = m0 / ppi;  // dropout multipliers change per image only: reloaded when the wave's pixels cross into the next one
+    if (drop) ps_load8<float>(drop + (long long)ncur * K + k0, dv);
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const int m = m0 + p;
@@ -184,8 +186,10 @@ __global__ __launch_bounds__(256) void fc8_fwd_kernel(const T* __restrict__ x, i
       float xv[8];
       ps_load8<T>(x + (long long)m * ldc + k0, xv);
       if (drop) {
-        float dv[8];
-        ps_load8<float>(drop + (long long)(m / ppi) * K + k0, dv);
+        if (m / ppi != ncur) {  // wave-uniform
+          ncur = m / ppi;
+          ps_load8<float>(drop + (long long)ncur * K + k0, dv);
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) xv[i] *= dv[i];
       }
@@ -209,18 +213,28 @@ __global__ __launch_bounds__(256) void fc8_fwd_kernel(const T* __restrict__ x, i
   }
 }
 
-// fc8 backward (+ ReLU(bn7) mask): a thread owns 8 channels and walks a pixel range, four pixels per iteration so
-// that four 16-byte activation loads are in flight per lane (eight per lane / shorter ranges measured slower: 750 vs 437 us) (the kernel is a pure stream: read x, write dx).
-template <typename T, int C>
+// fc8 backward (+ ReLU(bn7) mask): a thread owns 8 channels and walks a pixel range, four pixels per group (the kernel is a pure
+// stream: read x, write dx).
+//   * Groups alternate between two register sets and the NEXT group's loads are issued before the current group's stores: vmcnt
+//     counts loads and stores in one in-order queue, so loads issued behind stores could not be consumed before those stores were
+//     acknowledged by L2.  The loop body is branch-free (rows past the end are clamped: they re-store the last row and contribute
+//     nothing to dw), so the compiler's vmcnt bookkeeping stays exact.
+//   * A block's pixel range spans at most two images (the host picks pix_per_block <= pixels per image): their dropout multipliers
+//     are loaded once and selected per pixel.
+//   * dw: every block holds a [C][2048] partial sum.  With a workspace the partials are stored ([pixel block][C][K], plain stores)
+//     and summed by fc8_dw_reduce_kernel; without one they go to dw with atomics -- 9.6 M float atomics on 12 K addresses at the
+//     training shape, measured r01: 270 of the kernel's 455 us.
+template <typename T, int C, bool DROP>
 __global__ __launch_bounds__(256) void fc8_bwd_kernel(const T* __restrict__ x, int ldc, const float* __restrict__ w,
                                                       const float* __restrict__ drop, const float* __restrict__ scale7,
                                                       const float* __restrict__ dcam, T* __restrict__ dx, int ldc_dx,
-                                                      float* __restrict__ dw, int M, int ppi, int K, int pix_per_block) {
+                                                      float* __restrict__ dw, float* __restrict__ partial, int M, int ppi, int K,
+                                                      int pix_per_block) {
   const int kblocks = K / 2048;
   const int kb = blockIdx.x % kblocks, mb = blockIdx.x / kblocks;
   const int k0 = kb * 2048 + threadIdx.x * 8;
   const int ma = mb * pix_per_block, me = min(M, ma + pix_per_block);
-  float wv[C][8], gw[C][8], s7[8];
+  float wv[C][8], gw[C][8], s7[8], dva[8], dvb[8];
 #pragma unroll
   for (int c = 0; c < C; ++c) {
 #pragma unroll
@@ -228,45 +242,94 @@ __global__ __launch_bounds__(256) void fc8_bwd_kernel(const T* __restrict__ x, i
     ps_load8<float>(w + (long long)c * K + k0, wv[c]);
   }
   ps_load8<float>(scale7 + k0, s7);
+  const int na = ma / ppi;  // image of the first pixel; pixels of the block lie in image na or na + 1
+  if constexpr (DROP) {
+    ps_load8<float>(drop + (long long)na * K + k0, dva);
+    ps_load8<float>(drop + (long long)((me - 1) / ppi) * K + k0, dvb);
+  }
   constexpr int U = 4;
-  for (int m0 = ma; m0 < me; m0 += U) {
-    float xv[U][8], dv[U][8];
+  struct Group {
+    PsRaw8<T> x[U];
+    float dc[U][C];  // the pixels' dcam rows (same address in every lane; loaded with the group so that they share its wait)
+  };
+  auto issue = [&](Group& gr, int m0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int m = min(m0 + u, me - 1);
-      ps_load8<T>(x + (long long)m * ldc + k0, xv[u]);
-      if (drop) ps_load8<float>(drop + (long long)(m / ppi) * K + k0, dv[u]);
-      else {
+      gr.x[u].load(x + (long long)m * ldc + k0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dv[u][i] = 1.f;
-      }
+      for (int c = 0; c < C; ++c) gr.dc[u][c] = dcam[(long long)m * C + c];
     }
+  };
+  auto process = [&](const Group& gr, int m0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int m = m0 + u;
-      if (m >= me) break;
-      float g[8];
+      const int m = min(m0 + u, me - 1);
+      const float live = (m0 + u < me) ? 1.f : 0.f;
+      float xv[8], dv[8], g[8];
+      gr.x[u].unpack(xv);
+      const bool first = m / ppi == na;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dv[i] = DROP ? (first ? dva[i] : dvb[i]) : 1.f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) g[i] = 0.f;
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        const float d = dcam[(long long)m * C + c];  // wave-uniform
+        const float d = gr.dc[u][c];
+        const float dl = d * live;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           g[i] = fmaf(d, wv[c][i], g[i]);
-          gw[c][i] = fmaf(d, xv[u][i] * dv[u][i], gw[c][i]);
+          gw[c][i] = fmaf(dl, xv[i] * dv[i], gw[c][i]);
         }
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) g[i] = xv[u][i] > 0.f ? g[i] * dv[u][i] * s7[i] : 0.f;
+      for (int i = 0; i < 8; ++i) g[i] = xv[i] > 0.f ? g[i] * dv[i] * s7[i] : 0.f;
       ps_store8<T>(dx + (long long)m * ldc_dx + k0, g);
     }
+  };
+  // (loads past the end of the range are clamped to its last row.  The first group is peeled so that the loop header sees the same
+  // queue shape -- loads, stores, loads -- from the entry and from the back edge, and the waits stay vmcnt(N > 0).)
+  Group ga, gb;
+  issue(ga, ma);
+  issue(gb, ma + U);
+  process(ga, ma);
+  issue(ga, ma + 2 * U);
+  for (int m0 = ma + U; m0 < me; m0 += 2 * U) {
+    process(gb, m0);
+    issue(gb, m0 + 2 * U);
+    if (m0 + U >= me) break;
+    process(ga, m0 + U);
+    issue(ga, m0 + 3 * U);
   }
+  if (partial) {
 #pragma unroll
-  for (int c = 0; c < C; ++c) {
+    for (int c = 0; c < C; ++c) ps_store8<float>(partial + ((long long)mb * C + c) * K + k0, gw[c]);
+  } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) atomicAdd(dw + (long long)c * K + k0 + i, gw[c][i]);
+    for (int c = 0; c < C; ++c) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) atomicAdd(dw + (long long)c * K + k0 + i, gw[c][i]);
+    }
   }
+}
+
+// dw[j] += sum over the pixel blocks b of partial[b][j], j < C*K: a thread sums four consecutive j over a slice of the blocks
+// (blockIdx.y), the slices meet in dw with one atomic each.
+__global__ __launch_bounds__(256) void fc8_dw_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int ck, int nblocks,
+                                                            int per_slice) {
+  const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (j >= ck) return;
+  const int b0 = blockIdx.y * per_slice, b1 = min(nblocks, b0 + per_slice);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b = b0; b < b1; ++b) {
+    const float4 v = *reinterpret_cast<const float4*>(partial + (long long)b * ck + j);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  atomicAdd(dw + j, acc.x);
+  atomicAdd(dw + j + 1, acc.y);
+  atomicAdd(dw + j + 2, acc.z);
+  atomicAdd(dw + j + 3, acc.w);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -460,28 +523,59 @@ extern "C" int ps_fc8_fwd(int32_t dtype, const void* x, int32_t ldc_x, const flo
   return ps_fc_head_fwd(dtype, x, ldc_x, w, k, nullptr, drop, cam, 0, m_total, ppi, k, c, stream);
 }
 
-extern "C" int ps_fc8_bwd(int32_t dtype, const void* x, int32_t ldc_x, const float* w, const float* drop, const float* scale7,
-                          const float* dcam, void* dx, int32_t ldc_dx, float* dw, int32_t m_total, int32_t ppi, int32_t k,
-                          int32_t c, void* stream) {
+static int fc8_bwd_ppb(int ppi) { return ppi < 64 ? ppi : 64; }  // a block's pixels span at most two images
+
+extern "C" int64_t ps_fc8_bwd_workspace_floats(int32_t m_total, int32_t ppi, int32_t k, int32_t c) {
+  if (m_total <= 0 || ppi <= 0 || k <= 0 || c <= 0) return 0;
+  const int ppb = fc8_bwd_ppb(ppi);
+  return (int64_t)((m_total + ppb - 1) / ppb) * c * k;
+}
+
+extern "C" int ps_fc8_bwd_ws(int32_t dtype, const void* x, int32_t ldc_x, const float* w, const float* drop, const float* scale7,
+                             const float* dcam, void* dx, int32_t ldc_dx, float* dw, int32_t m_total, int32_t ppi, int32_t k,
+                             int32_t c, float* workspace, int64_t workspace_floats, void* stream) {
   PS_REQUIRE(x && w && scale7 && dcam && dx && dw, "fc8_bwd: null argument");
   PS_REQUIRE(c >= 1 && c <= FC8_MAXC, "fc8_bwd: C=%d unsupported (1..%d)", c, FC8_MAXC);
   PS_REQUIRE(k % 2048 == 0 && m_total > 0 && ppi > 0, "fc8_bwd: K=%d must be a multiple of 2048", k);
   const int es = ps_esize(dtype);
   PS_REQUIRE(ps_aligned16(x) && ps_aligned16(dx) && (ldc_x * es) % 16 == 0 && (ldc_dx * es) % 16 == 0, "fc8_bwd: misaligned tensor");
-  const int ppb = 64;
-  const int grid = (k / 2048) * ((m_total + ppb - 1) / ppb);
+  const int ppb = fc8_bwd_ppb(ppi);
+  const int mblocks = (m_total + ppb - 1) / ppb;
+  const int grid = (k / 2048) * mblocks;
+  float* partial = nullptr;
+  if (workspace) {
+    PS_REQUIRE(ps_aligned16(workspace) && workspace_floats >= (int64_t)mblocks * c * k, "fc8_bwd: workspace of %lld floats, need %lld (16-byte aligned)",
+               (long long)workspace_floats, (long long)mblocks * c * k);
+    partial = workspace;
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
   PS_REQUIRE(ps_dtype_ok(dtype), "fc8_bwd: dtype %d unsupported", dtype);
-#define PS_FC8_BWD(CC)                                                                                                                     \
-  case CC:                                                                                                                                 \
-    if (dtype == PS_BF16) hipLaunchKernelGGL((fc8_bwd_kernel<__bf16, CC>), dim3(grid), dim3(256), 0, s, (const __bf16*)x, ldc_x, w, drop, scale7, dcam, (__bf16*)dx, ldc_dx, dw, m_total, ppi, k, ppb); \
-    else if (dtype == PS_F16) hipLaunchKernelGGL((fc8_bwd_kernel<_Float16, CC>), dim3(grid), dim3(256), 0, s, (const _Float16*)x, ldc_x, w, drop, scale7, dcam, (_Float16*)dx, ldc_dx, dw, m_total, ppi, k, ppb); \
-    else hipLaunchKernelGGL((fc8_bwd_kernel<float, CC>), dim3(grid), dim3(256), 0, s, (const float*)x, ldc_x, w, drop, scale7, dcam, (float*)dx, ldc_dx, dw, m_total, ppi, k, ppb); \
+#define PS_FC8_BWD_T(TT, CC)                                                                                                              \
+  if (drop) hipLaunchKernelGGL((fc8_bwd_kernel<TT, CC, true>), dim3(grid), dim3(256), 0, s, (const TT*)x, ldc_x, w, drop, scale7, dcam, (TT*)dx, ldc_dx, dw, partial, m_total, ppi, k, ppb); \
+  else hipLaunchKernelGGL((fc8_bwd_kernel<TT, CC, false>), dim3(grid), dim3(256), 0, s, (const TT*)x, ldc_x, w, drop, scale7, dcam, (TT*)dx, ldc_dx, dw, partial, m_total, ppi, k, ppb);
+#define PS_FC8_BWD(CC)                                      \
+  case CC:                                                  \
+    if (dtype == PS_BF16) { PS_FC8_BWD_T(__bf16, CC) }      \
+    else if (dtype == PS_F16) { PS_FC8_BWD_T(_Float16, CC) } \
+    else { PS_FC8_BWD_T(float, CC) }                        \
     break;
   switch (c) { PS_FC8_BWD(1) PS_FC8_BWD(2) PS_FC8_BWD(3) PS_FC8_BWD(4) PS_FC8_BWD(5) PS_FC8_BWD(6) PS_FC8_BWD(7) PS_FC8_BWD(8) }
+#undef PS_FC8_BWD_T
 #undef PS_FC8_BWD
   PS_CHECK_LAUNCH("fc8_bwd");
+  if (partial) {
+    const int ck = c * k;
+    const int slices = mblocks < 16 ? 1 : 16, per_slice = (mblocks + slices - 1) / slices;
+    hipLaunchKernelGGL(fc8_dw_reduce_kernel, dim3((ck / 4 + 255) / 256, slices), dim3(256), 0, s, partial, dw, ck, mblocks, per_slice);
+    PS_CHECK_LAUNCH("fc8_dw_reduce");
+  }
   return PS_OK;
+}
+
+extern "C" int ps_fc8_bwd(int32_t dtype, const void* x, int32_t ldc_x, const float* w, const float* drop, const float* scale7,
+                          const float* dcam, void* dx, int32_t ldc_dx, float* dw, int32_t m_total, int32_t ppi, int32_t k,
+                          int32_t c, void* stream) {
+  return ps_fc8_bwd_ws(dtype, x, ldc_x, w, drop, scale7, dcam, dx, ldc_dx, dw, m_total, ppi, k, c, nullptr, 0, stream);
 }
 
 extern "C" int ps_weight_transpose(int32_t sdt, int32_t ddt, const void* src, void* dst, int32_t cout, int32_t taps, int32_t cin,

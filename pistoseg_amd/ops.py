@@ -231,16 +231,23 @@ def fc_head_fwd(x: Tensor, w: Tensor, ldw: int, bias: Optional[Tensor], drop: Op
                                   n * h * wd, h * wd, k, c, _stream()), "ps_fc_head_fwd")
 
 
+_fc8_ws = {}  # device -> workspace tensor for the dw partial sums (grown on demand, reused across steps)
+
+
 def fc8_bwd(x: Tensor, w: Tensor, drop: Optional[Tensor], scale7: Tensor, dcam: Tensor, dx: Tensor, dw: Tensor) -> None:
     _require_gpu(x, w, dcam, dx, dw)
     n, h, wd, k = x.shape
     c = w.shape[0]
     assert dcam.is_contiguous() and dcam.dtype == torch.float32 and dw.dtype == torch.float32 and dw.is_contiguous()
     lib = _lib.load()
+    need = int(lib.ps_fc8_bwd_workspace_floats(n * h * wd, h * wd, k, c))
+    ws = _fc8_ws.get(x.device)
+    if ws is None or ws.numel() < need:
+        ws = _fc8_ws[x.device] = torch.empty(need, device=x.device, dtype=torch.float32)
     _lib.check(
-        lib.ps_fc8_bwd(_dt(x), x.data_ptr(), _ldc(x), w.data_ptr(), _ptr(drop), scale7.data_ptr(), dcam.data_ptr(), dx.data_ptr(), _ldc(dx),
-                       dw.data_ptr(), n * h * wd, h * wd, k, c, _stream()),
-        "ps_fc8_bwd",
+        lib.ps_fc8_bwd_ws(_dt(x), x.data_ptr(), _ldc(x), w.data_ptr(), _ptr(drop), scale7.data_ptr(), dcam.data_ptr(), dx.data_ptr(), _ldc(dx),
+                          dw.data_ptr(), n * h * wd, h * wd, k, c, ws.data_ptr(), ws.numel(), _stream()),
+        "ps_fc8_bwd_ws",
     )
 
 
