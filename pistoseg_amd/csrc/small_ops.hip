@@ -164,53 +164,69 @@ constexpr int FC8_MAXC = 8;
 template <typename T, int C>  // C = number of classes (compile time: the per-class accumulators and weights live in registers)
 __global__ __launch_bounds__(256) void fc8_fwd_kernel(const T* __restrict__ x, int ldc, const float* __restrict__ w, int ldw,
                                                       const float* __restrict__ bias, const float* __restrict__ drop,
-                                                      float* __restrict__ cam, int accumulate, int M, int ppi, int K) {
+                                                      float* __restrict__ cam, int accumulate, int M, int ppi, int K, int ppw) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int m0 = (blockIdx.x * 4 + wave) * 8;
-  if (m0 >= M) return;
-  float acc[8][C];
+  const int mw = (blockIdx.x * 4 + wave) * ppw, mwe = min(M, mw + ppw);  // this wave's pixels, eight at a time
+  for (int m0 = mw; m0 < mwe; m0 += 8) {
+    float acc[8][C];
 #pragma unroll
-  for (int p = 0; p < 8; ++p)
+    for (int p = 0; p < 8; ++p)
 #pragma unroll
-    for (int c = 0; c < C; ++c) acc[p][c] = 0.f;
-  for (int k0 = lane * 8; k0 < K; k0 += 512) {
-    float wv[C][8], dv[8];
+      for (int c = 0; c < C; ++c) acc[p][c] = 0.f;
+    // the waves start at different 512-channel chunks (and wrap): in lockstep they would all read the same 1-KiB slice of every
+    // 8-KiB pixel row at the same time, i.e. hammer a subset of the HBM channels
+    const int nchunks = K / 512, rot = (blockIdx.x * 4 + wave) % nchunks;
+    for (int j = 0; j < nchunks; ++j) {
+      const int kc = j + rot < nchunks ? j + rot : j + rot - nchunks;
+      const int k0 = kc * 512 + lane * 8;
+      float wv[C][8], dv[8];
 #pragma unroll
-    for (int c = 0; c < C; ++c) ps_load8<float>(w + (long long)c * ldw + k0, wv[c]);
-    int ncur = m0 / ppi;  // dropout multipliers change per image only: reloaded when the wave's pixels cross into the next one
-    if (drop) ps_load8<float>(drop + (long long)ncur * K + k0, dv);
+      for (int c = 0; c < C; ++c) ps_load8<float>(w + (long long)c * ldw + k0, wv[c]);
+      int ncur = m0 / ppi;  // dropout multipliers change per image only: reloaded when the wave's pixels cross into the next one
+      if (drop) ps_load8<float>(drop + (long long)ncur * K + k0, dv);
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int m = m0 + p;
-      if (m >= M) break;
-      float xv[8];
-      ps_load8<T>(x + (long long)m * ldc + k0, xv);
-      if (drop) {
-        if (m / ppi != ncur) {  // wave-uniform
-          ncur = m / ppi;
-          ps_load8<float>(drop + (long long)ncur * K + k0, dv);
+      for (int p = 0; p < 8; ++p) {
+        const int m = m0 + p;
+        if (m >= mwe) break;
+        float xv[8];
+        ps_load8<T>(x + (long long)m * ldc + k0, xv);
+        if (drop) {
+          if (m / ppi != ncur) {  // wave-uniform
+            ncur = m / ppi;
+            ps_load8<float>(drop + (long long)ncur * K + k0, dv);
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) xv[i] *= dv[i];
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) xv[i] *= dv[i];
+        for (int c = 0; c < C; ++c) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[p][c] = fmaf(xv[i], wv[c][i], acc[p][c]);
+        }
       }
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[p][c] = fmaf(xv[i], wv[c][i], acc[p][c]);
+        const float s = ps_wave_sum(acc[p][c]);
+        if (lane == 0 && m0 + p < mwe) {
+          float* o = cam + (long long)(m0 + p) * C + c;
+          *o = (accumulate ? *o : 0.f) + s + (bias ? bias[c] : 0.f);
+        }
       }
     }
   }
-#pragma unroll
-  for (int p = 0; p < 8; ++p) {
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const float s = ps_wave_sum(acc[p][c]);
-      if (lane == 0 && m0 + p < M) {
-        float* o = cam + (long long)(m0 + p) * C + c;
-        *o = (accumulate ? *o : 0.f) + s + (bias ? bias[c] : 0.f);
-      }
-    }
-  }
+}
+
+// Resident 256-thread blocks per CU of a kernel (from its register use), queried once per instantiation: the fc8 kernels size
+// their per-wave / per-block pixel ranges so that the grid is a whole number of full rounds (at the training shape the fixed
+// 8 / 64 pixels gave 2.04 rounds, i.e. three).
+template <typename Kern>
+static int ps_blocks_per_cu(Kern kernel) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, 0) != hipSuccess || n < 1) n = 1;
+  return n;
 }
 
 // fc8 backward (+ ReLU(bn7) mask): a thread owns 8 channels and walks a pixel range, four pixels per group (the kernel is a pure
@@ -503,14 +519,22 @@ extern "C" int ps_fc_head_fwd(int32_t dtype, const void* x, int32_t ldc_x, const
   PS_REQUIRE(k % 512 == 0 && m_total > 0 && ppi > 0, "fc_head_fwd: K=%d must be a multiple of 512", k);
   PS_REQUIRE(ldw >= k && ldw % 4 == 0, "fc_head_fwd: weight row stride %d must be >= K and a multiple of 4", ldw);
   PS_REQUIRE(ps_aligned16(x) && ps_aligned16(w) && (ldc_x * ps_esize(dtype)) % 16 == 0, "fc_head_fwd: misaligned input");
-  const int grid = (m_total + 31) / 32;
   hipStream_t s = static_cast<hipStream_t>(stream);
   PS_REQUIRE(ps_dtype_ok(dtype), "fc_head_fwd: dtype %d unsupported", dtype);
-#define PS_FC8_FWD(CC)                                                                                                                     \
-  case CC:                                                                                                                                 \
-    if (dtype == PS_BF16) hipLaunchKernelGGL((fc8_fwd_kernel<__bf16, CC>), dim3(grid), dim3(256), 0, s, (const __bf16*)x, ldc_x, w, ldw, bias, drop, cam, accumulate, m_total, ppi, k); \
-    else if (dtype == PS_F16) hipLaunchKernelGGL((fc8_fwd_kernel<_Float16, CC>), dim3(grid), dim3(256), 0, s, (const _Float16*)x, ldc_x, w, ldw, bias, drop, cam, accumulate, m_total, ppi, k); \
-    else hipLaunchKernelGGL((fc8_fwd_kernel<float, CC>), dim3(grid), dim3(256), 0, s, (const float*)x, ldc_x, w, ldw, bias, drop, cam, accumulate, m_total, ppi, k); \
+  // pixels per wave: one (or a whole number of) full round(s) of resident waves, at most ~24 pixels each
+  auto launch = [&](auto kernel, auto xp) {
+    static const int bpc = ps_blocks_per_cu(kernel);
+    const long long cap = (long long)ps_num_cus() * bpc * 4;
+    const long long rounds = (m_total + cap * 24 - 1) / (cap * 24);
+    const int ppw = (int)((m_total + cap * rounds - 1) / (cap * rounds));
+    const int grid = (int)(((m_total + ppw - 1) / ppw + 3) / 4);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, s, xp, ldc_x, w, ldw, bias, drop, cam, accumulate, m_total, ppi, k, ppw);
+  };
+#define PS_FC8_FWD(CC)                                                                            \
+  case CC:                                                                                        \
+    if (dtype == PS_BF16) launch(fc8_fwd_kernel<__bf16, CC>, (const __bf16*)x);                   \
+    else if (dtype == PS_F16) launch(fc8_fwd_kernel<_Float16, CC>, (const _Float16*)x);           \
+    else launch(fc8_fwd_kernel<float, CC>, (const float*)x);                                      \
     break;
   switch (c) { PS_FC8_FWD(1) PS_FC8_FWD(2) PS_FC8_FWD(3) PS_FC8_FWD(4) PS_FC8_FWD(5) PS_FC8_FWD(6) PS_FC8_FWD(7) PS_FC8_FWD(8) }
 #undef PS_FC8_FWD
@@ -523,12 +547,23 @@ extern "C" int ps_fc8_fwd(int32_t dtype, const void* x, int32_t ldc_x, const flo
   return ps_fc_head_fwd(dtype, x, ldc_x, w, k, nullptr, drop, cam, 0, m_total, ppi, k, c, stream);
 }
 
-static int fc8_bwd_ppb(int ppi) { return ppi < 64 ? ppi : 64; }  // a block's pixels span at most two images
+// Pixels per block of fc8_bwd_kernel: at most one image's worth (a block's pixels span <= two images), at least min(32, ppi),
+// and -- given the kernel's resident blocks per CU -- such that the grid is a whole number of full rounds.
+static int fc8_bwd_ppb(int m_total, int ppi, int kblocks, int bpc) {
+  const long long cap = (long long)ps_num_cus() * bpc;
+  const long long rounds = ((long long)m_total * kblocks + cap * 96 - 1) / (cap * 96);
+  const long long mblocks = cap * rounds / kblocks > 0 ? cap * rounds / kblocks : 1;
+  long long ppb = (m_total + mblocks - 1) / mblocks;
+  const int lo = ppi < 32 ? ppi : 32;
+  if (ppb < lo) ppb = lo;
+  if (ppb > ppi) ppb = ppi;
+  return (int)ppb;
+}
 
 extern "C" int64_t ps_fc8_bwd_workspace_floats(int32_t m_total, int32_t ppi, int32_t k, int32_t c) {
   if (m_total <= 0 || ppi <= 0 || k <= 0 || c <= 0) return 0;
-  const int ppb = fc8_bwd_ppb(ppi);
-  return (int64_t)((m_total + ppb - 1) / ppb) * c * k;
+  const int lo = ppi < 32 ? ppi : 32;  // smallest block any launch uses
+  return (int64_t)((m_total + lo - 1) / lo) * c * k;
 }
 
 extern "C" int ps_fc8_bwd_ws(int32_t dtype, const void* x, int32_t ldc_x, const float* w, const float* drop, const float* scale7,
@@ -539,34 +574,40 @@ extern "C" int ps_fc8_bwd_ws(int32_t dtype, const void* x, int32_t ldc_x, const 
   PS_REQUIRE(k % 2048 == 0 && m_total > 0 && ppi > 0, "fc8_bwd: K=%d must be a multiple of 2048", k);
   const int es = ps_esize(dtype);
   PS_REQUIRE(ps_aligned16(x) && ps_aligned16(dx) && (ldc_x * es) % 16 == 0 && (ldc_dx * es) % 16 == 0, "fc8_bwd: misaligned tensor");
-  const int ppb = fc8_bwd_ppb(ppi);
-  const int mblocks = (m_total + ppb - 1) / ppb;
-  const int grid = (k / 2048) * mblocks;
-  float* partial = nullptr;
-  if (workspace) {
-    PS_REQUIRE(ps_aligned16(workspace) && workspace_floats >= (int64_t)mblocks * c * k, "fc8_bwd: workspace of %lld floats, need %lld (16-byte aligned)",
-               (long long)workspace_floats, (long long)mblocks * c * k);
-    partial = workspace;
-  }
+  PS_REQUIRE(!workspace || ps_aligned16(workspace), "fc8_bwd: workspace must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   PS_REQUIRE(ps_dtype_ok(dtype), "fc8_bwd: dtype %d unsupported", dtype);
-#define PS_FC8_BWD_T(TT, CC)                                                                                                              \
-  if (drop) hipLaunchKernelGGL((fc8_bwd_kernel<TT, CC, true>), dim3(grid), dim3(256), 0, s, (const TT*)x, ldc_x, w, drop, scale7, dcam, (TT*)dx, ldc_dx, dw, partial, m_total, ppi, k, ppb); \
-  else hipLaunchKernelGGL((fc8_bwd_kernel<TT, CC, false>), dim3(grid), dim3(256), 0, s, (const TT*)x, ldc_x, w, drop, scale7, dcam, (TT*)dx, ldc_dx, dw, partial, m_total, ppi, k, ppb);
-#define PS_FC8_BWD(CC)                                      \
-  case CC:                                                  \
-    if (dtype == PS_BF16) { PS_FC8_BWD_T(__bf16, CC) }      \
+  int mblocks = 0, rc = PS_OK;
+  auto launch = [&](auto kernel, auto xp, auto dxp) {
+    static const int bpc = ps_blocks_per_cu(kernel);
+    const int ppb = fc8_bwd_ppb(m_total, ppi, k / 2048, bpc);
+    mblocks = (m_total + ppb - 1) / ppb;
+    if (workspace && workspace_floats < (int64_t)mblocks * c * k) {
+      ps_set_error("fc8_bwd: workspace of %lld floats, need %lld", (long long)workspace_floats, (long long)mblocks * c * k);
+      rc = PS_ERR_ARG;
+      return;
+    }
+    hipLaunchKernelGGL(kernel, dim3((k / 2048) * mblocks), dim3(256), 0, s, xp, ldc_x, w, drop, scale7, dcam, dxp, ldc_dx, dw, workspace, m_total,
+                       ppi, k, ppb);
+  };
+#define PS_FC8_BWD_T(TT, CC)                                                          \
+  if (drop) launch(fc8_bwd_kernel<TT, CC, true>, (const TT*)x, (TT*)dx);              \
+  else launch(fc8_bwd_kernel<TT, CC, false>, (const TT*)x, (TT*)dx);
+#define PS_FC8_BWD(CC)                                       \
+  case CC:                                                   \
+    if (dtype == PS_BF16) { PS_FC8_BWD_T(__bf16, CC) }       \
     else if (dtype == PS_F16) { PS_FC8_BWD_T(_Float16, CC) } \
-    else { PS_FC8_BWD_T(float, CC) }                        \
+    else { PS_FC8_BWD_T(float, CC) }                         \
     break;
   switch (c) { PS_FC8_BWD(1) PS_FC8_BWD(2) PS_FC8_BWD(3) PS_FC8_BWD(4) PS_FC8_BWD(5) PS_FC8_BWD(6) PS_FC8_BWD(7) PS_FC8_BWD(8) }
 #undef PS_FC8_BWD_T
 #undef PS_FC8_BWD
+  if (rc != PS_OK) return rc;
   PS_CHECK_LAUNCH("fc8_bwd");
-  if (partial) {
+  if (workspace) {
     const int ck = c * k;
     const int slices = mblocks < 16 ? 1 : 16, per_slice = (mblocks + slices - 1) / slices;
-    hipLaunchKernelGGL(fc8_dw_reduce_kernel, dim3((ck / 4 + 255) / 256, slices), dim3(256), 0, s, partial, dw, ck, mblocks, per_slice);
+    hipLaunchKernelGGL(fc8_dw_reduce_kernel, dim3((ck / 4 + 255) / 256, slices), dim3(256), 0, s, workspace, dw, ck, mblocks, per_slice);
     PS_CHECK_LAUNCH("fc8_dw_reduce");
   }
   return PS_OK;
