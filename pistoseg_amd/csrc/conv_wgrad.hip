@@ -416,26 +416,31 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
   // byte offsets of this lane's transposed reads inside a stage, for K-half kk and half-fragment h: row R = 32kk + 8g + 4h + q4.
   // row_swz only depends on R & 3 (= q4) and (R >> 3) & 1 (= g & 1), so one swizzle value serves every (kk, h).
   const int swz = row_swz<ES, RBG>(8 * g + q4);  // identical formula for both row widths
-  const int a_lane = (8 * g + q4) * RBG + (p4 & 1) * 8, b_lane = G_BYTES + (8 * g + q4) * RBX + (p4 & 1) * 8;
-  int a_chunk[MI], b_chunk[NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i) a_chunk[i] = ((((wr * 128 + i * 16) >> 3) + (p4 >> 1)) ^ swz) << 4;
-#pragma unroll
-  for (int j = 0; j < NI; ++j) b_chunk[j] = ((((wc * 64 + j * 16) >> 3) + (p4 >> 1)) ^ swz) << 4;
+  // A fragment's 16-byte chunk index is (chunk ^ swz) with chunk = wr*16 + 2i + c resp. wc*8 + 2j + c (c = p4 >> 1) and swz confined to
+  // bits 1..3, so (chunk ^ swz) << 4 = lane constant + ((i ^ s) << 5) resp. ((j ^ (s & 3)) << 5), s = swz >> 1: the fragment addresses are
+  // rebuilt from two lane constants at every read (one xor + one shift-add each) instead of living in 12 registers -- the kernel
+  // sits at the 256-VGPR limit, and ANY spill reload in this wave carries a vmcnt(0) that waits for the previous item's atomics.
+  static_assert(ES == 2 && MI == 8 && NI == 4, "fragment address algebra below");
+  const int s3 = swz >> 1;
+  const int a_base = (8 * g + q4) * RBG + (p4 & 1) * 8 + (((wr * 16) + (p4 >> 1)) << 4);
+  const int b_base = G_BYTES + (8 * g + q4) * RBX + (p4 & 1) * 8 + ((((wc ^ (s3 >> 2)) << 3) + (p4 >> 1)) << 4);
 
   auto rd = [&](const unsigned char* st, int kk, bf16x8 (&af)[MI], bf16x8 (&bf)[NI]) {
+    int z;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z));  // opaque zero: keeps the address arithmetic inside the loop (see above)
+    const int sd = s3 + z;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int roff = (kk * 32 + 4 * h);
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
-        const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(st + a_lane + roff * RBG + a_chunk[i]));
+        const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(st + a_base + roff * RBG + ((i ^ sd) << 5)));
 #pragma unroll
         for (int e = 0; e < 4; ++e) af[i][4 * h + e] = t[e];
       }
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
-        const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(st + b_lane + roff * RBX + b_chunk[j]));
+        const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(st + b_base + roff * RBX + ((j ^ (sd & 3)) << 5)));
 #pragma unroll
         for (int e = 0; e < 4; ++e) bf[j][4 * h + e] = t[e];
       }
@@ -486,7 +491,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
     // fragment index j (two half-wave swaps + two row swaps per register quartet) leaves register j' of lane (g', l16) with
     // row 4j' + r, column 16g' + l16 = the lane id: every atomic wave-instruction then adds ONE 256-byte contiguous row
     // segment (the shape the memory-side atomic units take at full rate) instead of four 64-byte pieces.
-    float* base = a.dw + (long long)(tco * BCO + wr * 128) * wrow + (long long)tap * a.cin + tci * BCI + wc * 64 + lane;
+    // Buffer atomics: descriptor + scalar item offset + a 32-bit lane offset.  (No 64-bit VGPR address is live across the K loop: a
+    // spilled one used to be reloaded at the top of every item, and the vmcnt(0) of that reload made the wave wait for all of the
+    // previous item's atomics before it could start the next item's MFMAs.)
+    const __amdgpu_buffer_rsrc_t rs_dw = __builtin_amdgcn_make_buffer_rsrc((void*)a.dw, 0, (int)((long long)a.cout * wrow * 4), 0x00020000);
+    const unsigned row_bytes = (unsigned)wrow * 4u;
+    const unsigned item_off = (unsigned)(((long long)(tco * BCO + wr * 128) * wrow + (long long)tap * a.cin + tci * BCI + wc * 64) * 4);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -501,9 +511,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
         const float o[4] = {__uint_as_float(s01[0]), __uint_as_float(s01[1]), __uint_as_float(s23[0]), __uint_as_float(s23[1])};
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
-          float* dst = base + (long long)(i * 16 + 4 * jp + r) * wrow;
-          if (a.ablate == 0) atomicAdd(dst, o[jp]);
-          else if (a.ablate == 2) *dst = o[jp];
+          // (the item offset is part of the lane offset on purpose: an item-invariant offset would be hoisted out of the item
+          // loop, 128 live registers)
+          const unsigned voff = item_off + (unsigned)(i * 16 + 4 * jp + r) * row_bytes + (unsigned)lane * 4u;
+          if (a.ablate == 0) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(o[jp], rs_dw, voff, 0, 0);
+          else if (a.ablate == 2) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[jp]), rs_dw, voff, 0, 0);
           else asm volatile("" ::"v"(o[jp]));
         }
       }
