@@ -115,6 +115,17 @@ int ps_conv2d_wgrad(const ps_conv_geom* g, const void* x, const void* dy, float*
 /* dst[cin][taps][cout] = src[cout][taps][cin]; same 16-bit dtype on both sides, f32 -> f32, or f32 -> bf16/f16 (cast). */
 int ps_weight_transpose(int32_t src_dtype, int32_t dst_dtype, const void* src, void* dst, int32_t cout, int32_t taps,
                         int32_t cin, void* stream);
+/* The same for many tensors in ONE launch (the per-step refresh of the data-gradient layouts after an optimizer step).
+ * dst_ld >= cout is the row stride of dst in elements: dst[(ci * taps + tap) * dst_ld + co] = src[(co * taps + tap) * cin + ci];
+ * two items with the same dst_ld whose dst pointers are offset by the first's cout build the K-concatenated weights of two 1x1
+ * convolutions side by side.  All items share the (src, dst) dtype pair. */
+#define PS_WT_MAX_ITEMS 48 /* items per launch; longer lists are cut into several launches */
+typedef struct ps_wt_item {
+  const void* src;
+  void* dst;
+  int32_t cout, taps, cin, dst_ld;
+} ps_wt_item;
+int ps_weight_transpose_batched(int32_t src_dtype, int32_t dst_dtype, int32_t n_items, const ps_wt_item* items, void* stream);
 /* Strided row copy: dst[r][0..row_bytes) = src[r][0..row_bytes), r < rows (pitches in bytes; everything a multiple of 16).  Used to lay
  * two weight matrices side by side along K, so that a bottleneck unit's shortcut conv and its last 1x1 conv (and their data gradients)
  * run as ONE GEMM over concatenated channels (models/resnet38d.py:76-97: `branch1 + branch2`). */

@@ -45,6 +45,10 @@ class Epilogue(C.Structure):
     ]
 
 
+class WtItem(C.Structure):  # ps_wt_item
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("cout", C.c_int32), ("taps", C.c_int32), ("cin", C.c_int32), ("dst_ld", C.c_int32)]
+
+
 class TileDst(C.Structure):
     _fields_ = [
         ("canvas", C.c_void_p), ("count", C.c_void_p), ("canvas_h", C.c_int32), ("canvas_w", C.c_int32),
@@ -77,6 +81,7 @@ PROTOTYPES = {
     "ps_conv2d_dgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _P, C.POINTER(Epilogue), _P]),
     "ps_conv2d_wgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _P, _P, _P]),
     "ps_weight_transpose": (C.c_int, [_I, _I, _P, _P, _I, _I, _I, _P]),
+    "ps_weight_transpose_batched": (C.c_int, [_I, _I, _I, C.POINTER(WtItem), _P]),
     "ps_copy_rows": (C.c_int, [_P, _L, _P, _L, _L, _L, _P]),
     "ps_cast_f32_bf16": (C.c_int, [_P, _P, _L, _P]),
     "ps_cast_f32_lowp": (C.c_int, [_P, _P, _I, _L, _P]),

@@ -390,6 +390,41 @@ __global__ __launch_bounds__(256) void weight_transpose_kernel(const S* __restri
   }
 }
 
+// Many weight tensors in one launch (the per-step refresh of every trainable conv's data-gradient layout was 33 launches of a
+// few microseconds of work each): the items ride in the kernel arguments, a block finds its item by scanning the tile prefix sums.
+// dst rows may be wider than cout (dst_ld): two tensors transposed side by side form the K-concatenated weights of a fused unit.
+constexpr int WT_MAX_ITEMS = PS_WT_MAX_ITEMS;
+struct WtBatch {
+  ps_wt_item it[WT_MAX_ITEMS];
+  int tile_end[WT_MAX_ITEMS];
+  int n;
+};
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const WtBatch b) {
+  __shared__ float tile[32][33];
+  int k = 0;
+  while (k + 1 < b.n && (int)blockIdx.x >= b.tile_end[k]) ++k;
+  const ps_wt_item it = b.it[k];
+  const int t = blockIdx.x - (k ? b.tile_end[k - 1] : 0);
+  const int nx = (it.cin + 31) / 32, ny = (it.cout + 31) / 32;
+  const int tap = t / (nx * ny), r2 = t - tap * nx * ny;
+  const int ci0 = (r2 % nx) * 32, co0 = (r2 / nx) * 32;
+  const S* src = static_cast<const S*>(it.src);
+  D* dst = static_cast<D*>(it.dst);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    tile[r][tx] = (co < it.cout && ci < it.cin) ? to_f32<S>(src[((long long)co * it.taps + tap) * it.cin + ci]) : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < it.cin && co < it.cout) dst[((long long)ci * it.taps + tap) * it.dst_ld + co] = from_f32<D>(tile[tx][r]);
+  }
+}
+
 template <typename D>
 __global__ __launch_bounds__(256) void cast_f32_lowp_kernel(const float* __restrict__ src, D* __restrict__ dst, long long n) {
   const long long stride = (long long)gridDim.x * 256 * 8;
@@ -635,6 +670,37 @@ extern "C" int ps_weight_transpose(int32_t sdt, int32_t ddt, const void* src, vo
   else
     PS_REQUIRE(false, "weight_transpose: dtype pair (%d,%d) unsupported", sdt, ddt);
   PS_CHECK_LAUNCH("weight_transpose");
+  return PS_OK;
+}
+
+extern "C" int ps_weight_transpose_batched(int32_t sdt, int32_t ddt, int32_t n_items, const ps_wt_item* items, void* stream) {
+  PS_REQUIRE(n_items >= 0 && (n_items == 0 || items), "weight_transpose_batched: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  for (int base = 0; base < n_items; base += WT_MAX_ITEMS) {
+    WtBatch b{};
+    b.n = n_items - base < WT_MAX_ITEMS ? n_items - base : WT_MAX_ITEMS;
+    long long tiles = 0;
+    for (int k = 0; k < b.n; ++k) {
+      const ps_wt_item& it = items[base + k];
+      PS_REQUIRE(it.src && it.dst && it.cout > 0 && it.taps > 0 && it.cin > 0 && it.dst_ld >= it.cout, "weight_transpose_batched: bad item %d", base + k);
+      b.it[k] = it;
+      tiles += (long long)((it.cin + 31) / 32) * ((it.cout + 31) / 32) * it.taps;
+      PS_REQUIRE(tiles < (1LL << 31), "weight_transpose_batched: too many tiles");
+      b.tile_end[k] = (int)tiles;
+    }
+    const dim3 grid((unsigned)tiles);
+    if (sdt == PS_F32 && ddt == PS_F32)
+      hipLaunchKernelGGL((weight_transpose_batched_kernel<float, float>), grid, dim3(256), 0, s, b);
+    else if (sdt == PS_F32 && ddt == PS_BF16)
+      hipLaunchKernelGGL((weight_transpose_batched_kernel<float, uint16_t>), grid, dim3(256), 0, s, b);
+    else if (sdt == PS_F32 && ddt == PS_F16)
+      hipLaunchKernelGGL((weight_transpose_batched_kernel<float, h16>), grid, dim3(256), 0, s, b);
+    else if ((sdt == PS_BF16 && ddt == PS_BF16) || (sdt == PS_F16 && ddt == PS_F16))
+      hipLaunchKernelGGL((weight_transpose_batched_kernel<uint16_t, uint16_t>), grid, dim3(256), 0, s, b);
+    else
+      PS_REQUIRE(false, "weight_transpose_batched: dtype pair (%d,%d) unsupported", sdt, ddt);
+    PS_CHECK_LAUNCH("weight_transpose_batched");
+  }
   return PS_OK;
 }
 

@@ -169,6 +169,22 @@ def weight_transpose(src: Tensor, dst: Tensor, cout: int, taps: int, cin: int) -
     _lib.check(lib.ps_weight_transpose(_dt(src), _dt(dst), src.data_ptr(), dst.data_ptr(), cout, taps, cin, _stream()), "ps_weight_transpose")
 
 
+def weight_transpose_batched(items) -> None:
+    """items: (src [cout][taps][cin], dst view with rows [cin*taps] of stride dst.stride(0) >= cout, cout, taps, cin), all of one
+    dtype pair.  One launch for the whole list (ps_weight_transpose_batched)."""
+    if not items:
+        return
+    arr = (_lib.WtItem * len(items))()
+    sdt, ddt = _dt(items[0][0]), _dt(items[0][1])
+    for k, (src, dst, cout, taps, cin) in enumerate(items):
+        _require_gpu(src, dst)
+        assert _dt(src) == sdt and _dt(dst) == ddt and src.is_contiguous() and src.numel() == cout * taps * cin
+        assert dst.dim() == 2 and dst.shape == (cin * taps, cout) and dst.stride(1) == 1
+        arr[k] = _lib.WtItem(src.data_ptr(), dst.data_ptr(), cout, taps, cin, dst.stride(0))
+    lib = _lib.load()
+    _lib.check(lib.ps_weight_transpose_batched(sdt, ddt, len(items), arr, _stream()), "ps_weight_transpose_batched")
+
+
 def copy_rows(src: Tensor, dst: Tensor) -> None:
     """dst[r, :] = src[r, :] for 2-d views with unit inner stride and arbitrary row pitches (same dtype, same shape)."""
     _require_gpu(src, dst)

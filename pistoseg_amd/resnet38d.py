@@ -123,6 +123,7 @@ class Net(nn.Module):
         self._cache: Dict[str, Tuple] = {}
         self._weights_epoch = 0           # bumped by code that rewrites parameter memory behind torch's back
         self._bf16_shadow: Dict[str, Tensor] = {}  # param name -> bf16 W_fwd view kept fresh by the fused optimiser
+        self._wd_plan: Dict[str, Tuple] = {}       # cache key -> (deps, [(src fn, dst view, cout, taps, cin)]): see refresh_dgrad_weights
         self.train(True)  # apply the freezing rules from the start (the reference's scripts always call train())
 
     # ------------------------------------------------------------------ reference API
@@ -201,9 +202,30 @@ class Net(nn.Module):
             src = self.w_fwd(conv, key)
             out = torch.empty((cin, k, k, cout), device=w.device, dtype=self.compute_dtype)
             ops.weight_transpose(src, out, cout, k * k, cin)
+            self._wd_plan["wd:" + key] = ((w,), [(lambda: self.w_fwd(conv, key), out.view(cin * k * k, cout), cout, k * k, cin)])
             return out
 
         return self._cached("wd:" + key, (w,), make)
+
+    def refresh_dgrad_weights(self) -> None:
+        """Re-derives every data-gradient weight layout the reverse plan has asked for before (w_dgrad / w_dgrad_cat) whose source
+        changed, in ONE launch into the existing buffers -- instead of ~33 lazily triggered transposes per step."""
+        items, fresh = [], []
+        for ckey, (deps, parts) in self._wd_plan.items():
+            hit = self._cache.get(ckey)
+            sig = tuple((t.data_ptr(), t._version) for t in deps) + (self.precision, self._weights_epoch)
+            if hit is None or hit[0] == sig:
+                continue
+            if hit[1].dtype != self.compute_dtype or hit[1].device != deps[0].device:  # precision / device changed: rebuild lazily
+                del self._cache[ckey]
+                continue
+            for src_fn, dst, cout, taps, cin in parts:
+                items.append((src_fn().reshape(cout, taps * cin), dst, cout, taps, cin))
+            fresh.append((ckey, sig, hit[1]))
+        if items:
+            ops.weight_transpose_batched(items)
+        for ckey, sig, val in fresh:
+            self._cache[ckey] = (sig, val)
 
     def w_fwd_cat(self, unit: "ResBlock_bot", name: str) -> Tensor:
         """[cout][cin + cout/2]: conv_branch1 and conv_branch2b2 side by side along K, so that
@@ -227,8 +249,10 @@ class Net(nn.Module):
 
         def make():
             out = torch.empty((cin, cout + c4), device=w1.device, dtype=self.compute_dtype)
-            ops.copy_rows(self.w_dgrad(unit.conv_branch1, name + ".conv_branch1").reshape(cin, cout), out[:, :cout])
-            ops.copy_rows(self.w_dgrad(unit.conv_branch2a, name + ".conv_branch2a").reshape(cin, c4), out[:, cout:])
+            parts = [(lambda: self.w_fwd(unit.conv_branch1, name + ".conv_branch1"), out[:, :cout], cout, 1, cin),
+                     (lambda: self.w_fwd(unit.conv_branch2a, name + ".conv_branch2a"), out[:, cout:], c4, 1, cin)]
+            ops.weight_transpose_batched([(fn().reshape(co, cin), dst, co, 1, cin) for fn, dst, co, _t, _c in parts])
+            self._wd_plan["wdc:" + name] = ((w1, w2), parts)
             return out
 
         return self._cached("wdc:" + name, (w1, w2), make)
@@ -388,6 +412,7 @@ class Net(nn.Module):
         g_taps = g_taps or {}
         first = self.first_trainable_unit()
         G = g_x7
+        self.refresh_dgrad_weights()
         self._out_grad_buf = {k: v for k, v in self._out_grad_buf.items() if k == self.units[-1][0]}  # drop stale buffers of aborted steps
         dt, dev, n = G.dtype, G.device, saved.n
         for i in range(len(self.units) - 1, -1, -1):
