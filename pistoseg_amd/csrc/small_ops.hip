@@ -399,13 +399,50 @@ struct WtBatch {
   int tile_end[WT_MAX_ITEMS];
   int n;
 };
+// 64 x 64 tiles with 16-byte global accesses when both sides are the same 16-bit type and the shapes allow (every backbone conv);
+// 32 x 32 element-wise tiles otherwise.  The host's tile prefix sums use the same rule (wt_fast).
+__host__ __device__ static inline bool wt_fast(const ps_wt_item& it, bool same16) {
+  return same16 && it.cin % 64 == 0 && it.cout % 64 == 0 && it.dst_ld % 8 == 0 && (reinterpret_cast<uintptr_t>(it.src) & 15) == 0 &&
+         (reinterpret_cast<uintptr_t>(it.dst) & 15) == 0;
+}
 template <typename S, typename D>
 __global__ __launch_bounds__(256) void weight_transpose_batched_kernel(const WtBatch b) {
-  __shared__ float tile[32][33];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[64 * 66 * 2 > 32 * 33 * 4 ? 64 * 66 * 2 : 32 * 33 * 4];
   int k = 0;
   while (k + 1 < b.n && (int)blockIdx.x >= b.tile_end[k]) ++k;
   const ps_wt_item it = b.it[k];
   const int t = blockIdx.x - (k ? b.tile_end[k - 1] : 0);
+  constexpr bool same16 = sizeof(S) == 2 && sizeof(D) == 2;
+  if constexpr (same16) {
+    if (wt_fast(it, true)) {
+      uint16_t (*tile)[66] = reinterpret_cast<uint16_t (*)[66]>(lds);  // [co][ci], 132-byte rows: column reads hit distinct banks
+      const int nx = it.cin / 64, ny = it.cout / 64;
+      const int tap = t / (nx * ny), r2 = t - tap * nx * ny;
+      const int ci0 = (r2 % nx) * 64, co0 = (r2 / nx) * 64;
+      const uint16_t* src = static_cast<const uint16_t*>(it.src);
+      uint16_t* dst = static_cast<uint16_t*>(it.dst);
+      const int row = threadIdx.x >> 3, ch = threadIdx.x & 7;  // 32 rows x 8 chunks of 8 elements per pass
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int co = row + 32 * p;
+        const uint4 q = *reinterpret_cast<const uint4*>(src + ((long long)(co0 + co) * it.taps + tap) * it.cin + ci0 + ch * 8);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *reinterpret_cast<uint32_t*>(&tile[co][ch * 8 + 2 * e]) = w[e];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int ci = row + 32 * p;
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (uint32_t)tile[ch * 8 + 2 * e][ci] | ((uint32_t)tile[ch * 8 + 2 * e + 1][ci] << 16);
+        *reinterpret_cast<uint4*>(dst + ((long long)(ci0 + ci) * it.taps + tap) * it.dst_ld + co0 + ch * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+      return;
+    }
+  }
+  float (*tile)[33] = reinterpret_cast<float (*)[33]>(lds);
   const int nx = (it.cin + 31) / 32, ny = (it.cout + 31) / 32;
   const int tap = t / (nx * ny), r2 = t - tap * nx * ny;
   const int ci0 = (r2 % nx) * 32, co0 = (r2 / nx) * 32;
@@ -684,7 +721,9 @@ extern "C" int ps_weight_transpose_batched(int32_t sdt, int32_t ddt, int32_t n_i
       const ps_wt_item& it = items[base + k];
       PS_REQUIRE(it.src && it.dst && it.cout > 0 && it.taps > 0 && it.cin > 0 && it.dst_ld >= it.cout, "weight_transpose_batched: bad item %d", base + k);
       b.it[k] = it;
-      tiles += (long long)((it.cin + 31) / 32) * ((it.cout + 31) / 32) * it.taps;
+      const bool same16 = (sdt == PS_BF16 && ddt == PS_BF16) || (sdt == PS_F16 && ddt == PS_F16);
+      const int ts = wt_fast(it, same16) ? 64 : 32;
+      tiles += (long long)((it.cin + ts - 1) / ts) * ((it.cout + ts - 1) / ts) * it.taps;
       PS_REQUIRE(tiles < (1LL << 31), "weight_transpose_batched: too many tiles");
       b.tile_end[k] = (int)tiles;
     }

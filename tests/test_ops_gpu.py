@@ -678,3 +678,40 @@ def test_conv_pixel_tile_variants(case, bm, dtype):
         lib.ps_debug_set_bn(0)
         lib.ps_debug_set_bm(0)
         lib.ps_debug_set_ws2(WS2_DEFAULT)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_weight_transpose_batched_matches_permute(dtype):
+    """ps_weight_transpose_batched: many tensors in one launch, bit-exact against torch's permute -- shapes on the 64 x 64
+    16-byte path (multiples of 64), on the element-wise path (ragged), and two 1x1 tensors side by side in one K-concatenated
+    destination (row stride > cout), the layout of the fused bottleneck units."""
+    from pistoseg_amd import ops
+
+    d = dev()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(128, 9, 64), (64, 1, 192), (50, 9, 20), (3, 1, 4096), (256, 9, 128)]
+    items, want = [], []
+    for cout, taps, cin in shapes:
+        src = torch.randn(cout, taps, cin, generator=g).to(dtype).to(d)
+        dst = torch.full((cin * taps, cout), 7.0, device=d, dtype=dtype)
+        items.append((src.reshape(cout, taps * cin), dst, cout, taps, cin))
+        want.append(src.permute(2, 1, 0).reshape(cin * taps, cout))
+    cin, c1, c2 = 128, 192, 64  # K-concatenated pair
+    cat = torch.full((cin, c1 + c2), 7.0, device=d, dtype=dtype)
+    s1 = torch.randn(c1, 1, cin, generator=g).to(dtype).to(d)
+    s2 = torch.randn(c2, 1, cin, generator=g).to(dtype).to(d)
+    items += [(s1.reshape(c1, cin), cat[:, :c1], c1, 1, cin), (s2.reshape(c2, cin), cat[:, c1:], c2, 1, cin)]
+    ops.weight_transpose_batched(items)
+    torch.cuda.synchronize()
+    for (src, dst, *_), w in zip(items, want):
+        assert torch.equal(dst, w)
+    assert torch.equal(cat, torch.cat([s1.reshape(c1, cin).t(), s2.reshape(c2, cin).t()], dim=1))
+    # more items than one launch carries
+    many = []
+    for i in range(60):
+        src = torch.randn(64, 1, 64, generator=g).to(dtype).to(d)
+        many.append((src.reshape(64, 64), torch.empty(64, 64, device=d, dtype=dtype), 64, 1, 64))
+    ops.weight_transpose_batched(many)
+    torch.cuda.synchronize()
+    for src, dst, *_ in many:
+        assert torch.equal(dst, src.t())
