@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="weight gradients on the launch stream instead of a second stream")
     ap.add_argument("--cpu-tiles", type=int, default=2)
     ap.add_argument("--workload", default="seg", choices=["seg", "rfm"],
                     help="seg: BASELINE configs[1]/[4] (segmentation_train.py step, the headline metric); rfm: configs[3], the stage-3 step "
@@ -211,7 +212,7 @@ def main():
     init_weights_he(model, seed=42)
     model = model.to(dev)
     trainer = SegTrainer(model, lr=1e-3, weight_decay=0.05, ignore_index=args.classes,
-                         process_group=torch.distributed.group.WORLD if dist_on else None)
+                         process_group=torch.distributed.group.WORLD if dist_on else None, overlap_wgrad=not args.no_overlap)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     x = torch.randn(args.batch, 3, args.tile, args.tile, generator=g).to(dev)
     y = torch.randint(0, args.classes + 1, (args.batch, args.tile, args.tile), generator=g).to(dev)
@@ -250,10 +251,17 @@ def main():
         out["infer_ms_per_step"] = round(1e3 * dti / args.steps, 3)
         model.train()
 
+    def serial_step():  # the instrumented step runs the weight gradients on the launch stream: per-kernel times are exclusive
+        ws, trainer.wgrad_stream = trainer.wgrad_stream, None
+        try:
+            train_step()
+        finally:
+            trainer.wgrad_stream = ws
+
     if rank == 0:
-        out["roofline"] = roofline_leg(train_step, args.precision)
+        out["roofline"] = roofline_leg(serial_step, args.precision)
     else:
-        train_step()  # keep ranks in lockstep through the instrumented step (it contains collectives)
+        serial_step()  # keep ranks in lockstep through the instrumented step (it contains collectives)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_tiles, args.tile, args.classes)
     if dist_on:

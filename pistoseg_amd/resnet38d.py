@@ -404,11 +404,15 @@ class Net(nn.Module):
         return len(self.units)
 
     def backward_backbone(self, saved: _Saved, g_x7: Tensor, grads: Dict[str, Tensor], g_taps: Optional[Dict[str, Tensor]] = None,
-                          after_unit=None) -> None:
+                          after_unit=None, wgrad_stream=None) -> None:
         """Reverse plan.  g_x7: gradient w.r.t. b7's raw output (the ReLU(bn7) mask already applied),
         channels-last compute dtype.  grads: parameter name -> f32 buffer [cout][kh][kw][cin] that wgrad
         ACCUMULATES into (caller zeroes).  g_taps: gradients w.r.t. the conv4 / conv5 taps.
-        after_unit(name): optional callback after a unit's weight gradients are complete (DDP buckets)."""
+        after_unit(name): optional callback after a unit's weight gradients are complete (DDP buckets).
+        wgrad_stream: optional side stream for the weight gradients.  They depend on the data-gradient chain but nothing in the
+        backward depends on them, so on a second HIP stream their blocks fill the CUs that a data-gradient launch leaves idle in
+        its last partial round (and vice versa); after_unit then runs with that stream current (the all-reduce waits on it), and
+        the caller's stream waits for it at the end."""
         g_taps = g_taps or {}
         first = self.first_trainable_unit()
         G = g_x7
@@ -431,8 +435,16 @@ class Net(nn.Module):
 
             def wgrad(cname, x_act, dy):
                 p = getattr(unit, cname).weight
-                if p.requires_grad:
+                if not p.requires_grad:
+                    return
+                if wgrad_stream is None:
                     ops.conv2d_wgrad(specs[cname], x_act, dy, grads[f"{name}.{cname}.weight"])
+                    return
+                wgrad_stream.wait_stream(torch.cuda.current_stream())  # dy (and the zeroed gradient arena) are ready
+                with torch.cuda.stream(wgrad_stream):
+                    ops.conv2d_wgrad(specs[cname], x_act, dy, grads[f"{name}.{cname}.weight"])
+                x_act.record_stream(wgrad_stream)  # keep the caching allocator from recycling them under the side stream
+                dy.record_stream(wgrad_stream)
 
             def new(hh, ww, c):
                 return torch.empty((n, hh, ww, c), device=dev, dtype=dt)
@@ -491,7 +503,13 @@ class Net(nn.Module):
                                          add0=t, mask_src=a, bn_scale=s_in, out=Gp)
                     G = Gp
             if after_unit is not None:
-                after_unit(name)
+                if wgrad_stream is None:
+                    after_unit(name)
+                else:
+                    with torch.cuda.stream(wgrad_stream):
+                        after_unit(name)
+        if wgrad_stream is not None:
+            torch.cuda.current_stream().wait_stream(wgrad_stream)
 
     def invalidate_weight_cache(self) -> None:
         """Call after parameter memory was rewritten by a raw-pointer kernel (fused optimiser step)."""

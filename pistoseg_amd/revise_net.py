@@ -153,7 +153,7 @@ class Net(ResNet38dSeg):
         return tuple(outs), ctx
 
     # ------------------------------------------------------------------ reverse plan
-    def rfm_backward(self, ctx, d_outs, grads: Dict[str, Tensor], after_unit=None) -> None:
+    def rfm_backward(self, ctx, d_outs, grads: Dict[str, Tensor], after_unit=None, wgrad_stream=None) -> None:
         """d_outs = gradients of (cam, cam_rv, pmask_rv, pcam_rv) (NCHW f32, or None).  grads: name -> f32 buffer
         [cout][kh][kw][cin] that the weight gradients are ACCUMULATED into (caller zeroes); 'f9' maps to the packed
         [384,1,1,256] buffer (see _unpack_w9_grad)."""
@@ -196,7 +196,7 @@ class Net(ResNet38dSeg):
         g_x7 = self.head_backward(saved.conv6, ctx["drop7"], d_cam, dw8)
         if after_unit is not None:
             after_unit("heads")
-        self.backward_backbone(saved, g_x7, grads, g_taps=g_taps, after_unit=after_unit)
+        self.backward_backbone(saved, g_x7, grads, g_taps=g_taps, after_unit=after_unit, wgrad_stream=wgrad_stream)
 
     def new_grad_buffers(self, device) -> Dict[str, Tensor]:
         out = {}

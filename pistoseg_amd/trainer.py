@@ -72,9 +72,11 @@ def arena_order(model: ResNet38dSeg) -> List[Tuple[str, torch.nn.Parameter]]:
 class SegTrainer:
     def __init__(self, model: ResNet38dSeg, lr: float = 1e-3, weight_decay: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8,
                  ignore_index: Optional[int] = 3, process_group=None, bucket_mb: float = 48.0, track_iou: bool = True,
-                 loss_scale: Optional[float] = None):
+                 loss_scale: Optional[float] = None, overlap_wgrad: bool = True):
         assert next(model.parameters()).is_cuda, "move the model to the GPU first"
         self.model = model
+        # weight gradients on a second stream (see Net.backward_backbone)
+        self.wgrad_stream = torch.cuda.Stream(device=next(model.parameters()).device) if overlap_wgrad else None
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
         self.ignore_index = ignore_index
         self.step_count = 0
@@ -139,7 +141,8 @@ class SegTrainer:
         if self.reducer is not None:
             self.reducer.begin_step()
             self.reducer.on_unit_done("fc8")
-        model.backward_backbone(saved, g_x7, self.grads, after_unit=self.reducer.on_unit_done if self.reducer is not None else None)
+        model.backward_backbone(saved, g_x7, self.grads, after_unit=self.reducer.on_unit_done if self.reducer is not None else None,
+                                wgrad_stream=self.wgrad_stream)
         if self.reducer is not None:
             self.reducer.finish()
         if self.dynamic_scale:
@@ -171,11 +174,12 @@ class RFMTrainer:
     """
 
     def __init__(self, model, lr: float = 0.01, wt_dec: float = 5e-4, max_step: int = 1000, power: float = 0.9, process_group=None,
-                 bucket_mb: float = 48.0, loss_scale: Optional[float] = None):
+                 bucket_mb: float = 48.0, loss_scale: Optional[float] = None, overlap_wgrad: bool = True):
         from .revise_net import FCAT, Net
 
         assert isinstance(model, Net) and next(model.parameters()).is_cuda
         self.model, self.FCAT = model, FCAT
+        self.wgrad_stream = torch.cuda.Stream(device=next(model.parameters()).device) if overlap_wgrad else None  # see backward_backbone
         self.lr0, self.wt_dec, self.max_step, self.power = lr, wt_dec, max_step, power
         self.global_step = 0
         self.pg = process_group
@@ -246,7 +250,7 @@ class RFMTrainer:
             elif self.reducer is not None:
                 self.reducer.on_unit_done(name)
 
-        model.rfm_backward(ctx, list(d_outs), self.grads, after_unit=after)
+        model.rfm_backward(ctx, list(d_outs), self.grads, after_unit=after, wgrad_stream=self.wgrad_stream)
         if self.reducer is not None:
             self.reducer.finish()
         if self.dynamic_scale:
