@@ -224,3 +224,33 @@ def test_seg_training_gradients_match_oracle(precision):
         worst = max(worst, e)
         assert e < grad_tol, (k, e, flips)
     print(f"[{precision}] relu pattern flips={flips} worst grad err={worst:.3e}")
+
+
+def test_seg_trainer_side_stream_weight_gradients_match_single_stream():
+    """SegTrainer(overlap_wgrad=True) issues the weight gradients on a second stream; two steps must give the same losses and the
+    same parameters as the single-stream trainer (up to the order of the f32 atomics inside one wgrad launch, which both share)."""
+    from pistoseg_amd.trainer import SegTrainer
+
+    c, n, s = 3, 4, 64
+    sd = ref_cpu.make_state_dict(c, False, seed=42)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(n, 3, s, s, generator=g).to(D)
+    y = torch.randint(0, c + 1, (n, s, s), generator=g).to(D)
+    results = []
+    for overlap in (False, False, True):
+        model = build(c, "fp32", sd)
+        drops = iter([{k: (torch.rand(v.shape, generator=torch.Generator().manual_seed(100 + i)) >= 0.5).float().to(D) * 2.0
+                       for k, v in model.sample_dropout(n, torch.device("cpu")).items()} for i in range(2)])
+        model.sample_dropout = lambda n_, dev_: next(drops)
+        tr = SegTrainer(model, lr=1e-3, weight_decay=0.05, ignore_index=c, track_iou=False, overlap_wgrad=overlap)
+        assert (tr.wgrad_stream is not None) == overlap
+        losses = [float(tr.train_step(x, y)) for _ in range(2)]
+        torch.cuda.synchronize()
+        results.append((losses, tr.p_flat.clone()))
+    (l0, p0), (lr_, pr), (l1, p1) = results
+    assert l0[0] == l1[0]  # the first forward does not depend on any gradient
+    assert abs(l0[1] - l1[1]) <= 1e-5 * abs(l0[1])
+    # AdamW's first steps are sign-like (g / sqrt(g^2)): a weight whose gradient is at the level of the f32-atomic ordering noise can
+    # move by +-lr in either run, so the yardstick is the difference between two IDENTICAL single-stream runs
+    noise = rel_err(pr, p0)
+    assert rel_err(p1, p0) <= max(10 * noise, 2e-4), (rel_err(p1, p0), noise)
