@@ -37,6 +37,10 @@ struct IgemmArgs {
   unsigned wgt_bytes;
   int ablate;                 // timing experiments only (results WRONG): 1 = stage the first two K-steps only; 2 = also no per-step barriers (ws kernel)
   int nb, tpb;                // persistent kernels: blocks per batch (#CUs), tiles per block (0 = one batch), see ps_block_items
+  // stride-2 data gradient, one launch per output parity class (conv_igemm_ws2_kernel<.., SPLIT>): the produced grid Ho x Wo is the
+  // class's sub-grid, pixel (p', q') of it is pixel (oy + 2p', ox + 2q') of the full Hf x Wf gradient, and only the taps in tap_mask
+  // (those that hit dy at integer positions for this parity) are staged and multiplied.  epi_M = rows of the full tensor.
+  int tap_mask, oy, ox, Hf, Wf;
   ps_epilogue epi;
 };
 
@@ -157,8 +161,9 @@ struct Raw8 {
 // rows past the end are dropped by the range check (no predication, no 64-bit address arithmetic), and no load is left pending on
 // any path, so the next tile's first MFMAs need no vmcnt wait.  Layers with dropout (per-row multipliers; b6 / b7 only) keep the
 // row-by-row order.  (f32 tensors: 8 channels at a time to bound the registers.)
-template <typename T, int MI, int WI, bool COLMAP = false, int CW = (sizeof(T) == 2 ? 4 * WI : 8)>
+template <typename T, int MI, int WI, int MAP = 0, int CW = (sizeof(T) == 2 ? 4 * WI : 8)>  // MAP: 0 rows = pixels in order, 1 halo kernel's 8 x 2 patches, 2 parity sub-grid
 __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[MI][WI], int mbase, int cbase, int lane) {
+  constexpr bool COLMAP = MAP == 1;
   constexpr int CH = 4 * WI;  // 16 or 8 channels per lane, handled CW at a time
   constexpr int NO = CW / 8, ES = (int)sizeof(T);
   static_assert(CW % 8 == 0 && CH % CW == 0, "channel chunk");
@@ -166,6 +171,21 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
   const ps_epilogue& e = a.epi;
   const int row0 = COLMAP ? mbase + (frow & 7) * a.Wo + (frow >> 3) : mbase + frow;  // row of fragment mi: row0 + mi * RSTEP
   constexpr int RSTEP = COLMAP ? 2 : 16;
+  // MAP 2: fragment row mi is pixel m = row0 + 16 mi of the class's sub-grid -> row rrow[mi] of the full tensor (epi_M = dropped)
+  int rrow[MAP == 2 ? MI : 1];
+  if constexpr (MAP == 2) {
+    const int hw = a.Ho * a.Wo;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = row0 + mi * RSTEP;
+      const int n = m / hw, rem = m - n * hw, pp = rem / a.Wo, qq = rem - pp * a.Wo;
+      rrow[mi] = m < a.M ? (n * a.Hf + a.oy + 2 * pp) * a.Wf + a.ox + 2 * qq : a.epi_M;
+    }
+  }
+  auto roff = [&](int mi, int ldc, int cb) {  // byte offset of fragment row mi, channel cb, in a tensor of row stride ldc
+    if constexpr (MAP == 2) return (rrow[mi] * ldc + cb) * ES;
+    else return ((row0 + mi * RSTEP) * ldc + cb) * ES;
+  };
   auto rsrc = [&](const void* base, int ldc) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, a.epi_M * ldc * ES, 0x00020000);
   };
@@ -189,12 +209,11 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
     constexpr int LW = MI < 4 ? MI : 4;
     auto add_rows = [&](const void* base, int ldc) {  // acc += tensor rows
       const __amdgpu_buffer_rsrc_t rs = rsrc(base, ldc);
-      const int v0 = (row0 * ldc + cb) * ES, step = RSTEP * ldc * ES;
       Raw8<T> t[LW][NO];
 #pragma unroll
       for (int mi = 0; mi < LW; ++mi)
 #pragma unroll
-        for (int o = 0; o < NO; ++o) t[mi][o].load(rs, v0 + mi * step + 8 * o * ES);
+        for (int o = 0; o < NO; ++o) t[mi][o].load(rs, roff(mi, ldc, cb) + 8 * o * ES);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -203,14 +222,13 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
           t[mi % LW][o].unpack(f);
 #pragma unroll
           for (int i = 0; i < 8; ++i) acc[mi][(c0 + 8 * o + i) / 4][i & 3] += f[i];
-          if (mi + LW < MI) t[mi % LW][o].load(rs, v0 + (mi + LW) * step + 8 * o * ES);
+          if (mi + LW < MI) t[mi % LW][o].load(rs, roff(mi + LW, ldc, cb) + 8 * o * ES);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     };
     auto store_rows = [&](void* base, int ldc, bool bnrelu) {  // bnrelu: max(acc * sc + sh, 0) on the way out (a select, not a branch)
       const __amdgpu_buffer_rsrc_t rs = rsrc(base, ldc);
-      const int v0 = (row0 * ldc + cb) * ES, step = RSTEP * ldc * ES;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -222,7 +240,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
             const float y = fmaxf(x * sc[8 * o + i] + sh[8 * o + i], 0.f);
             f[i] = bnrelu ? y : x;
           }
-          Raw8<T>::store(rs, v0 + mi * step + 8 * o * ES, f);
+          Raw8<T>::store(rs, roff(mi, ldc, cb) + 8 * o * ES, f);
         }
     };
     if (e.add0) add_rows(e.add0, e.ldc_add0);
@@ -238,7 +256,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
       const int hw = a.Ho * a.Wo;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        const int m = row0 + mi * RSTEP;
+        const int m = row0 + mi * RSTEP;  // (MAP 2 never comes with dropout: the host keeps such launches on the plain path)
         if (m >= a.epi_M) continue;
         const float* d = e.drop + (long long)(m / hw) * a.Cd + cb;
         float v[CW];
@@ -268,12 +286,11 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
     }
     if (e.mode == PS_EPI_RELUBWD) {  // in place: acc = mask > 0 ? acc * sc : 0 [+ add1]
       const __amdgpu_buffer_rsrc_t rs = rsrc(e.mask_src, e.ldc_mask);
-      const int v0 = (row0 * e.ldc_mask + cb) * ES, step = RSTEP * e.ldc_mask * ES;
       Raw8<T> t[LW][NO];
 #pragma unroll
       for (int mi = 0; mi < LW; ++mi)
 #pragma unroll
-        for (int o = 0; o < NO; ++o) t[mi][o].load(rs, v0 + mi * step + 8 * o * ES);
+        for (int o = 0; o < NO; ++o) t[mi][o].load(rs, roff(mi, e.ldc_mask, cb) + 8 * o * ES);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -285,7 +302,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
             const float x = acc[mi][(c0 + 8 * o + i) / 4][i & 3] * sc[8 * o + i];
             acc[mi][(c0 + 8 * o + i) / 4][i & 3] = ms[i] > 0.f ? x : 0.f;
           }
-          if (mi + LW < MI) t[mi % LW][o].load(rs, v0 + (mi + LW) * step + 8 * o * ES);
+          if (mi + LW < MI) t[mi % LW][o].load(rs, roff(mi + LW, e.ldc_mask, cb) + 8 * o * ES);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1018,7 +1035,7 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_ws_kernel(const IgemmArgs a
 //   * the loaders run two K-steps ahead (counted vmcnt), so a DMA has two barrier intervals (~2 x 1024 cycles) to land.
 // BM = 224 (7-fragment waves) makes 28x28-derived pixel counts tile exactly: 64 x 784 = 224 x 224.
 // ------------------------------------------------------------------------------------------------
-template <typename Tr, int BM>
+template <typename Tr, int BM, bool SPLIT = false>  // SPLIT: one parity class of a stride-2 data gradient (IgemmArgs::tap_mask ...)
 __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs a) {
   typedef typename Tr::elem T;
   constexpr int BN = 128, MI = BM / 32, WI = 4, WM = 16 * MI, WN = 64;
@@ -1037,7 +1054,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
   // whole round -- tens of MB -- were exposed at HBM speed before any CU could start its next tile).
   int first, G, ntiles;  // this block's tiles: first, first + G, ... < ntiles
   ps_block_items(blockIdx.x, gridDim.x, a.ntm * a.ntn, a.nb, a.tpb, first, G, ntiles);
-  const int nsteps = a.taps * a.klines;
+  const int ntap = SPLIT ? __builtin_popcount(a.tap_mask) : a.taps;
+  const int nsteps = ntap * a.klines;
   const int my_tiles = (ntiles - first + G - 1) / G;  // >= 1
   const int total_steps = my_tiles * nsteps;
 
@@ -1051,7 +1069,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
     int py[AJ], px[AJ], nb[AJ];
     unsigned woff[BJ], aoff[AJ];
     int tap = 0, kl = 0, wk = 0;
-    auto tap_offsets = [&](int t) {
+    auto tap_id = [&](int t) {  // SPLIT: the t-th tap of tap_mask
+      if constexpr (!SPLIT) return t;
+      int mk = a.tap_mask;
+      for (int i = 0; i < t; ++i) mk &= mk - 1;
+      return __builtin_ctz(mk);
+    };
+    auto tap_offsets = [&](int tt) {
+      const int t = tap_id(tt);
       const int ty = (a.taps == 1) ? a.ctr : t / 3, tx = (a.taps == 1) ? a.ctr : t - (t / 3) * 3;
       const int dy = (ty - a.ctr) * a.dstep, dx = (tx - a.ctr) * a.dstep;
       const int dmask = (1 << a.div_shift) - 1;
@@ -1074,8 +1099,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
           const int hw = a.Ho * a.Wo;
           const int n = m / hw, rem = m - n * hw;
           const int p = rem / a.Wo, q = rem - p * a.Wo;
-          py[j] = p * a.mul;
-          px[j] = q * a.mul;
+          py[j] = (SPLIT ? a.oy + 2 * p : p) * a.mul;
+          px[j] = (SPLIT ? a.ox + 2 * q : q) * a.mul;
           nb[j] = n * a.Hs * a.Ws;
         } else {
           py[j] = -(1 << 20);
@@ -1090,7 +1115,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
         const int cout = n0 + wg * WN + 4 * WI * (rho >> 2) + 4 * fi + (rho & 3);
         woff[j] = (unsigned)(cout * a.wrow_bytes) + chunk_off;
       }
-      tap = 0; kl = 0; wk = 0;
+      tap = 0; kl = 0; wk = SPLIT ? tap_id(0) * a.klines * 128 : 0;
       tap_offsets(0);
     };
     int tile = first, slot = 0, issued = 0;
@@ -1110,8 +1135,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
       wk += 128;
       if (++kl == a.klines) {
         kl = 0;
-        if (++tap < a.taps) {
+        if (++tap < ntap) {
           tap_offsets(tap);
+          if constexpr (SPLIT) wk = tap_id(tap) * a.klines * 128;
         } else if (issued < total_steps) {
           tile += G;
           tile_setup(tile);
@@ -1204,7 +1230,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
       for (int i = 0; i < WI; ++i) Tr::mma(wf1[i], xf1[mi], acc[mi][i]);
     int tm, tn;
     ps_tile_of_block(tile, a.ntn, a.ntm, tm, tn, a.supertile);
-    conv_epilogue<T, MI, WI>(a, acc, tm * BM + wm * WM, tn * BN + wn * WN, lane);
+    conv_epilogue<T, MI, WI, SPLIT ? 2 : 0>(a, acc, tm * BM + wm * WM, tn * BN + wn * WN, lane);
   }
 }
 
@@ -1446,7 +1472,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
     int tm, tn;
     ps_tile_of_block(tile, a.ntn, a.ntm, tm, tn, a.supertile);
     const int rb = tm / ncb;
-    conv_epilogue<T, MI, WI, true>(a, acc, rb * TR * W + (tm - rb * ncb) * TW + wm * 14, tn * BN + wn * WN, lane);
+    conv_epilogue<T, MI, WI, 1>(a, acc, rb * TR * W + (tm - rb * ncb) * TW + wm * 14, tn * BN + wn * WN, lane);
   }
 }
 
@@ -1687,6 +1713,48 @@ extern "C" int ps_conv2d_fwd(const ps_conv_geom* g, const void* x, const void* w
   return dispatch_bn<TraitsF32>(a, s);
 }
 
+static int g_s2split = 1;  // stride-2 3x3 data gradient as four parity-class launches: 0 off, 1 for big 16-bit problems, 2 whenever legal
+extern "C" void ps_debug_set_s2split(int v) { g_s2split = v; }
+
+// Stride-2 3x3 data gradient: an output pixel's parity (p & 1, q & 1) decides which taps meet dy at integer positions -- 1, 2, 2 or 4
+// of the 9.  Gathering all 9 per pixel (and multiplying the zero rows) does 4x the work; one launch per parity class stages and
+// multiplies only its live taps and writes its pixels of the full gradient through the epilogue's sub-grid row map.
+template <typename Tr>
+static int dgrad_s2_split(const IgemmArgs& a0, hipStream_t s) {
+  for (int cy = 0; cy < 2; ++cy)
+    for (int cx = 0; cx < 2; ++cx) {
+      IgemmArgs b = a0;
+      b.Hf = a0.Ho; b.Wf = a0.Wo;
+      b.Ho = (a0.Ho - cy + 1) / 2; b.Wo = (a0.Wo - cx + 1) / 2;
+      const int nimg = a0.M / (a0.Ho * a0.Wo);
+      b.M = nimg * b.Ho * b.Wo;
+      if (b.M == 0) continue;
+      b.oy = cy; b.ox = cx;
+      b.tap_mask = 0;
+      for (int ty = 0; ty < 3; ++ty)
+        for (int tx = 0; tx < 3; ++tx)
+          if (((cy + (ty - 1) * a0.dstep) & 1) == 0 && ((cx + (tx - 1) * a0.dstep) & 1) == 0) b.tap_mask |= 1 << (ty * 3 + tx);
+      b.ntn = a0.Cd / 128;
+      const long long t256 = (b.M + 255) / 256, t224 = (b.M + 223) / 224;
+      const long long c256 = ((t256 * b.ntn + 255) / 256) * 256, c224 = ((t224 * b.ntn + 255) / 256) * 224;
+      const bool use224 = c224 * 103 < c256 * 100;
+      b.ntm = (int)(use224 ? t224 : t256);
+      b.nb = ps_num_cus();
+      b.tpb = ps_tiles_per_block();
+      const dim3 pgrid(ps_persistent_grid((long long)b.ntm * b.ntn, b.nb, b.tpb));
+      if (use224) hipLaunchKernelGGL((conv_igemm_ws2_kernel<Tr, 224, true>), pgrid, dim3(512), 3 * (224 * 128 + 128 * 128), s, b);
+      else hipLaunchKernelGGL((conv_igemm_ws2_kernel<Tr, 256, true>), pgrid, dim3(512), 3 * (256 * 128 + 128 * 128), s, b);
+      PS_CHECK_LAUNCH("conv_igemm_ws2<split>");
+    }
+  return PS_OK;
+}
+
+static bool dgrad_s2_split_ok(const ps_conv_geom* g, const ps_epilogue* epi) {
+  if (!g_s2split || g->stride != 2 || g->ksize != 3 || g->dilation != 1 || ps_esize(g->dtype) != 2 || epi->drop) return false;
+  if (g_use_glds != 2 || !g_use_ws2 || g->cin % 128 != 0) return false;
+  return g_s2split == 2 || ((long long)g->n * g->h * g->w / 4 / 224) * (g->cin / 128) >= 256;  // >= one round per class
+}
+
 extern "C" int ps_conv2d_dgrad(const ps_conv_geom* g, const void* dy, const void* w_dgrad, const ps_epilogue* epi, void* stream) {
   if (int rc = check_geom(g)) return rc;
   if (int rc = check_epilogue(epi, g->dtype, "conv2d_dgrad")) return rc;
@@ -1707,6 +1775,7 @@ extern "C" int ps_conv2d_dgrad(const ps_conv_geom* g, const void* dy, const void
   a.epi = *epi;
   if (int rc = set_extents(a, (long long)g->n * a.Hs * a.Ws * a.pix_bytes, (long long)g->cin * a.wrow_bytes, es)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dgrad_s2_split_ok(g, epi)) return g->dtype == PS_BF16 ? dgrad_s2_split<TraitsBF16>(a, s) : dgrad_s2_split<TraitsF16>(a, s);
   if (g->dtype == PS_BF16) return dispatch_bn<TraitsBF16>(a, s);
   if (g->dtype == PS_F16) return dispatch_bn<TraitsF16>(a, s);
   return dispatch_bn<TraitsF32>(a, s);

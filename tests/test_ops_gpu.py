@@ -715,3 +715,42 @@ def test_weight_transpose_batched_matches_permute(dtype):
     torch.cuda.synchronize()
     for src, dst, *_ in many:
         assert torch.equal(dst, src.t())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(128, 256, 56, 56, 2), (256, 512, 28, 28, 3), (128, 128, 23, 31, 2)])  # cin, cout, H, W, N (odd sizes: ragged classes)
+def test_stride2_dgrad_parity_class_launches_are_bit_identical(case, dtype):
+    """Stride-2 3x3 data gradient as four parity-class launches (only the live taps of each class) vs the one-launch path that gathers
+    all nine taps per pixel: skipping zero contributions does not change any f32 sum, so the outputs must be bit-identical -- with the
+    ReLU-mask + add1 epilogue and with a plain store."""
+    from pistoseg_amd import _lib, ops
+
+    cin, cout, h, w, n = case
+    lib = _lib.load()
+    d = dev()
+    g = torch.Generator().manual_seed(11)
+    spec = ops.ConvSpec(cin, cout, 3, 2, 1)
+    ho, wo = spec.out_hw(h, w)
+    gy = torch.randn(n, ho, wo, cout, generator=g).to(dtype).to(d)
+    wd = (torch.randn(cin, 3, 3, cout, generator=g) * 0.05).to(dtype).to(d)
+    act = torch.randn(n, h, w, cin, generator=g).to(dtype).to(d)
+    add = torch.randn(n, h, w, cin, generator=g).to(dtype).to(d)
+    sc = (torch.rand(cin, generator=g) + 0.5).to(d)
+    outs = []
+    try:
+        for mode in (0, 2):
+            lib.ps_debug_set_s2split(mode)
+            a = torch.full((n, h, w, cin), 7.0, device=d, dtype=dtype)
+            b = torch.full((n, h, w, cin), 7.0, device=d, dtype=dtype)
+            ops.conv2d_dgrad(spec, gy, wd, (h, w), mask_src=act, bn_scale=sc, add1=add, out=a)
+            ops.conv2d_dgrad(spec, gy, wd, (h, w), out_raw=b)
+            torch.cuda.synchronize()
+            outs.append((a, b))
+    finally:
+        lib.ps_debug_set_s2split(1)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # and against the CPU primitive (same check as test_conv_fwd_dgrad_wgrad)
+    q = quant(dtype)
+    wt = wd.float().cpu().permute(3, 0, 1, 2).contiguous()  # [cin][kh][kw][cout] -> OIHW of the forward conv
+    ref = torch.nn.grad.conv2d_input((n, cin, h, w), wt, q(gy.float().cpu()).permute(0, 3, 1, 2), stride=2, padding=1)
+    assert rel_err(outs[1][1].float().cpu().permute(0, 3, 1, 2), ref) < TOL[dtype]

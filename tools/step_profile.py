@@ -26,7 +26,7 @@ def wrap(name):
 for nm in ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad"): wrap(nm)
 import pistoseg_amd.resnet38d, pistoseg_amd.seg_model
 model = ResNet38dSeg(3, "bf16"); init_weights_he(model); model = model.to(D)
-tr = SegTrainer(model)
+tr = SegTrainer(model, overlap_wgrad=False)  # one stream: every launch alone on the GPU
 x = torch.randn(64, 3, 224, 224, device=D); y = torch.randint(0, 4, (64, 224, 224), device=D)
 for _ in range(3): tr.train_step(x, y)
 torch.cuda.synchronize(); rec.clear()
