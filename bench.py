@@ -156,7 +156,8 @@ def rfm_bench(args, world, rank, dev, dist_on):
     model = Net(c, precision=args.precision)
     init_weights_he(model, seed=42)
     model = model.to(dev)
-    tr = RFMTrainer(model, lr=0.01, wt_dec=5e-4, max_step=10 ** 6, process_group=torch.distributed.group.WORLD if dist_on else None)
+    tr = RFMTrainer(model, lr=0.01, wt_dec=5e-4, max_step=10 ** 6, process_group=torch.distributed.group.WORLD if dist_on else None,
+                    overlap_wgrad=not args.no_overlap)
     g = torch.Generator(device="cpu").manual_seed(4321 + rank)
     n = args.batch
     x = torch.randn(n, 3, args.tile, args.tile, generator=g).to(dev)

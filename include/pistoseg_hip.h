@@ -260,6 +260,12 @@ int ps_ecr_bwd(const float* ref, const float* rv, const float* label, const floa
  * that belong to the selection, sums[row] = sum of the selected values (of relu(values) if relu != 0). */
 int ps_topk_select(const float* x, int32_t rows, int64_t row_len, int32_t k, int32_t largest, int32_t relu, float* thr, int32_t* take,
                    float* sums, void* stream);
+/* The same with every row spread over many blocks (one launch per radix pass + a summation and a finishing launch): the single-block
+ * version walks each row five times on one CU.  workspace: ps_topk_select_workspace_bytes(rows) bytes, 16-byte aligned, contents
+ * clobbered; NULL falls back to ps_topk_select.  Results are identical (thr, take exactly; sums up to the order of a float sum). */
+int64_t ps_topk_select_workspace_bytes(int32_t rows);
+int ps_topk_select_ws(const float* x, int32_t rows, int64_t row_len, int32_t k, int32_t largest, int32_t relu, float* thr, int32_t* take,
+                      float* sums, void* workspace, int64_t workspace_bytes, void* stream);
 /* out[0] (+)= scale * sum_i x[i]   (fixed-order reduction of per-row sums). */
 int ps_sum_scaled(const float* x, int32_t n, float scale, float* out, int32_t accumulate, void* stream);
 /* out[nc] = mean over hw of x[nc, hw]   (F.adaptive_avg_pool2d(cam, 1), revise_pseudo_labels.py:253). */

@@ -137,6 +137,8 @@ PROTOTYPES = {
     "ps_ecr_tensor": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ps_ecr_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P]),
     "ps_topk_select": (C.c_int, [_P, _I, _L, _I, _I, _I, _P, _P, _P, _P]),
+    "ps_topk_select_workspace_bytes": (C.c_int64, [_I]),
+    "ps_topk_select_ws": (C.c_int, [_P, _I, _L, _I, _I, _I, _P, _P, _P, _P, C.c_int64, _P]),
     "ps_sum_scaled": (C.c_int, [_P, _I, _F, _P, _I, _P]),
     "ps_gap": (C.c_int, [_P, _P, _I, _L, _P]),
     "ps_softmargin": (C.c_int, [_P, _P, _P, _P, _I, _F, _I, _I, _P]),

@@ -248,6 +248,27 @@ __global__ __launch_bounds__(256) void ecr_tensor_kernel(const float* __restrict
     }
   }
 }
+// Tie tickets for a top-k selection: of the elements EQUAL to the threshold, take[img] belong to the selection (which ones is free).
+// The tie lanes of a wave draw their tickets with ONE returning atomic (ballot + rank), and with none once the image's quota is used
+// up: per-lane returning atomics on one address per image serialised these kernels (the maps hold few distinct values -- ReLU zeros,
+// bf16-derived numbers -- so ties come by the thousand).  Must be called by every active lane of the wave.
+__device__ __forceinline__ bool tie_ticket(bool tie, long long img, int* __restrict__ counter, const int* __restrict__ take) {
+  const unsigned long long tmask = __ballot(tie);
+  if (!tmask) return false;
+  const int lane = threadIdx.x & 63, leader = __ffsll((long long)tmask) - 1;
+  const long long img0 = __shfl(img, leader);
+  if (__ballot(tie && img != img0) == 0) {
+    int base = 0;
+    if (lane == leader) {
+      base = __atomic_load_n(&counter[img0], __ATOMIC_RELAXED);
+      if (base < take[img0]) base = atomicAdd(&counter[img0], __popcll(tmask));
+    }
+    base = __shfl(base, leader);
+    return tie && base + __popcll(tmask & ((1ull << lane) - 1ull)) < take[img];
+  }
+  return tie && atomicAdd(&counter[img], 1) < take[img];  // the wave straddles two images: one ticket per lane
+}
+
 // d rv (+)= -sign(oh - rv*label) * label * gscale on the selected (top-k) elements
 __global__ __launch_bounds__(256) void ecr_bwd_kernel(const float* __restrict__ ref, const float* __restrict__ rv, const float* __restrict__ label,
                                                       const float* __restrict__ t, const float* __restrict__ thr, const int* __restrict__ ties_take,
@@ -261,8 +282,7 @@ __global__ __launch_bounds__(256) void ecr_bwd_kernel(const float* __restrict__ 
     for (int k = 0; k < c; ++k) {
       const long long off = (img * c + k) * hw + pix;
       const float tv = t[off], th = thr[img];
-      bool sel = tv > th;
-      if (!sel && tv == th) sel = atomicAdd(&tie_counter[img], 1) < ties_take[img];
+      const bool sel = tv > th || tie_ticket(tv == th, img, tie_counter, ties_take);
       if (!sel) continue;
       float oh = rp[k * hw];
       if (k >= 1 && oh != fgmax) oh = 0.f;
@@ -305,7 +325,18 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restri
     const unsigned hi_mask = pass == 3 ? 0u : (0xFFFFFFFFu << (8 * (pass + 1)));
     for (long long i = threadIdx.x; i < row_len; i += blockDim.x) {
       const uint32_t key = fkey(r[i], largest);
-      if ((key & hi_mask) == prefix) atomicAdd(&hist[(key >> (8 * pass)) & 255u], 1u);
+      // one LDS atomic per distinct bin per wave, not per lane: the maps hold few distinct values (ReLU zeros, bf16-derived
+      // numbers), so per-lane atomics all landed on one or two bins and serialised
+      const bool act = (key & hi_mask) == prefix;
+      const unsigned bin = (key >> (8 * pass)) & 255u;
+      unsigned long long todo = __ballot(act);
+      while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned b0 = __shfl(bin, leader);
+        const unsigned long long same = __ballot(act && bin == b0);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[b0], (unsigned)__popcll(same));
+        todo &= ~same;
+      }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -337,6 +368,92 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restri
     take[blockIdx.x] = (int)s_remaining;
     sums[blockIdx.x] = s + (relu ? fmaxf(t, 0.f) : t) * (float)s_remaining;
   }
+}
+
+// The same selection with each row spread over TOPK_SPLIT-able blocks (the single-block kernel above walks a 50 K - 200 K element row
+// five times with 1024 threads on ONE CU: 440 us for 32 rows): one launch per radix pass builds the row's 256-bin histogram in a
+// global workspace (LDS histogram per block, then <= 256 atomics), every block re-derives the prefix chosen so far from the finished
+// histograms of the earlier passes (a 256-entry scan), a fifth launch sums the selected values per block and a last one adds the
+// partial sums in block order (deterministic) and writes thr / take / sums.
+struct TopkState { uint32_t prefix, remaining; };
+__device__ __forceinline__ TopkState topk_state(const unsigned* __restrict__ ghist /* [4][256] of this row */, int k, int upto_pass) {
+  TopkState st{0u, (uint32_t)k};
+  for (int pass = 3; pass > upto_pass; --pass) {  // passes already histogrammed
+    const unsigned* h = ghist + pass * 256;
+    unsigned rem = st.remaining, b = 0;
+    for (; b < 256; ++b) {
+      if (h[b] >= rem) break;
+      rem -= h[b];
+    }
+    st.prefix |= b << (8 * pass);
+    st.remaining = rem;
+  }
+  return st;
+}
+__global__ __launch_bounds__(1024) void topk_hist_kernel(const float* __restrict__ x, long long row_len, long long chunk, int k, int largest, int pass,
+                                                         unsigned* __restrict__ ghist) {
+  __shared__ unsigned int hist[256];
+  __shared__ TopkState s_st;
+  const int row = blockIdx.y;
+  const float* r = x + (long long)row * row_len;
+  unsigned* gh = ghist + (long long)row * 1024;
+  if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_st = topk_state(gh, k, pass);
+  __syncthreads();
+  const unsigned prefix = s_st.prefix;
+  const unsigned hi_mask = pass == 3 ? 0u : (0xFFFFFFFFu << (8 * (pass + 1)));
+  const long long lo = (long long)blockIdx.x * chunk, hi = min(row_len, lo + chunk);
+  for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const uint32_t key = fkey(r[i], largest);
+    const bool act = (key & hi_mask) == prefix;
+    const unsigned bin = (key >> (8 * pass)) & 255u;
+    unsigned long long todo = __ballot(act);
+    while (todo) {  // one LDS atomic per distinct bin per wave
+      const int leader = __ffsll((long long)todo) - 1;
+      const unsigned b0 = __shfl(bin, leader);
+      const unsigned long long same = __ballot(act && bin == b0);
+      if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[b0], (unsigned)__popcll(same));
+      todo &= ~same;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 256 && hist[threadIdx.x]) atomicAdd(&gh[pass * 256 + threadIdx.x], hist[threadIdx.x]);
+}
+__global__ __launch_bounds__(1024) void topk_sum_kernel(const float* __restrict__ x, long long row_len, long long chunk, int k, int largest, int relu,
+                                                        const unsigned* __restrict__ ghist, float* __restrict__ partial) {
+  __shared__ TopkState s_st;
+  __shared__ float red[16];
+  const int row = blockIdx.y;
+  const float* r = x + (long long)row * row_len;
+  if (threadIdx.x == 0) s_st = topk_state(ghist + (long long)row * 1024, k, -1);
+  __syncthreads();
+  const uint32_t kth = s_st.prefix;
+  const long long lo = (long long)blockIdx.x * chunk, hi = min(row_len, lo + chunk);
+  float local = 0.f;
+  for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const float v = r[i];
+    if (fkey(v, largest) < kth) local += relu ? fmaxf(v, 0.f) : v;
+  }
+  local = ps_wave_sum(local);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float sm = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sm += red[w];
+    partial[(long long)row * gridDim.x + blockIdx.x] = sm;
+  }
+}
+__global__ __launch_bounds__(64) void topk_finish_kernel(const unsigned* __restrict__ ghist, const float* __restrict__ partial, int rows, int nblk, int k,
+                                                         int largest, int relu, float* __restrict__ thr, int* __restrict__ take, float* __restrict__ sums) {
+  const int row = blockIdx.x * 64 + threadIdx.x;
+  if (row >= rows) return;
+  const TopkState st = topk_state(ghist + (long long)row * 1024, k, -1);
+  const float t = fkey_inv(st.prefix, largest);
+  float sm = 0.f;
+  for (int b = 0; b < nblk; ++b) sm += partial[(long long)row * nblk + b];
+  thr[row] = t;
+  take[row] = (int)st.remaining;
+  sums[row] = sm + (relu ? fmaxf(t, 0.f) : t) * (float)st.remaining;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -409,10 +526,10 @@ __global__ __launch_bounds__(256) void minpool_bwd_kernel(const float* __restric
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const long long img = i / hw, pix = i - img * hw;
     const float v = m[i], th = thr[img];
-    if (!(v > 0.f)) continue;  // relu: no gradient -- and no tie ticket: the threshold is usually 0 with tens of thousands of ties, and a
-                               // returning atomic per tie on one address per image serialised the whole kernel (11 ms at bs = 32)
-    bool sel = v < th;
-    if (!sel && v == th) sel = atomicAdd(&tie_counter[img], 1) < take[img];
+    // relu: no gradient -- and no tie ticket for v <= 0: the threshold is usually 0 with tens of thousands of ties, and a returning
+    // atomic per tie on one address per image serialised the whole kernel (11 ms at bs = 32).  Ties at a positive threshold are common
+    // too (the maps come from bf16 convolutions: few distinct values): see tie_ticket.
+    const bool sel = (v > 0.f && v < th) || tie_ticket(v > 0.f && v == th, img, tie_counter, take);
     if (!sel) continue;
     const int k = arg[i];
     dx[(img * c + k) * hw + pix] += gscale * label[img * c + k];
@@ -515,6 +632,43 @@ extern "C" int ps_topk_select(const float* x, int32_t rows, int64_t row_len, int
   hipLaunchKernelGGL(topk_select_kernel, dim3(rows), dim3(1024), 0, static_cast<hipStream_t>(stream), x, (long long)row_len, k, largest, relu, thr,
                      take, sums);
   PS_CHECK_LAUNCH("topk_select");
+  return PS_OK;
+}
+
+static int topk_blocks_per_row(int rows, long long row_len) {
+  long long b = (2LL * ps_num_cus() + rows - 1) / rows;         // ~2 blocks per CU in total
+  const long long maxb = (row_len + 4095) / 4096;               // at least 4 elements per thread
+  if (b > maxb) b = maxb;
+  if (b > 64) b = 64;
+  return b < 1 ? 1 : (int)b;
+}
+extern "C" int64_t ps_topk_select_workspace_bytes(int32_t rows) { return rows <= 0 ? 0 : (int64_t)rows * (1024 + 64) * 4; }
+
+extern "C" int ps_topk_select_ws(const float* x, int32_t rows, int64_t row_len, int32_t k, int32_t largest, int32_t relu, float* thr, int32_t* take,
+                                 float* sums, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!workspace) return ps_topk_select(x, rows, row_len, k, largest, relu, thr, take, sums, stream);
+  PS_REQUIRE(x && thr && take && sums && rows > 0 && row_len > 0 && k >= 1 && k <= row_len, "topk_select: bad argument (k=%d, len=%lld)", k,
+             (long long)row_len);
+  PS_REQUIRE(workspace_bytes >= ps_topk_select_workspace_bytes(rows) && ps_aligned16(workspace), "topk_select: workspace of %lld bytes, need %lld",
+             (long long)workspace_bytes, (long long)ps_topk_select_workspace_bytes(rows));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  unsigned* ghist = static_cast<unsigned*>(workspace);
+  float* partial = reinterpret_cast<float*>(ghist + (long long)rows * 1024);
+  const int nblk = topk_blocks_per_row(rows, row_len);
+  const long long chunk = (row_len + nblk - 1) / nblk;
+  if (hipMemsetAsync(ghist, 0, (size_t)rows * 1024 * 4, s) != hipSuccess) {
+    ps_set_error("topk_select: hipMemsetAsync failed");
+    return PS_ERR_LAUNCH;
+  }
+  const dim3 grid(nblk, rows);
+  for (int pass = 3; pass >= 0; --pass) {
+    hipLaunchKernelGGL(topk_hist_kernel, grid, dim3(1024), 0, s, x, (long long)row_len, chunk, k, largest, pass, ghist);
+    PS_CHECK_LAUNCH("topk_hist");
+  }
+  hipLaunchKernelGGL(topk_sum_kernel, grid, dim3(1024), 0, s, x, (long long)row_len, chunk, k, largest, relu, ghist, partial);
+  PS_CHECK_LAUNCH("topk_sum");
+  hipLaunchKernelGGL(topk_finish_kernel, dim3((rows + 63) / 64), dim3(64), 0, s, ghist, partial, rows, nblk, k, largest, relu, thr, take, sums);
+  PS_CHECK_LAUNCH("topk_finish");
   return PS_OK;
 }
 

@@ -470,7 +470,10 @@ def topk_select(x: Tensor, k: int, largest: bool, relu: bool = False):
     take = torch.empty(rows, device=x.device, dtype=torch.int32)
     sums = torch.empty(rows, device=x.device, dtype=torch.float32)
     lib = _lib.load()
-    _lib.check(lib.ps_topk_select(x.data_ptr(), rows, length, k, int(largest), int(relu), thr.data_ptr(), take.data_ptr(), sums.data_ptr(), _stream()), "ps_topk_select")
+    need = int(lib.ps_topk_select_workspace_bytes(rows))
+    ws = torch.empty(need, device=x.device, dtype=torch.uint8)  # (caching allocator: no real allocation after the first step)
+    _lib.check(lib.ps_topk_select_ws(x.data_ptr(), rows, length, k, int(largest), int(relu), thr.data_ptr(), take.data_ptr(), sums.data_ptr(),
+                                     ws.data_ptr(), need, _stream()), "ps_topk_select_ws")
     return thr, take, sums
 
 

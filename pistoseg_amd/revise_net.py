@@ -158,6 +158,7 @@ class Net(ResNet38dSeg):
         [cout][kh][kw][cin] that the weight gradients are ACCUMULATED into (caller zeroes); 'f9' maps to the packed
         [384,1,1,256] buffer (see _unpack_w9_grad)."""
         saved, F, QK, Pm, V, R = ctx["saved"], ctx["F"], ctx["QK"], ctx["Pm"], ctx["V"], ctx["R"]
+        self.refresh_dgrad_weights()  # one launch for every data-gradient weight layout, the heads' included
         n, C = saved.n, self.classes
         g1, g2 = ctx["g"]
         P = g1 * g2

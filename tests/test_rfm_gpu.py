@@ -224,3 +224,39 @@ def test_rfm_trainer_step_matches_autograd_path_and_poly_optimizer():
     for k in s1:
         if s1[k].is_floating_point():
             assert float((s1[k] - s2[k]).abs().max()) <= 1e-5 + 1e-3 * float((s2[k] - sd[k]).abs().max()), k
+
+
+@pytest.mark.parametrize("largest", [True, False])
+@pytest.mark.parametrize("shape", [(5, 50176), (3, 200704), (2, 777), (1, 64)])
+def test_topk_select_multi_block_matches_torch_topk(shape, largest):
+    """ps_topk_select_ws (rows spread over many blocks) against torch.topk on data full of ties (few distinct values, ReLU zeros):
+    threshold and tie count exactly, sum of the selection to float-summation accuracy; and against the single-block C-ABI entry."""
+    import ctypes as C
+
+    from pistoseg_amd import _lib, ops
+
+    rows, n = shape
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(rows, n, generator=g) * 4).round() / 4  # quarter steps: many equal values
+    x = torch.where(torch.rand(rows, n, generator=g) < 0.3, torch.zeros(()), x)
+    k = max(1, n // 4)
+    xd = x.to(D)
+    for relu in (False, True):
+        thr, take, sums = ops.topk_select(xd, k, largest=largest, relu=relu)
+        torch.cuda.synchronize()
+        vals = torch.topk(x.double(), k, dim=1, largest=largest)[0]
+        kth = vals[:, -1]
+        assert torch.equal(thr.cpu().double(), kth)
+        strict = (x.double() > kth[:, None]) if largest else (x.double() < kth[:, None])
+        assert torch.equal(take.cpu().long(), k - strict.sum(1))
+        want = (vals.clamp_min(0) if relu else vals).sum(1)
+        assert torch.allclose(sums.cpu().double(), want, rtol=1e-5, atol=1e-3)
+        # the single-block entry gives the same threshold / tie count
+        lib = _lib.load()
+        t1 = torch.empty(rows, device=D)
+        k1 = torch.empty(rows, device=D, dtype=torch.int32)
+        s1 = torch.empty(rows, device=D)
+        _lib.check(lib.ps_topk_select(xd.data_ptr(), rows, n, k, int(largest), int(relu), t1.data_ptr(), k1.data_ptr(), s1.data_ptr(),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "ps_topk_select")
+        torch.cuda.synchronize()
+        assert torch.equal(t1, thr) and torch.equal(k1, take) and torch.allclose(s1, sums, rtol=1e-5, atol=1e-3)
