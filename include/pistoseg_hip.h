@@ -77,7 +77,8 @@ typedef struct ps_epilogue {
   void*       out_raw;  int32_t ldc_raw;   int32_t mode;
   const float* scale;
   const float* shift;
-  const float* drop;                        /* [n, C] f32 multipliers, or NULL */
+  const float* drop;                        /* [n, C] f32 dropout multipliers (>= 0: 0 or 1/(1-p)), or NULL.  Where all rows of a wave lie in
+                                             * one image they are folded into scale/shift: max(v*(scale*drop) + shift*drop, 0) */
   const void* mask_src; int32_t ldc_mask;  int32_t _pad1;
   const void* add1;     int32_t ldc_add1;  int32_t _pad2;
   void*       out;      int32_t ldc_out;   int32_t _pad3;

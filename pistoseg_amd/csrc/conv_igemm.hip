@@ -204,6 +204,18 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
     for (int i = 0; i < CW; ++i) sc[i] = 1.f, sh[i] = 0.f;
     if (e.scale && e.mode != PS_EPI_NONE) load_vec(e.scale + cb, sc);
     if (e.shift && e.mode == PS_EPI_BNRELU) load_vec(e.shift + cb, sh);
+    // Dropout (b6 / b7): the multipliers are per (image, channel) and >= 0, so when every row of this wave lies in ONE image they fold
+    // into the per-channel affine -- max(x*sc + sh, 0) * dm = max(x*(sc*dm) + sh*dm, 0) -- and the wave takes the batched path below at
+    // no extra cost.  Waves that straddle two images keep the row-by-row path.
+    float dm[CW];
+    bool fold = false;
+    if (e.drop && e.mode != PS_EPI_NONE && MAP != 2) {
+      const int hw = a.Ho * a.Wo;
+      const int mf = row0 < a.epi_M ? row0 : 0, ml0 = row0 + (MI - 1) * RSTEP, ml = ml0 < a.epi_M ? ml0 : mf;
+      const int nf = mf / hw, nl = ml / hw, n0 = __builtin_amdgcn_readfirstlane(nf);
+      fold = __builtin_amdgcn_ballot_w64(nf != n0 || nl != n0) == 0;
+      if (fold) load_vec(e.drop + (long long)n0 * a.Cd + cb, dm);
+    }
     // Row loads run LW rows ahead of their use (a row's registers are refilled with row + LW as soon as it has been consumed):
     // every load still precedes every store, with LW instead of MI rows of operands live.
     constexpr int LW = MI < 4 ? MI : 4;
@@ -247,12 +259,16 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
     __builtin_amdgcn_sched_barrier(0);  // keep the phases apart: a hoisted second batch of loads would double the live registers
     // scale / shift have arrived by now; "use" them before the first store so that the compiler's wait for them does not become
     // a vmcnt(0) behind the stores below
+    if (fold) {
+#pragma unroll
+      for (int i = 0; i < CW; ++i) sc[i] *= dm[i], sh[i] *= dm[i];
+    }
 #pragma unroll
     for (int i = 0; i < CW; ++i) asm volatile("" ::"v"(sc[i]), "v"(sh[i]));
     if (e.out_raw) store_rows(e.out_raw, e.ldc_raw, false);
     if (e.mode == PS_EPI_NONE) continue;  // next channel chunk
-    if (e.drop) {
-      // dropout layers (b6 / b7 only): per-row multipliers, row by row
+    if (e.drop && !fold) {
+      // dropout, rows of more than one image: per-row multipliers, row by row
       const int hw = a.Ho * a.Wo;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
