@@ -376,31 +376,40 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restri
 // histograms of the earlier passes (a 256-entry scan), a fifth launch sums the selected values per block and a last one adds the
 // partial sums in block order (deterministic) and writes thr / take / sums.
 struct TopkState { uint32_t prefix, remaining; };
-__device__ __forceinline__ TopkState topk_state(const unsigned* __restrict__ ghist /* [4][256] of this row */, int k, int upto_pass) {
-  TopkState st{0u, (uint32_t)k};
+// Block-cooperative: the finished histograms of the passes above `upto_pass` are copied into LDS by 256 threads each, thread 0 walks
+// them there (a single thread walking them in global memory cost ~50 us of dependent loads per launch).  All threads must call it;
+// returns the state to every thread.  lds: 256 uints + 2.
+__device__ __forceinline__ TopkState topk_state(const unsigned* __restrict__ ghist /* [4][256] of this row */, int k, int upto_pass, unsigned* lds) {
+  if (threadIdx.x == 0) { lds[256] = 0u; lds[257] = (unsigned)k; }
   for (int pass = 3; pass > upto_pass; --pass) {  // passes already histogrammed
-    const unsigned* h = ghist + pass * 256;
-    unsigned rem = st.remaining, b = 0;
-    for (; b < 256; ++b) {
-      if (h[b] >= rem) break;
-      rem -= h[b];
+    __syncthreads();
+    if (threadIdx.x < 256) lds[threadIdx.x] = ghist[pass * 256 + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned rem = lds[257], b = 0;
+      for (; b < 256; ++b) {
+        if (lds[b] >= rem) break;
+        rem -= lds[b];
+      }
+      lds[256] |= b << (8 * pass);
+      lds[257] = rem;
     }
-    st.prefix |= b << (8 * pass);
-    st.remaining = rem;
   }
+  __syncthreads();
+  const TopkState st{lds[256], lds[257]};
+  __syncthreads();
   return st;
 }
 __global__ __launch_bounds__(1024) void topk_hist_kernel(const float* __restrict__ x, long long row_len, long long chunk, int k, int largest, int pass,
                                                          unsigned* __restrict__ ghist) {
   __shared__ unsigned int hist[256];
-  __shared__ TopkState s_st;
+  __shared__ unsigned int st_lds[258];
   const int row = blockIdx.y;
   const float* r = x + (long long)row * row_len;
   unsigned* gh = ghist + (long long)row * 1024;
+  const unsigned prefix = topk_state(gh, k, pass, st_lds).prefix;
   if (threadIdx.x < 256) hist[threadIdx.x] = 0;
-  if (threadIdx.x == 0) s_st = topk_state(gh, k, pass);
   __syncthreads();
-  const unsigned prefix = s_st.prefix;
   const unsigned hi_mask = pass == 3 ? 0u : (0xFFFFFFFFu << (8 * (pass + 1)));
   const long long lo = (long long)blockIdx.x * chunk, hi = min(row_len, lo + chunk);
   for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
@@ -421,13 +430,11 @@ __global__ __launch_bounds__(1024) void topk_hist_kernel(const float* __restrict
 }
 __global__ __launch_bounds__(1024) void topk_sum_kernel(const float* __restrict__ x, long long row_len, long long chunk, int k, int largest, int relu,
                                                         const unsigned* __restrict__ ghist, float* __restrict__ partial) {
-  __shared__ TopkState s_st;
+  __shared__ unsigned int st_lds[258];
   __shared__ float red[16];
   const int row = blockIdx.y;
   const float* r = x + (long long)row * row_len;
-  if (threadIdx.x == 0) s_st = topk_state(ghist + (long long)row * 1024, k, -1);
-  __syncthreads();
-  const uint32_t kth = s_st.prefix;
+  const uint32_t kth = topk_state(ghist + (long long)row * 1024, k, -1, st_lds).prefix;
   const long long lo = (long long)blockIdx.x * chunk, hi = min(row_len, lo + chunk);
   float local = 0.f;
   for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
@@ -443,14 +450,15 @@ __global__ __launch_bounds__(1024) void topk_sum_kernel(const float* __restrict_
     partial[(long long)row * gridDim.x + blockIdx.x] = sm;
   }
 }
-__global__ __launch_bounds__(64) void topk_finish_kernel(const unsigned* __restrict__ ghist, const float* __restrict__ partial, int rows, int nblk, int k,
-                                                         int largest, int relu, float* __restrict__ thr, int* __restrict__ take, float* __restrict__ sums) {
-  const int row = blockIdx.x * 64 + threadIdx.x;
-  if (row >= rows) return;
-  const TopkState st = topk_state(ghist + (long long)row * 1024, k, -1);
+__global__ __launch_bounds__(256) void topk_finish_kernel(const unsigned* __restrict__ ghist, const float* __restrict__ partial, int nblk, int k,
+                                                          int largest, int relu, float* __restrict__ thr, int* __restrict__ take, float* __restrict__ sums) {
+  __shared__ unsigned int st_lds[258];
+  const int row = blockIdx.x;  // one block per row
+  const TopkState st = topk_state(ghist + (long long)row * 1024, k, -1, st_lds);
+  if (threadIdx.x != 0) return;
   const float t = fkey_inv(st.prefix, largest);
   float sm = 0.f;
-  for (int b = 0; b < nblk; ++b) sm += partial[(long long)row * nblk + b];
+  for (int b = 0; b < nblk; ++b) sm += partial[(long long)row * nblk + b];  // block order: deterministic
   thr[row] = t;
   take[row] = (int)st.remaining;
   sums[row] = sm + (relu ? fmaxf(t, 0.f) : t) * (float)st.remaining;
@@ -667,7 +675,7 @@ extern "C" int ps_topk_select_ws(const float* x, int32_t rows, int64_t row_len, 
   }
   hipLaunchKernelGGL(topk_sum_kernel, grid, dim3(1024), 0, s, x, (long long)row_len, chunk, k, largest, relu, ghist, partial);
   PS_CHECK_LAUNCH("topk_sum");
-  hipLaunchKernelGGL(topk_finish_kernel, dim3((rows + 63) / 64), dim3(64), 0, s, ghist, partial, rows, nblk, k, largest, relu, thr, take, sums);
+  hipLaunchKernelGGL(topk_finish_kernel, dim3(rows), dim3(256), 0, s, ghist, partial, nblk, k, largest, relu, thr, take, sums);
   PS_CHECK_LAUNCH("topk_finish");
   return PS_OK;
 }
