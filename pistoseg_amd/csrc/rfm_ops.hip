@@ -17,7 +17,9 @@ __device__ __forceinline__ void st(void* p, int dtype, long long i, float v) {
 
 // ------------------------------------------------------------------------------------------------
 // Batched strided GEMM  C[b][m][n] = alpha * sum_k A[b][m*sam + k*sak] * B[b][k*sbk + n*sbn]
-// 64x64 tile, 16-deep K steps, 256 threads x (4x4) outputs.
+// 64x64 tile, 16-deep K steps staged in LDS as f32 (any input dtype), four waves of 32x32 on the exact-f32 MFMA 16x16x4
+// (a lane supplies A[row = lane & 15][k = lane >> 4] and B[k][col = lane & 15]; LDS rows of 80 floats: the four k-groups of a
+// fragment read hit disjoint banks).
 // ------------------------------------------------------------------------------------------------
 struct BgemmArgs {
   const void* A; const void* B; void* C;
@@ -26,13 +28,19 @@ struct BgemmArgs {
   long long sab, sam, sak, sbb, sbk, sbn, scb, scm, scn;
   float alpha;
 };
+typedef float bg_f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmArgs a) {
-  __shared__ float As[16][65], Bs[16][65];
+  __shared__ float As[16][80], Bs[16][80];
   const int b = blockIdx.z, m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, l16 = lane & 15, g = lane >> 4;
   const unsigned char* Ab = static_cast<const unsigned char*>(a.A);
   const unsigned char* Bb = static_cast<const unsigned char*>(a.B);
-  float acc[4][4] = {};
+  bg_f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = bg_f32x4{0.f, 0.f, 0.f, 0.f};
   for (int k0 = 0; k0 < a.K; k0 += 16) {
     for (int e = threadIdx.x; e < 16 * 64; e += 256) {
       // pick the index that is contiguous in memory as the fast one
@@ -47,24 +55,29 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmArgs a) {
     }
     __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      float av[4], bv[4];
+    for (int k4 = 0; k4 < 4; ++k4) {
+      float av[2], bv[2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { av[i] = As[kk][ty * 4 + i]; bv[i] = Bs[kk][tx * 4 + i]; }
+      for (int i = 0; i < 2; ++i) {
+        av[i] = As[4 * k4 + g][wm * 32 + i * 16 + l16];
+        bv[i] = Bs[4 * k4 + g][wn * 32 + i * 16 + l16];
+      }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
-      if (m < a.M && n < a.N) st(a.C, a.cdt, b * a.scb + m * a.scm + n * a.scn, a.alpha * acc[i][j]);
-    }
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 32 + i * 16 + 4 * g + r, n = n0 + wn * 32 + j * 16 + l16;
+        if (m < a.M && n < a.N) st(a.C, a.cdt, b * a.scb + m * a.scm + n * a.scn, a.alpha * acc[i][j][r]);
+      }
 }
 
 // in-place softmax of rows of length len (one wave per row)
