@@ -1,0 +1,35 @@
+"""Whole training steps beside a kernel that holds `hog` CUs (an RCCL all-reduce beside the backward): static persistent schedule
+(tiles_per_block 0) vs 1-2 tiles per block, with the weight gradients on the side stream (two kernels share the GPU anyway)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pistoseg_amd import _lib
+from pistoseg_amd.seg_model import ResNet38dSeg
+from pistoseg_amd.trainer import SegTrainer, init_weights_he
+
+lib = _lib.load()
+D = torch.device("cuda:0")
+model = ResNet38dSeg(3, "bf16"); init_weights_he(model, seed=1); model = model.to(D)
+tr = SegTrainer(model)
+x = torch.randn(64, 3, 224, 224, device=D); y = torch.randint(0, 4, (64, 224, 224), device=D)
+hog_stream = torch.cuda.Stream()
+for _ in range(3): tr.train_step(x, y)
+torch.cuda.synchronize()
+for hog in (0, 16, 32):
+    for tpb in (0, 2, 1):
+        lib.ps_set_tiles_per_block(tpb)
+        best = 1e9
+        for _ in range(2):
+            torch.cuda.synchronize()
+            if hog:
+                with torch.cuda.stream(hog_stream):
+                    _lib.check(lib.ps_debug_hog(hog, 400000, 96 * 1024, hog_stream.cuda_stream), "hog")  # 0.4 s, 96 KiB LDS each: those CUs are lost
+                torch.cuda._sleep(2000000)
+            t0 = time.perf_counter()
+            for _ in range(8): tr.train_step(x, y)
+            torch.cuda.current_stream().synchronize()
+            tr.wgrad_stream.synchronize()
+            best = min(best, (time.perf_counter() - t0) / 8)
+            torch.cuda.synchronize()
+        print(f"hog={hog:2d} CUs tpb={tpb}: {best*1e3:6.2f} ms/step  {64/best:6.0f} tiles/s", flush=True)
+lib.ps_set_tiles_per_block(0)
