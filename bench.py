@@ -122,7 +122,9 @@ def roofline_leg(run_step, precision):
 
 
 def cpu_baseline(tiles, tile, classes):
-    """The CPU oracle's training step (fwd + CE + bwd + AdamW) on a bounded sample; oracle = checker, timed beside."""
+    """The CPU oracle's training step (fwd + CE + bwd + AdamW) on a bounded sample; oracle = checker, timed beside.
+    One warm-up step, then one timed step with all host threads (the `value`); and one timed step with two threads, the setting the
+    reference's own entry scripts pin (segmentation_train.py:21-27) -- SURVEY 8d asks for both."""
     from oracle import ref_cpu
 
     threads = torch.get_num_threads()
@@ -133,18 +135,36 @@ def cpu_baseline(tiles, tile, classes):
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(tiles, 3, tile, tile, generator=g)
     y = torch.randint(0, classes + 1, (tiles, tile, tile), generator=g)
-    t0 = time.perf_counter()
-    loss = ref_cpu.seg_ce_loss(ref_cpu.seg_forward(sd, x), y, classes)
-    loss.backward()
-    opt.step()
-    dt = time.perf_counter() - t0
+
+    def step():
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        loss = ref_cpu.seg_ce_loss(ref_cpu.seg_forward(sd, x), y, classes)
+        loss.backward()
+        opt.step()
+        return time.perf_counter() - t0
+
+    step()  # warm-up (allocator, thread pool)
+    dt = step()
     with torch.no_grad():
         t1 = time.perf_counter()
         ref_cpu.seg_forward(sd, x)
         dti = time.perf_counter() - t1
-    return {"value": round(tiles / dt, 4), "unit": "tiles/s", "cores": threads, "kind": "port",
-            "sample": f"1 un-warmed training step (fwd+CE+bwd+AdamW) on {tiles} synthetic {tile}x{tile} tiles, torch CPU fp32",
-            "infer_value": round(tiles / dti, 4)}
+    out = {"value": round(tiles / dt, 4), "unit": "tiles/s", "cores": threads, "kind": "port",
+           "sample": f"1 training step (fwd+CE+bwd+AdamW, after 1 warm-up step) on {tiles} synthetic {tile}x{tile} tiles, torch CPU fp32",
+           "infer_value": round(tiles / dti, 4)}
+    if threads > 2:
+        torch.set_num_threads(2)
+        try:
+            x1, y1 = x[:1], y[:1]
+            t0 = time.perf_counter()
+            opt.zero_grad(set_to_none=True)
+            ref_cpu.seg_ce_loss(ref_cpu.seg_forward(sd, x1), y1, classes).backward()
+            opt.step()
+            out["value_2_threads"] = round(1 / (time.perf_counter() - t0), 4)  # 1 tile: the reference's thread setting
+        finally:
+            torch.set_num_threads(threads)
+    return out
 
 
 def rfm_bench(args, world, rank, dev, dist_on):
