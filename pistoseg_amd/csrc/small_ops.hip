@@ -115,21 +115,34 @@ __global__ __launch_bounds__(256) void conv1a_lowp_kernel(const float* __restric
   }
   const long long total = (long long)n * h * wd;
   const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
-  for (long long p0 = wave_id * 16; p0 < total; p0 += nwaves * 16) {
+  // The NEXT 16 pixels' taps are loaded before this group's stores are issued (loads are unconditional on clamped coordinates; the
+  // validity bits zero the padding afterwards): vmcnt is one in-order queue, a load issued behind the stores would wait for them.
+  float raw[8];
+  unsigned vmask = 0;
+  auto gather = [&](long long p0) {
     const long long pix = p0 + col;
     const bool live = pix < total;
     const int img = live ? (int)(pix / ((long long)h * wd)) : 0;
     const int rem = live ? (int)(pix - (long long)img * h * wd) : 0;
     const int y = rem / wd, xx = rem - y * wd;
     const float* xb = x + (long long)img * 3 * h * wd;
-    t8 bv;
+    vmask = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int yy = y + tdy[e], xs = xx + tdx[e];
-      float v = 0.f;
-      if (live && yy >= 0 && yy < h && xs >= 0 && xs < wd) v = xb[toff[e] + yy * wd + xs];
-      bv[e] = static_cast<T>(v);
+      const bool ok = live && yy >= 0 && yy < h && xs >= 0 && xs < wd;
+      raw[e] = xb[ok ? toff[e] + yy * wd + xs : 0];  // (k >= 27 and padding taps read the image's first element, masked off)
+      vmask |= (ok ? 1u : 0u) << e;
     }
+  };
+  gather(wave_id * 16);
+  for (long long p0 = wave_id * 16; p0 < total; p0 += nwaves * 16) {
+    const long long pix = p0 + col;
+    const bool live = pix < total;
+    t8 bv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = static_cast<T>((vmask >> e) & 1u ? raw[e] : 0.f);
+    gather(p0 + nwaves * 16 < total ? p0 + nwaves * 16 : p0);  // (the last group re-reads itself)
     f32x4 acc[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
