@@ -530,21 +530,43 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
-template <typename SH>
+template <typename SH, bool VEC>
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                                                   SH* __restrict__ pb, long long n, float lr, float mom, float wd, int first, float ginv) {
-  const long long stride = (long long)gridDim.x * 256;
-  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
-    float pk = p[k];
-    float gk = g[k] * ginv;
+  auto upd = [&](float& pk, float gk, float& bk) {
+    gk *= ginv;
     if (wd != 0.f) gk = fmaf(wd, pk, gk);
     if (mom != 0.f) {
-      const float b = first ? gk : mom * buf[k] + gk;
-      buf[k] = b;
-      gk = b;
+      bk = first ? gk : mom * bk + gk;
+      gk = bk;
     }
     pk -= lr * gk;
+  };
+  // one element group per thread (no loop: a second iteration's loads would queue behind the first one's stores)
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * (VEC ? 4 : 1);
+  if (i >= n) return;
+  if constexpr (VEC) {
+    if (i + 4 <= n) {  // 16-byte accesses (the host checks the alignment)
+      float4 pk = *reinterpret_cast<const float4*>(p + i), bk = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 gk = *reinterpret_cast<const float4*>(g + i);
+      if (mom != 0.f && !first) bk = *reinterpret_cast<const float4*>(buf + i);
+      upd(pk.x, gk.x, bk.x); upd(pk.y, gk.y, bk.y); upd(pk.z, gk.z, bk.z); upd(pk.w, gk.w, bk.w);
+      *reinterpret_cast<float4*>(p + i) = pk;
+      if (mom != 0.f) *reinterpret_cast<float4*>(buf + i) = bk;
+      if (pb) {
+        typedef SH sh4 __attribute__((ext_vector_type(4)));
+        sh4 o;
+        o[0] = static_cast<SH>(pk.x); o[1] = static_cast<SH>(pk.y); o[2] = static_cast<SH>(pk.z); o[3] = static_cast<SH>(pk.w);
+        *reinterpret_cast<sh4*>(pb + i) = o;
+      }
+      return;
+    }
+  }
+  for (long long k = i; k < n && k < i + (VEC ? 4 : 1); ++k) {
+    float pk = p[k], bk = (mom != 0.f && !first) ? buf[k] : 0.f;
+    upd(pk, g[k], bk);
     p[k] = pk;
+    if (mom != 0.f) buf[k] = bk;
     if (pb) pb[k] = static_cast<SH>(pk);
   }
 }
@@ -786,10 +808,10 @@ extern "C" int ps_adamw_step_scaled(float* p, const float* g, float* m, float* v
   const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (p_shadow && shadow_dtype == PS_F16)
-    hipLaunchKernelGGL(adamw_kernel<_Float16>, dim3(grid_for(n, 256 * 4)), dim3(256), 0, s, p, g, m, v, (_Float16*)p_shadow, (long long)n, lr,
+    hipLaunchKernelGGL(adamw_kernel<_Float16>, dim3(grid_for(n, 256 * 4, 1 << 30)), dim3(256), 0, s, p, g, m, v, (_Float16*)p_shadow, (long long)n, lr,
                        beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_inv_scale);
   else
-    hipLaunchKernelGGL(adamw_kernel<__bf16>, dim3(grid_for(n, 256 * 4)), dim3(256), 0, s, p, g, m, v, (__bf16*)p_shadow, (long long)n, lr,
+    hipLaunchKernelGGL(adamw_kernel<__bf16>, dim3(grid_for(n, 256 * 4, 1 << 30)), dim3(256), 0, s, p, g, m, v, (__bf16*)p_shadow, (long long)n, lr,
                        beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_inv_scale);
   PS_CHECK_LAUNCH("adamw_step");
   return PS_OK;
@@ -815,12 +837,15 @@ extern "C" int ps_sgd_step_scaled(float* p, const float* g, float* buf, void* p_
   PS_REQUIRE(!p_shadow || shadow_dtype == PS_BF16 || shadow_dtype == PS_F16, "sgd_step: shadow dtype %d unsupported", shadow_dtype);
   if (n == 0) return PS_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (p_shadow && shadow_dtype == PS_F16)
-    hipLaunchKernelGGL(sgd_kernel<_Float16>, dim3(grid_for(n, 256)), dim3(256), 0, s, p, g, buf, (_Float16*)p_shadow, (long long)n, lr, momentum,
-                       weight_decay, first_step, grad_inv_scale);
-  else
-    hipLaunchKernelGGL(sgd_kernel<__bf16>, dim3(grid_for(n, 256)), dim3(256), 0, s, p, g, buf, (__bf16*)p_shadow, (long long)n, lr, momentum,
-                       weight_decay, first_step, grad_inv_scale);
+  const bool vec = ps_aligned16(p) && ps_aligned16(g) && (!buf || ps_aligned16(buf)) && (!p_shadow || (reinterpret_cast<uintptr_t>(p_shadow) & 7u) == 0);
+  const dim3 grid((unsigned)((n + (vec ? 1024 : 256) - 1) / (vec ? 1024 : 256)));
+#define PS_SGD(SH)                                                                                                                              \
+  if (vec) hipLaunchKernelGGL((sgd_kernel<SH, true>), grid, dim3(256), 0, s, p, g, buf, (SH*)p_shadow, (long long)n, lr, momentum, weight_decay, \
+                              first_step, grad_inv_scale);                                                                                     \
+  else hipLaunchKernelGGL((sgd_kernel<SH, false>), grid, dim3(256), 0, s, p, g, buf, (SH*)p_shadow, (long long)n, lr, momentum, weight_decay,    \
+                          first_step, grad_inv_scale);
+  if (p_shadow && shadow_dtype == PS_F16) { PS_SGD(_Float16) } else { PS_SGD(__bf16) }
+#undef PS_SGD
   PS_CHECK_LAUNCH("sgd_step");
   return PS_OK;
 }
