@@ -192,24 +192,35 @@ __global__ __launch_bounds__(256) void fc8_fwd_kernel(const T* __restrict__ x, i
     for (int j = 0; j < nchunks; ++j) {
       const int kc = j + rot < nchunks ? j + rot : j + rot - nchunks;
       const int k0 = kc * 512 + lane * 8;
-      float wv[C][8], dv[8];
+      float wv[C][8], dva[8], dvb[8];
 #pragma unroll
       for (int c = 0; c < C; ++c) ps_load8<float>(w + (long long)c * ldw + k0, wv[c]);
-      int ncur = m0 / ppi;  // dropout multipliers change per image only: reloaded when the wave's pixels cross into the next one
-      if (drop) ps_load8<float>(drop + (long long)ncur * K + k0, dv);
+      // the eight pixel rows are loaded back to back (rows past the end of the range re-read its last row: their sums are never
+      // written); the dropout multipliers change per image only: those of the first and of the last pixel's image cover the group
+      // unless the maps are smaller than a group (then per pixel)
+      const int na = m0 / ppi, nb = min(m0 + 7, mwe - 1) / ppi;
+      if (drop) {
+        ps_load8<float>(drop + (long long)na * K + k0, dva);
+        ps_load8<float>(drop + (long long)nb * K + k0, dvb);
+      }
+      PsRaw8<T> xr[8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) xr[p].load(x + (long long)min(m0 + p, mwe - 1) * ldc + k0);
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
-        const int m = m0 + p;
-        if (m >= mwe) break;
         float xv[8];
-        ps_load8<T>(x + (long long)m * ldc + k0, xv);
+        xr[p].unpack(xv);
         if (drop) {
-          if (m / ppi != ncur) {  // wave-uniform
-            ncur = m / ppi;
-            ps_load8<float>(drop + (long long)ncur * K + k0, dv);
-          }
+          const int n = min(m0 + p, mwe - 1) / ppi;
+          if (nb - na > 1 && n != na && n != nb) {  // wave-uniform, maps smaller than 8 pixels only
+            float dv[8];
+            ps_load8<float>(drop + (long long)n * K + k0, dv);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) xv[i] *= dv[i];
+            for (int i = 0; i < 8; ++i) xv[i] *= dv[i];
+          } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xv[i] *= (n == na ? dva[i] : dvb[i]);
+          }
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
