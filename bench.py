@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """Headline benchmark: 224x224 tiles/s of the ResNet38-d segmentation hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU over RCCL.  Under `torch.distributed.run` (WORLD_SIZE set) this process is one rank; started plainly
+with --gpus N > 1 it launches `torch.distributed.run` with N ranks of itself as a CHILD process (before any GPU call), relays the
+child's output and exits with its return code -- it never reports fewer GPUs than were asked for.
 
 Workload (BASELINE.json configs[1]): SegmentationModule-style training step -- ResNet38-d backbone + fc8 +
 bilinear upsample, per-pixel CE (ignore_index=3, mean over all pixels), backward, AdamW -- on bs=64
@@ -48,20 +52,47 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="weight gradients on the launch stream instead of a second stream")
-    ap.add_argument("--cpu-tiles", type=int, default=2)
-    ap.add_argument("--workload", default="seg", choices=["seg", "rfm"],
+    ap.add_argument("--cpu-tiles", type=int, default=8, help="tiles per CPU-baseline step (SURVEY 8d: bs=8, 1 warm-up + 3 timed)")
+    ap.add_argument("--workload", default="seg", choices=["seg", "rfm", "infer2"],
                     help="seg: BASELINE configs[1]/[4] (segmentation_train.py step, the headline metric); rfm: configs[3], the stage-3 step "
-                         "(revise_pseudo_labels.py train_epoch body: RFM net, cls + rfm + ecr losses, PolyOptimizer)")
+                         "(revise_pseudo_labels.py train_epoch body: RFM net, cls + rfm + ecr losses, PolyOptimizer); infer2: configs[2], the "
+                         "stage-2 loop (infer_pseudo_masks.py:116-154) over this rank's shard of --steps x --batch tiles")
+    ap.add_argument("--tta", action="store_true", help="infer2: d4 test-time augmentation (8 views per tile) as infer_pseudo_masks.py:96")
+    ap.add_argument("--pack", default=None, help="infer2: write logits_32x32 of every rank into this ONE packed file")
     return ap.parse_args()
 
 
+def spawn_ranks(args) -> int:
+    """--gpus N > 1 without a launcher: start N ranks of this script under torch.distributed.run as a child process.  Nothing in this
+    process has touched the GPU yet (device_count() does not initialise HIP) and it never exec()s -- it waits and relays."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"[bench] --gpus {args.gpus} asked for but {have} GPU(s) visible: refusing to report a smaller job", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def timed(fn, steps, dist_on):
+    """Wall clock over exactly `steps` calls, bracketed by barrier + synchronize on both sides, MAX over ranks (the driver contract);
+    plus a HIP event after every step on the launch stream (side streams re-join it before a step ends): the median step time."""
     if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(steps):
+    evs[0].record()
+    for i in range(steps):
         fn()
+        evs[i + 1].record()
     torch.cuda.synchronize()
     if dist_on:
         torch.distributed.barrier()
@@ -70,6 +101,8 @@ def timed(fn, steps, dist_on):
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+    timed.median_ms = per[len(per) // 2] if steps % 2 else 0.5 * (per[steps // 2 - 1] + per[steps // 2])
     return dt
 
 
@@ -122,9 +155,10 @@ def roofline_leg(run_step, precision):
 
 
 def cpu_baseline(tiles, tile, classes):
-    """The CPU oracle's training step (fwd + CE + bwd + AdamW) on a bounded sample; oracle = checker, timed beside.
-    One warm-up step, then one timed step with all host threads (the `value`); and one timed step with two threads, the setting the
-    reference's own entry scripts pin (segmentation_train.py:21-27) -- SURVEY 8d asks for both."""
+    """The CPU oracle's training step (fwd + CE + bwd + AdamW) on a bounded sample; oracle = checker, timed beside:
+    bs = `tiles` (8), one warm-up step then three timed steps with all host threads (the `value` = tiles / median step), the forward
+    alone timed the same way; then the same on two threads -- the setting the reference's own entry scripts pin
+    (segmentation_train.py:21-27) -- on a 2-tile batch, one warm-up + two timed steps."""
     from oracle import ref_cpu
 
     threads = torch.get_num_threads()
@@ -136,32 +170,35 @@ def cpu_baseline(tiles, tile, classes):
     x = torch.randn(tiles, 3, tile, tile, generator=g)
     y = torch.randint(0, classes + 1, (tiles, tile, tile), generator=g)
 
-    def step():
+    def step(xb, yb):
         t0 = time.perf_counter()
         opt.zero_grad(set_to_none=True)
-        loss = ref_cpu.seg_ce_loss(ref_cpu.seg_forward(sd, x), y, classes)
+        loss = ref_cpu.seg_ce_loss(ref_cpu.seg_forward(sd, xb), yb, classes)
         loss.backward()
         opt.step()
         return time.perf_counter() - t0
 
-    step()  # warm-up (allocator, thread pool)
-    dt = step()
-    with torch.no_grad():
-        t1 = time.perf_counter()
-        ref_cpu.seg_forward(sd, x)
-        dti = time.perf_counter() - t1
+    def fwd(xb):
+        with torch.no_grad():
+            t1 = time.perf_counter()
+            ref_cpu.seg_forward(sd, xb)
+            return time.perf_counter() - t1
+
+    med = lambda v: sorted(v)[len(v) // 2]
+    step(x, y)  # warm-up (allocator, thread pool)
+    dt = med([step(x, y) for _ in range(3)])
+    fwd(x)
+    dti = med([fwd(x) for _ in range(3)])
     out = {"value": round(tiles / dt, 4), "unit": "tiles/s", "cores": threads, "kind": "port",
-           "sample": f"1 training step (fwd+CE+bwd+AdamW, after 1 warm-up step) on {tiles} synthetic {tile}x{tile} tiles, torch CPU fp32",
+           "sample": f"training step (fwd+CE+bwd+AdamW) on {tiles} synthetic {tile}x{tile} tiles, torch CPU fp32: 1 warm-up + 3 timed steps, median",
            "infer_value": round(tiles / dti, 4)}
     if threads > 2:
         torch.set_num_threads(2)
         try:
-            x1, y1 = x[:1], y[:1]
-            t0 = time.perf_counter()
-            opt.zero_grad(set_to_none=True)
-            ref_cpu.seg_ce_loss(ref_cpu.seg_forward(sd, x1), y1, classes).backward()
-            opt.step()
-            out["value_2_threads"] = round(1 / (time.perf_counter() - t0), 4)  # 1 tile: the reference's thread setting
+            x2, y2 = x[:2], y[:2]
+            step(x2, y2)
+            out["value_2_threads"] = round(2 / med([step(x2, y2) for _ in range(2)]), 4)
+            out["sample_2_threads"] = "same step on 2 tiles with torch.set_num_threads(2) (the reference's own setting): 1 warm-up + 2 timed"
         finally:
             torch.set_num_threads(threads)
     return out
@@ -202,16 +239,107 @@ def rfm_bench(args, world, rank, dev, dist_on):
                        "per_gpu_batch": n, "global_batch": n * world, "tile": args.tile, "parallelism": f"dp{world}"}}))
 
 
+def infer2_bench(args, world, rank, dev, dist_on):
+    """BASELINE configs[2]: infer_pseudo_masks.py's stage-2 loop (:116-154) -- forward (x8 d4 views with --tta), 32x32 bilinear
+    downsample, label-masked softmax / entropy / argmax / background fill -- over a tile set sharded by contiguous ranges, no
+    collective on the data path.  Every rank owns --steps x --batch tiles (weak scaling; 20 x 64 = 1280 ~ the 1250 of 10k / 8),
+    resident in HBM; one timed "pass" = `infer.infer_pseudo_masks` over the rank's whole shard, a step = one batch of it."""
+    from pistoseg_amd import infer
+    from pistoseg_amd.packed import PackedTilesWriter
+    from pistoseg_amd.seg_model import ResNet38dSeg
+    from pistoseg_amd.trainer import init_weights_he
+
+    c, n, s = args.classes, args.batch, args.tile
+    model = ResNet38dSeg(classes=c, precision=args.precision)
+    init_weights_he(model, seed=42)
+    model = model.to(dev)
+    model.eval()
+    per_rank = args.steps * n
+    total = per_rank * world
+    lo, hi = rank * per_rank, (rank + 1) * per_rank  # == dist.shard_range(total, rank, world)
+    g = torch.Generator(device="cpu").manual_seed(977 + rank)
+    # the rank's shard only is materialised (device-resident); indices outside [lo, hi) are never touched by infer_pseudo_masks
+    base = torch.randn(n, 3, s, s, generator=g).to(dev)
+    shard = base.repeat(args.steps, 1, 1, 1)
+    lab = (torch.rand(per_rank, c, generator=g) < 0.6).float()
+    lab[torch.arange(per_rank), torch.randint(0, c, (per_rank,), generator=g)] = 1.0
+    tissue = (torch.rand(per_rank, s, s, generator=g) > 0.2).to(torch.uint8).mul_(255).to(dev)
+
+    class _Shard:  # [T,...] view whose rows [lo, hi) live on this rank
+        def __init__(self, t, shape0):
+            self.t, self.shape = t, (shape0,) + tuple(t.shape[1:])
+
+        def __getitem__(self, sl):
+            return self.t[sl.start - lo:sl.stop - lo]
+
+    writer = None
+    if args.pack:
+        if dist_on:
+            torch.distributed.barrier()
+        writer = PackedTilesWriter(args.pack, [f"tile{i:06d}" for i in range(total)], (c, 32, 32), shared=True)
+
+    def one_pass():
+        return infer.infer_pseudo_masks(model, _Shard(shard, total), _Shard(lab.to(dev), total), _Shard(tissue, total), batch_size=n,
+                                        rank=rank, world=world, tta=args.tta, writer=writer)
+
+    for _ in range(max(1, min(args.warmup, 2))):
+        one_pass()
+    dt = timed(one_pass, 1, dist_on)
+    out_lo, out_hi, small, masks, ents = one_pass()
+    assert (out_lo, out_hi) == (lo, hi) and small.shape == (per_rank, c, 32, 32) and masks.shape == (per_rank, s, s)
+
+    # per-pixel tail: HIP events around interpolate_tensor + get_mask_pred_and_entropy of one batch; HBM roofline
+    logits = model(base)
+    labd = lab[:n].to(dev)
+    tail_ms = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        infer.interpolate_tensor(logits)
+        infer.get_mask_pred_and_entropy(logits, tissue[:n], labd)
+        e1.record()
+        torch.cuda.synchronize()
+        tail_ms.append(e0.elapsed_time(e1))
+    tail = sorted(tail_ms)[2]
+    # algorithmic bytes per tile: argmax reads C*S^2 f32 logits + S^2 u8 tissue, writes S^2 u8 mask + S^2 f32 entropy; the 32x32
+    # downsample reads 32*32*C*{1 (S=224: exact tap) | 4} f32 and writes 32*32*C f32
+    taps = 1 if s == 224 else 4
+    tail_bytes = n * (c * s * s * 4 + s * s + s * s + s * s * 4 + 32 * 32 * c * 4 * (taps + 1))
+    views = 8 if args.tta else 1
+    if dist_on:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        value = total / dt
+        print(json.dumps({
+            "metric": "224x224 tiles/sec (stage-2 pseudo-mask inference" + (", d4 TTA x8)" if args.tta else ")"), "value": round(value, 2),
+            "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2]: infer_pseudo_masks.py stage-2 loop over {total} synthetic tiles sharded by contiguous ranges, "
+                                   f"{c}-class ResNet38-d seg model, forward{' x8 d4 views' if args.tta else ''} + 32x32 downsample + mask/entropy",
+                       "per_gpu_batch": n, "tiles_per_gpu": per_rank, "tile": s, "parallelism": f"dp{world}", "packed_output": bool(args.pack)},
+            "infer_conv_tflops_per_gpu": round(value / world * views * GFLOP_FWD_PER_TILE * (s / 224.0) ** 2 / 1e3, 1),
+            "roofline_tail": {"bound": "hbm", "kernel": "bilinear_fwd(32x32) + argmax_mask(fill, entropy)", "achieved": round(tail_bytes / (tail * 1e-3) / 1e9, 1),
+                              "peak": 8000.0, "unit": "GB/s", "frac": round(tail_bytes / (tail * 1e-3) / 8e12, 4), "bytes_per_batch": tail_bytes,
+                              "us_per_batch": round(1e3 * tail, 1)}}))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1
-    if args.gpus != world and rank == 0 and dist_on:
-        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if args.gpus != world:
+        if rank == 0:
+            print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to mislabel the job", file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the HIP path has no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible); RCCL needs one device per rank")
     torch.cuda.set_device(local_rank)
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -229,6 +357,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     if args.workload == "rfm":
         return rfm_bench(args, world, rank, dev, dist_on)
+    if args.workload == "infer2":
+        return infer2_bench(args, world, rank, dev, dist_on)
     model = ResNet38dSeg(classes=args.classes, precision=args.precision)
     init_weights_he(model, seed=42)
     model = model.to(dev)
@@ -250,8 +380,8 @@ def main():
 
     out = {
         "metric": "224x224 tiles/sec (train fwd+bwd+opt)", "value": round(value, 2), "unit": "tiles/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "ms_per_step_median_hip_events": round(timed.median_ms, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{1 if (args.classes, args.precision, args.batch) == (3, 'bf16', 64) else 4}]: segmentation_train.py step, "
                                f"ResNet38-d seg model, {args.classes}-class CE(ignore={args.classes}), AdamW, random-init",
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "tile": args.tile, "parallelism": f"dp{world}"},
@@ -270,6 +400,7 @@ def main():
         dti = timed(infer_step, args.steps, dist_on)
         out["infer_value"] = round(tiles / dti, 2)
         out["infer_ms_per_step"] = round(1e3 * dti / args.steps, 3)
+        out["infer_ms_per_step_median_hip_events"] = round(timed.median_ms, 3)
         model.train()
 
     def serial_step():  # the instrumented step runs the weight gradients on the launch stream: per-kernel times are exclusive

@@ -498,8 +498,9 @@ def trainable_keys(sd: Dict[str, Tensor], not_training: Sequence[str] = RFM_NOT_
 
 # --------------------------------------------------------------------------------------
 # Sliding-window evaluation.  These restate host-side numpy / torch-builtin code of the
-# reference statement by statement; the arithmetic is numpy float64 adds/divides, torch.softmax and F.interpolate
-# (builtins: the same functions on both sides), so the restatement is pinned by construction (as for CE).
+# reference statement by statement.  PINNED: tests/test_oracle_golden.py checks `sliding_window_big_masks` and `multi_scale_cam`
+# bit for bit against tests/golden/seg_eval.npz / oeem_ms_cam.npz, which oracle/make_golden_eval.py minted by executing the
+# reference's own method bodies (validation_step / validation_epoch_end; the per-image statements of prepare_seg_inputs.py).
 # --------------------------------------------------------------------------------------
 def sliding_window_big_masks(batches, image_sizes: Dict[str, Tuple[int, int]], num_classes: int = 3):
     """models/segmentation_module.py:127-178 (== segmentation_test.py:141-196): `batches` yields

@@ -33,10 +33,13 @@ def get_mask_pred_and_entropy(logits: Tensor, tissue: Optional[Tensor], patch_la
 
 @torch.no_grad()
 def infer_pseudo_masks(model, images: Tensor, patch_label: Tensor, tissue: Optional[Tensor] = None, batch_size: int = 64,
-                       rank: int = 0, world: int = 1, tta: bool = False):
-    """Stage 2 over this rank's contiguous shard of `images` ([T,3,H,W], host or device).  Returns
-    (lo, hi, logits_32x32 [t,C,32,32], mask uint8 [t,H,W], entropy [t,H,W]).  tta=True wraps the model in the d4
-    test-time augmentation exactly where the reference does (infer_pseudo_masks.py:96)."""
+                       rank: int = 0, world: int = 1, tta: bool = False, writer=None):
+    """Stage 2 (infer_pseudo_masks.py:116-154) over this rank's contiguous shard of `images` ([T,3,H,W], host or device): per batch
+    forward (x8 d4 views when tta, wrapped exactly where the reference wraps: :96) -> `interpolate_tensor` to 32x32 (:126) ->
+    `get_mask_pred_and_entropy` (:137).  Returns (lo, hi, logits_32x32 [t,C,32,32], mask uint8 [t,H,W], entropy [t,H,W]); no
+    collective on the data path.  `writer` (packed.PackedTilesWriter over ALL T tiles) receives this rank's rows [lo, hi) of the
+    32x32 logits -- the reference's one `logits_32x32/<name>.pt` per tile (:127) as rows of one file -- in a single device->host
+    copy after the loop, so the launch stream never waits for the host inside the loop."""
     dev = next(model.parameters()).device
     if tta:
         from .tta import SegmentationTTAWrapper
@@ -54,7 +57,10 @@ def infer_pseudo_masks(model, images: Tensor, patch_label: Tensor, tissue: Optio
         masks.append(m)
         ents.append(en)
     cat = lambda xs: torch.cat(xs, 0) if xs else None
-    return lo, hi, cat(small), cat(masks), cat(ents)
+    small = cat(small)
+    if writer is not None and small is not None:
+        writer.write_rows(lo, small)
+    return lo, hi, small, cat(masks), cat(ents)
 
 
 @torch.no_grad()

@@ -60,10 +60,16 @@ class PackedTiles:
 
 
 class PackedTilesWriter:
-    """Write side: preallocates the file, rows are written in any order (one writer per rank over its shard_range works:
-    ranks write disjoint rows of the same file)."""
+    """Write side: preallocates the file; rows are written in any order.
 
-    def __init__(self, path: str, names: Sequence[str], item_shape: Sequence[int], dtype="float32", create: bool = True):
+    create=True  (default) one writer owns the file: it is created / truncated.
+    create=False           the file must exist with exactly this index (names, shape, dtype) -- checked.
+    shared=True            several ranks construct a writer over the SAME path concurrently and write disjoint rows (their
+                           `shard_range`): whoever gets there first publishes a fully initialised file atomically (`os.link` of a
+                           private temp file: it either appears complete or not at all), everybody else opens and checks it.  Nobody
+                           truncates, so rows already written by a faster rank survive (a stale file with a different index raises)."""
+
+    def __init__(self, path: str, names: Sequence[str], item_shape: Sequence[int], dtype="float32", create: bool = True, shared: bool = False):
         self.path = str(path)
         self.names = list(names)
         if len(set(self.names)) != len(self.names):
@@ -73,14 +79,38 @@ class PackedTilesWriter:
         meta = json.dumps({"names": self.names, "item_shape": self.item_shape, "dtype": self.dtype.str}).encode()
         off = (_HEADER.size + len(meta) + 4095) // 4096 * 4096  # page-aligned data
         nbytes = int(np.prod((len(self.names),) + self.item_shape)) * self.dtype.itemsize
-        if create:
-            os.makedirs(os.path.dirname(os.path.abspath(self.path)), exist_ok=True)
-            with open(self.path, "wb") as f:
+
+        def init_file(fname):
+            with open(fname, "wb") as f:
                 f.write(_HEADER.pack(MAGIC, len(meta), off))
                 f.write(meta)
                 f.truncate(off + nbytes)
+
+        if shared:
+            os.makedirs(os.path.dirname(os.path.abspath(self.path)), exist_ok=True)
+            if not os.path.exists(self.path):
+                tmp = f"{self.path}.{os.getpid()}.{id(self):x}.tmp"
+                init_file(tmp)
+                try:
+                    os.link(tmp, self.path)  # atomic publish; FileExistsError = another rank won
+                except FileExistsError:
+                    pass
+                finally:
+                    os.unlink(tmp)
+            self._check_existing(meta, off)
+        elif create:
+            os.makedirs(os.path.dirname(os.path.abspath(self.path)), exist_ok=True)
+            init_file(self.path)
+        else:
+            self._check_existing(meta, off)
         self.array = np.memmap(self.path, dtype=self.dtype, mode="r+", offset=off, shape=(len(self.names),) + self.item_shape)
         self.index = {n: i for i, n in enumerate(self.names)}
+
+    def _check_existing(self, meta: bytes, off: int) -> None:
+        with open(self.path, "rb") as f:
+            magic, jlen, off2 = _HEADER.unpack(f.read(_HEADER.size))
+            if magic != MAGIC or jlen != len(meta) or off2 != off or f.read(jlen) != meta:
+                raise ValueError(f"{self.path}: existing pack has a different index (names / shape / dtype) than this writer's")
 
     def write(self, name: str, value) -> None:
         self.write_rows(self.index[name], torch.as_tensor(value).unsqueeze(0))

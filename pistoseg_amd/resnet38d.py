@@ -123,6 +123,7 @@ class Net(nn.Module):
         self._cache: Dict[str, Tuple] = {}
         self._weights_epoch = 0           # bumped by code that rewrites parameter memory behind torch's back
         self._bf16_shadow: Dict[str, Tensor] = {}  # param name -> bf16 W_fwd view kept fresh by the fused optimiser
+        self._shadow_version: Dict[str, int] = {}  # param name -> the parameter's torch version the shadow was last derived at
         self._wd_plan: Dict[str, Tuple] = {}       # cache key -> (deps, [(src fn, dst view, cout, taps, cin)]): see refresh_dgrad_weights
         self.train(True)  # apply the freezing rules from the start (the reference's scripts always call train())
 
@@ -184,6 +185,12 @@ class Net(nn.Module):
             return flat
         shadow = self._bf16_shadow.get(key + ".weight")
         if shadow is not None:
+            # The fused optimiser refreshes the shadow in the launch that updates the f32 master (raw pointers: no version bump).
+            # Any torch-side write since -- load_state_dict on resume, re-initialisation, a manual copy_ -- bumps the parameter's
+            # version: re-cast from the master before the stale 16-bit weights can be used.
+            if w._version != self._shadow_version.get(key + ".weight"):
+                ops.cast_f32_lowp(flat, shadow)
+                self._shadow_version[key + ".weight"] = w._version
             return shadow
 
         def make():
@@ -510,6 +517,11 @@ class Net(nn.Module):
                         after_unit(name)
         if wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(wgrad_stream)
+
+    def register_shadow(self, name: str, param: nn.Parameter, view: Tensor) -> None:
+        """`view`: 16-bit [cout][kh][kw][cin] storage that a trainer keeps equal to `param` (cast by its fused optimiser)."""
+        self._bf16_shadow[name] = view
+        self._shadow_version[name] = -1  # force one cast from the master on first use
 
     def invalidate_weight_cache(self) -> None:
         """Call after parameter memory was rewritten by a raw-pointer kernel (fused optimiser step)."""

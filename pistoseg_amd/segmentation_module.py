@@ -102,27 +102,37 @@ class _Shell(LightningModule):
             self.sliding.add_batch(output, list(name_batch), [int(v) for v in original_h_batch], [int(v) for v in original_w_batch])
 
     def validation_epoch_end(self, validation_step_outputs=None):
+        """Logs exactly the reference's keys (models/segmentation_module.py:200-204,218-222,244-249; mosaic_module.py likewise):
+        `validation_miou_mask_epoch` is what `ModelCheckpoint(monitor=...)` watches and formats into the checkpoint file name
+        (segmentation_train.py:108-117, mosaic_train.py:121-130).  Key lists pinned by tests/golden/logged_keys.json."""
         out = {}
-        if self.args.dataset == "wsss4luad" and self.sliding is not None:
+        tissue_iou = self.valid_iou.Tissue_Intersection_over_Union()
+        miou, fwiou = self.valid_iou.Mean_Intersection_over_Union(), self.valid_iou.Frequency_Weighted_Intersection_over_Union()
+        if self.args.dataset == "wsss4luad":
+            if self.sliding is None:  # an epoch without a validation batch: empty canvases, as the reference's empty dicts
+                self.on_validation_epoch_start()
             big_mask_iou = self.sliding.big_mask_iou(lambda idx: self.gt_mask_fn(idx))
-            tissue_iou = self.valid_iou.Tissue_Intersection_over_Union()
             big_tissue = big_mask_iou.Tissue_Intersection_over_Union()
             out = {
-                "validation_tiou_patch_epoch": tissue_iou[0], "validation_siou_patch_epoch": tissue_iou[1], "validation_niou_patch_epoch": tissue_iou[2],
-                "validation_miou_patch_epoch": self.valid_iou.Mean_Intersection_over_Union(),
-                "validation_fwiou_patch_epoch": self.valid_iou.Frequency_Weighted_Intersection_over_Union(),
-                "validation_tiou_epoch": big_tissue[0], "validation_siou_epoch": big_tissue[1], "validation_niou_epoch": big_tissue[2],
-                "validation_miou_epoch": big_mask_iou.Mean_Intersection_over_Union(),
-                "validation_fwiou_epoch": big_mask_iou.Frequency_Weighted_Intersection_over_Union(),
+                "validation_tiou_patch_epoch": (tissue_iou[0], False), "validation_siou_patch_epoch": (tissue_iou[1], False),
+                "validation_niou_patch_epoch": (tissue_iou[2], False),
+                "validation_miou_patch_epoch": (miou, True), "validation_fwiou_patch_epoch": (fwiou, True),
+                "validation_tiou_mask_epoch": (big_tissue[0], False), "validation_siou_mask_epoch": (big_tissue[1], False),
+                "validation_niou_mask_epoch": (big_tissue[2], False),
+                "validation_miou_mask_epoch": (big_mask_iou.Mean_Intersection_over_Union(), True),
+                "validation_fwiou_mask_epoch": (big_mask_iou.Frequency_Weighted_Intersection_over_Union(), True),
             }
-        else:
-            out = {"validation_miou_epoch": self.valid_iou.Mean_Intersection_over_Union(),
-                   "validation_fwiou_epoch": self.valid_iou.Frequency_Weighted_Intersection_over_Union()}
-        for k, v in out.items():
-            self.log(k, v, prog_bar=False)
+        else:  # bcss: per-tissue IoUs of the patch meter under the *_mask_epoch names (four tissues)
+            out = {
+                "validation_tmr_mask_epoch": (tissue_iou[0], False), "validation_str_mask_epoch": (tissue_iou[1], False),
+                "validation_lym_mask_epoch": (tissue_iou[2], False), "validation_nec_mask_epoch": (tissue_iou[3], False),
+                "validation_miou_mask_epoch": (miou, True), "validation_fwiou_mask_epoch": (fwiou, True),
+            }
+        for k, (v, bar) in out.items():
+            self.log(k, v, prog_bar=bar)
         self.valid_iou.reset()
         self.sliding = None
-        return out
+        return {k: v for k, (v, _) in out.items()}
 
     def configure_optimizers(self):
         params = [p for p in self.model.parameters() if p.requires_grad]

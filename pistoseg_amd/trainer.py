@@ -69,7 +69,26 @@ def arena_order(model: ResNet38dSeg) -> List[Tuple[str, torch.nn.Parameter]]:
     return out
 
 
-class SegTrainer:
+class _ArenaMixin:
+    def sync_shadow(self) -> None:
+        """Re-derive the whole 16-bit weight arena from the f32 master in one launch (after construction, or after the masters were
+        written through torch: `load_state_dict` on resume).  Per-parameter staleness is also caught lazily by `Net.w_fwd`."""
+        if self.pb_flat is not None:
+            ops.cast_f32_lowp(self.p_flat, self.pb_flat)
+            for name, p in self.entries:
+                if name in self.model._bf16_shadow:
+                    self.model._shadow_version[name] = p._version
+        self.model.invalidate_weight_cache()
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """Checkpoint resume through the trainer: the parameters live in the f32 arena (their `.data` are views of it), so the
+        module's own load writes the masters in place; then the 16-bit shadows and every derived weight layout are refreshed."""
+        out = self.model.load_state_dict(state_dict, strict=strict)
+        self.sync_shadow()
+        return out
+
+
+class SegTrainer(_ArenaMixin):
     def __init__(self, model: ResNet38dSeg, lr: float = 1e-3, weight_decay: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8,
                  ignore_index: Optional[int] = 3, process_group=None, bucket_mb: float = 48.0, track_iou: bool = True,
                  loss_scale: Optional[float] = None, overlap_wgrad: bool = True):
@@ -109,12 +128,10 @@ class SegTrainer:
             p.data = view.permute(0, 3, 1, 2)  # OIHW shape, channels-last strides, arena storage
             self.grads[name] = self.g_flat[off:off + n].view(cout, kh, kw, cin)
             if self.pb_flat is not None:
-                model._bf16_shadow[name] = self.pb_flat[off:off + n].view(cout, kh, kw, cin)
+                model.register_shadow(name, p, self.pb_flat[off:off + n].view(cout, kh, kw, cin))
             self.offsets[name] = (off, n)
             off += n
-        if self.pb_flat is not None:
-            ops.cast_f32_lowp(self.p_flat, self.pb_flat)
-        model.invalidate_weight_cache()
+        self.sync_shadow()
         # all-reduce buckets: (unit after which the bucket is final, start, end) over the arena
         self.reducer: Optional[BucketedAllReduce] = None
         if self.world > 1:
@@ -166,7 +183,7 @@ class SegTrainer:
         self.lr *= gamma
 
 
-class RFMTrainer:
+class RFMTrainer(_ArenaMixin):
     """Native stage-3 step (`revise_pseudo_labels.py:232-301`): RFM forward plan -> fused cls/rfm/ecr losses with their
     gradients (rfm_loss.py) -> reverse plan into a flat f32 gradient arena -> [N > 1: bucketed RCCL all-reduce overlapped
     with the backward] -> utils.PolyOptimizer's update (SGD, momentum = the reference's mis-placed weight_decay argument,
@@ -208,7 +225,7 @@ class RFMTrainer:
             if not name.startswith("f9_"):
                 self.grads[name] = self.g_flat[off:off + n].view(cout, kh, kw, cin)
                 if self.pb_flat is not None:
-                    model._bf16_shadow[name] = self.pb_flat[off:off + n].view(cout, kh, kw, cin)
+                    model.register_shadow(name, p, self.pb_flat[off:off + n].view(cout, kh, kw, cin))
             self.offsets[name] = (off, n)
             off += n
             if id(p) in scratch:
@@ -216,9 +233,7 @@ class RFMTrainer:
                 self.n_scratch = off
         self.f9_packed = torch.zeros((384, 1, 1, FCAT), device=dev, dtype=torch.float32)
         self.grads["f9"] = self.f9_packed
-        if self.pb_flat is not None:
-            ops.cast_f32_lowp(self.p_flat, self.pb_flat)
-        model.invalidate_weight_cache()
+        self.sync_shadow()
         self.reducer: Optional[BucketedAllReduce] = None
         if self.world > 1:
             buckets = plan_buckets([(name, p.numel()) for name, p in self.entries], int(bucket_mb * (1 << 20) / 4))
@@ -260,9 +275,7 @@ class RFMTrainer:
                 self.skipped_steps += 1
                 return losses
             self.clean_steps += 1
-            if self.clean_steps >= 200:
-                self.loss_scale, self.clean_steps = min(self.loss_scale * 2.0, 2.0 ** 24), 0
-        inv = 1.0 / self.loss_scale
+        inv = 1.0 / self.loss_scale  # the scale these gradients were produced with (it may grow below, for the NEXT step)
         # utils.PolyOptimizer.step
         mult = (1 - self.global_step / self.max_step) ** self.power if self.global_step < self.max_step else None
         if mult is not None:
@@ -276,4 +289,6 @@ class RFMTrainer:
                              lr, self.wt_dec, self.wt_dec, first, grad_inv_scale=inv)
         self.global_step += 1
         model.invalidate_weight_cache()
+        if self.dynamic_scale and self.clean_steps >= 200:
+            self.loss_scale, self.clean_steps = min(self.loss_scale * 2.0, 2.0 ** 24), 0
         return losses

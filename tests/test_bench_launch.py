@@ -1,0 +1,39 @@
+"""`python bench.py --gpus N` must start N ranks by itself (torch.distributed.run as a child process) or fail: it never prints a line
+for fewer GPUs than were asked for (round-1 finding: it silently ran one GPU and printed n_gpus: 1)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*argv, env=None, timeout=600):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
+
+
+def test_more_gpus_than_visible_is_refused_without_a_json_line():
+    n = torch.cuda.device_count() + 1 if torch.cuda.device_count() else 2
+    r = run_bench("--gpus", str(n), "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0 and "n_gpus" not in r.stdout, (r.returncode, r.stdout[-500:])
+    assert "refusing" in r.stderr
+
+
+def test_mismatched_launcher_world_size_is_refused():
+    r = run_bench("--gpus", "4", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "n_gpus" not in r.stdout and "refusing" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_launches_two_rccl_ranks_when_the_box_has_them():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible: RCCL refuses two ranks on one device (profiles/r02_rccl_two_ranks_one_gpu_probe.txt)")
+    r = run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-infer")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 16

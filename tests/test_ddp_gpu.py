@@ -1,6 +1,12 @@
-"""Two ranks (both on the single test GPU, gloo backend so that no second device is needed) drive SegTrainer's
-data-parallel step: bucketed all-reduce of the flat gradient arena + per-rank 1/world gradient scaling must give
-the same parameters on every rank, equal to a single-process step on the concatenated batch."""
+"""Data-parallel steps of both native trainers across two ranks.
+
+Backend: `nccl` (= RCCL) with one GPU per rank whenever the box has two GPUs.  RCCL refuses two ranks of one communicator on the same
+device ("Duplicate GPU detected", profiles/r02_rccl_two_ranks_one_gpu_probe.txt), so on the one-GPU test box the two ranks share
+cuda:0 over `gloo` instead -- that still drives the whole bucket path (reverse-order arena buckets launched from the backward,
+1/world gradient scaling, the f9 unpack of RFMTrainer, the tiles-per-block switch while buckets are in flight); RCCL itself is then
+exercised by the world-size-1 test at the bottom (same code path, real RCCL communicator and kernels on the side stream).
+
+Checked: every rank ends with identical parameters, equal to a single-process step on the concatenated batch."""
 import os
 import socket
 import sys
@@ -12,6 +18,9 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
+DROP_SPECS = (("b6.dropout_2b1", 512, 0.3), ("b6.dropout_2b2", 1024, 0.3), ("b7.dropout_2b1", 1024, 0.5),
+              ("b7.dropout_2b2", 2048, 0.5), ("dropout7", 4096, 0.5))
+
 
 def _free_port():
     s = socket.socket()
@@ -21,63 +30,88 @@ def _free_port():
     return p
 
 
-def _data():
+def _data(kind):
     g = torch.Generator().manual_seed(5)
-    x = torch.randn(4, 3, 64, 64, generator=g)
-    y = torch.randint(0, 4, (4, 64, 64), generator=g)
+    n = 4
     drops = []
     for _ in range(2):
-        d = {}
-        for name, c, p in (("b6.dropout_2b1", 512, 0.3), ("b6.dropout_2b2", 1024, 0.3), ("b7.dropout_2b1", 1024, 0.5),
-                           ("b7.dropout_2b2", 2048, 0.5), ("dropout7", 4096, 0.5)):
-            d[name] = (torch.rand(4, c, generator=g) >= p).float() / (1 - p)
-        drops.append(d)
-    return x, y, drops
+        drops.append({name: (torch.rand(n, c, generator=g) >= p).float() / (1 - p) for name, c, p in DROP_SPECS})
+    if kind == "seg":
+        x = torch.randn(n, 3, 64, 64, generator=g)
+        y = torch.randint(0, 4, (n, 64, 64), generator=g)
+        return (x, y), drops
+    from oracle.make_golden import make_inputs, with_bg
+
+    x, pmask, pcam, lab = make_inputs(n, 64, 4, seed=140)
+    pm, pc, label = with_bg(pmask, pcam, lab)
+    return (x, pm, pc, label.reshape(n, 4)), drops
 
 
-def _run(rank, world, port, out):
+def _run(rank, world, port, backend, kind, out):
     sys.path.insert(0, ROOT)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
 
     from oracle import ref_cpu
-    from pistoseg_amd.seg_model import ResNet38dSeg
-    from pistoseg_amd.trainer import SegTrainer
 
+    dev_index = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev_index)
+    D = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        kw = {"device_id": D} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     try:
-        D = torch.device("cuda:0")
-        x, y, drops = _data()
-        per = x.shape[0] // world
+        inputs, drops = _data(kind)
+        per = inputs[0].shape[0] // world
         sl = slice(rank * per, (rank + 1) * per)
-        model = ResNet38dSeg(3, "fp32")
-        model.load_state_dict(ref_cpu.make_state_dict(3, False, seed=42))
-        model = model.to(D)
+        pg = dist.group.WORLD if world > 1 else None
         it = iter(drops)
-        model.sample_dropout = lambda n_, dev_: {k: v[sl].to(dev_) for k, v in next(it).items()}
-        tr = SegTrainer(model, lr=1e-3, weight_decay=0.05, ignore_index=3, process_group=dist.group.WORLD if world > 1 else None,
-                        bucket_mb=64.0, track_iou=False)
+        sample = lambda n_, dev_: {k: v[sl].to(dev_) for k, v in next(it).items()}
+        if kind == "seg":
+            from pistoseg_amd.seg_model import ResNet38dSeg
+            from pistoseg_amd.trainer import SegTrainer
+
+            model = ResNet38dSeg(3, "fp32")
+            model.load_state_dict(ref_cpu.make_state_dict(3, False, seed=42))
+            model = model.to(D)
+            model.sample_dropout = sample
+            tr = SegTrainer(model, lr=1e-3, weight_decay=0.05, ignore_index=3, process_group=pg, bucket_mb=64.0, track_iou=False)
+            step = lambda: float(tr.train_step(inputs[0][sl].to(D), inputs[1][sl].to(D)))
+        else:
+            from pistoseg_amd.revise_net import Net
+            from pistoseg_amd.trainer import RFMTrainer
+
+            model = Net(4, "fp32")
+            model.load_state_dict(ref_cpu.make_state_dict(4, True, seed=42))
+            model = model.to(D)
+            model.sample_dropout = sample
+            tr = RFMTrainer(model, lr=0.01, wt_dec=5e-4, max_step=10, process_group=pg, bucket_mb=64.0)
+            step = lambda: float(tr.train_step(*(t[sl].to(D) for t in inputs))[0])
         if world > 1:
             assert len(tr.reducer.buckets) >= 3  # several buckets so the overlap path is exercised
-        losses = [float(tr.train_step(x[sl].to(D), y[sl].to(D))) for _ in range(2)]
+            assert dist.get_backend(pg) == backend
+        losses = [step() for _ in range(2)]
         torch.cuda.synchronize()
-        out.put((world, rank, losses, tr.p_flat[::499].cpu().numpy()))  # every 499th weight (numpy: plain pickle)
+        f9 = {k: tr.p_flat[o:o + n].cpu().numpy() for k, (o, n) in tr.offsets.items() if k.startswith("f9_")}
+        out.put((world, rank, losses, tr.p_flat[::499].cpu().numpy(), f9))  # every 499th weight (numpy: plain pickle)
     except Exception as e:  # pragma: no cover
         import traceback
 
-        out.put((world, rank, "ERR " + repr(e) + traceback.format_exc(), None))
+        out.put((world, rank, "ERR " + repr(e) + traceback.format_exc(), None, None))
     finally:
         if world > 1:
             dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_single_process_step():
+@pytest.mark.parametrize("kind", ["seg", "rfm"])
+def test_two_rank_step_equals_single_process_step(kind):
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_run, args=(0, 1, 0, q))]
+    procs = [ctx.Process(target=_run, args=(0, 1, 0, backend, kind, q))]
     port = _free_port()
-    procs += [ctx.Process(target=_run, args=(r, 2, port, q)) for r in range(2)]
+    procs += [ctx.Process(target=_run, args=(r, 2, port, backend, kind, q)) for r in range(2)]
     procs[0].start()
     single = q.get(timeout=300)
     procs[0].join(timeout=60)
@@ -91,8 +125,64 @@ def test_two_rank_step_equals_single_process_step():
         assert not isinstance(r[2], str), r[2]
     r0, r1 = sorted(res, key=lambda t: t[1])
     assert (r0[3] == r1[3]).all(), "ranks diverged"
-    # global loss = mean of the per-rank means (equal shard sizes)
+    for k in r0[4]:
+        assert (r0[4][k] == r1[4][k]).all(), f"ranks diverged on {k}"
+    # global loss = mean of the per-rank means (equal shard sizes; every loss of the path is a mean over samples of per-sample terms)
     for s in range(2):
         assert abs(0.5 * (r0[2][s] + r1[2][s]) - single[2][s]) < 2e-4 * abs(single[2][s])
     d = abs(r0[3] - single[3])
-    assert float(d.mean()) < 1e-6 and float(d.max()) <= 2 * 2 * 1e-3 * 1.1  # Adam sign noise bound, see test_modules_gpu
+    if kind == "seg":
+        assert float(d.mean()) < 1e-6 and float(d.max()) <= 2 * 2 * 1e-3 * 1.1  # Adam sign noise bound, see test_modules_gpu
+    else:  # plain SGD: the update is linear in the gradient, only the summation order of the weight gradients differs
+        assert float(d.mean()) < 1e-7 and float(d.max()) <= 1e-4, (float(d.mean()), float(d.max()))
+        for k in r0[4]:  # the packed f9 gradient was unpacked into both arena slots before their bucket was reduced
+            assert float(abs(r0[4][k] - single[4][k]).max()) <= 1e-4, k
+    print(f"{kind}: backend {backend}, losses {r0[2]} / {r1[2]} vs single {single[2]}, max |dp| {float(d.max()):.2e}")
+
+
+def _rccl_world1(port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        from pistoseg_amd.dist import BucketedAllReduce, plan_buckets
+
+        assert dist.get_backend() == "nccl"
+        n = 1 << 22
+        flat = torch.zeros(3 * n, device="cuda")
+        red = BucketedAllReduce(flat, plan_buckets([("fc8.w", n), ("b7.w", n), ("b6.w", n)], n // 2), dist.group.WORLD)
+        assert len(red.buckets) == 3
+        ok = True
+        for step in range(3):
+            red.begin_step()
+            for i, unit in enumerate(("fc8", "b7", "b6")):
+                # the producer of a bucket is still running on the launch stream when the bucket is handed to RCCL on the side stream
+                a = torch.randn(2048, 2048, device="cuda")
+                for _ in range(4):
+                    a = a @ a * 1e-3
+                flat[i * n:(i + 1) * n] = float(step * 3 + i + 1) + 0.0 * a.flatten()[0]
+                red.on_unit_done(unit)
+            red.finish()
+            want = torch.cat([torch.full((n,), float(step * 3 + i + 1)) for i in range(3)])
+            ok = ok and bool(torch.equal(flat.cpu(), want))
+        out.put(("ok" if ok else "values wrong (side stream ran ahead of the producer?)"))
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        out.put("ERR " + repr(e) + traceback.format_exc())
+
+
+def test_bucketed_allreduce_through_rccl_world1():
+    """backend 'nccl' IS RCCL: a one-rank communicator on the test GPU runs the reducer's real code path (RCCL all-reduce launched on the
+    comm stream behind an event on the producing stream, tiles-per-block switch, finish() join)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1, args=(_free_port(), q))
+    p.start()
+    msg = q.get(timeout=300)
+    p.join(timeout=60)
+    assert msg == "ok", msg

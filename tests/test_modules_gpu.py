@@ -150,3 +150,40 @@ def test_seg_trainer_step_matches_autograd_path_and_torch_adamw():
             # the maximum by that and require the MEAN difference to be negligible against one update
             d = (s1[k] - s2[k]).abs()
             assert float(d.max()) <= 2 * 2 * 1e-3 * 1.1 and float(d.mean()) < 1e-6, (k, float(d.max()), float(d.mean()))
+
+
+@pytest.mark.parametrize("through_trainer", [False, True])
+def test_weights_loaded_after_trainer_construction_reach_the_16bit_shadow(through_trainer):
+    """The bf16 path reads a 16-bit shadow arena that only the fused optimiser refreshes; a torch-side write to the f32 masters
+    (checkpoint resume = load_state_dict AFTER the trainer was built) must not leave the forward / backward on stale weights."""
+    from pistoseg_amd.seg_model import ResNet38dSeg
+    from pistoseg_amd.trainer import SegTrainer
+
+    sd_a = ref_cpu.make_state_dict(3, False, seed=42)
+    sd_b = ref_cpu.make_state_dict(3, False, seed=43)
+    x, *_ = make_inputs(2, 64, 4, 150)
+    model = ResNet38dSeg(3, "bf16")
+    model.load_state_dict(sd_a)
+    model = model.to(D)
+    tr = SegTrainer(model, track_iou=False)
+    model.eval()
+    with torch.no_grad():
+        out_a = model(x.to(D)).clone()
+    (tr if through_trainer else model).load_state_dict(sd_b)  # resume: new masters, written through torch
+    with torch.no_grad():
+        out_b = model(x.to(D)).clone()
+    fresh = ResNet38dSeg(3, "bf16")
+    fresh.load_state_dict(sd_b)
+    fresh = fresh.to(D)
+    fresh.eval()
+    with torch.no_grad():
+        want = fresh(x.to(D))
+    assert not torch.equal(out_a, out_b)
+    assert torch.equal(out_b, want), float((out_b - want).abs().max())
+    # and the arena is still what the parameters alias: a training step moves the loaded weights
+    model.train()
+    before = tr.p_flat.clone()
+    tr.train_step(x.to(D), torch.randint(0, 4, (2, 64, 64), generator=torch.Generator().manual_seed(2)).to(D))
+    assert not torch.equal(before, tr.p_flat)
+    o, n = tr.offsets["fc8.weight"]
+    assert torch.equal(tr.p_flat[o:o + n].view(3, 1, 1, 4096).permute(0, 3, 1, 2), model.fc8.weight.detach())

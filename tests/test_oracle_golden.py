@@ -161,3 +161,52 @@ def test_oeem_wide_resnet_forward_cam_and_cls(golden_dir):
     got = cam.reshape(-1)[torch.from_numpy(g[f"cam_c{c}_s{s}.idx"])]
     assert torch.allclose(got, torch.from_numpy(g[f"cam_c{c}_s{s}.val"]), rtol=1e-5, atol=1e-6)
     assert np.allclose(cls.numpy(), g[f"cls_c{c}_s{s}"], rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Evaluation restatements vs fixtures minted by executing the reference's own method bodies (oracle/make_golden_eval.py)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def test_sliding_window_restatement_matches_reference_method_bodies(golden_dir):
+    """ref_cpu.sliding_window_big_masks / big_mask_predictions / confusion_matrix against what SegmentationModule.validation_step +
+    validation_epoch_end (models/segmentation_module.py:127-251) themselves produced on the same canned logits."""
+    from oracle.make_golden_eval import eval_case
+
+    g = np.load(os.path.join(golden_dir, "seg_eval.npz"))
+    pre = "SegmentationModule.wsss4luad."
+    sizes, batches, gt = eval_case(3)
+    big = ref_cpu.sliding_window_big_masks([(lg, nm, oh, ow) for lg, _, nm, oh, ow in batches], sizes, 3)
+    cm = np.zeros((3, 3))
+    for k, (pred, cnt) in big.items():
+        assert np.array_equal(pred / cnt, g[pre + "big." + k])  # same statements, same builtins: bit-identical
+        cm += ref_cpu.confusion_matrix(ref_cpu.big_mask_predictions(big)[k], gt[k], 3)
+    miou, fw = ref_cpu.miou_from_confusion(cm)
+    logged = g[pre + "val_logged"]  # [t, s, n, miou, fwiou]_patch, [t, s, n, miou, fwiou]_mask
+    assert abs(miou - logged[8]) < 1e-15 and abs(fw - logged[9]) < 1e-15
+    # patch-level meter
+    cmp_ = np.zeros((3, 3))
+    for lg, mk, *_ in batches:
+        cmp_ += ref_cpu.confusion_matrix(ref_cpu.logits_to_mask(lg).numpy(), mk.numpy().astype(np.uint8), 3)
+    miou_p, fw_p = ref_cpu.miou_from_confusion(cmp_)
+    assert abs(miou_p - logged[3]) < 1e-15 and abs(fw_p - logged[4]) < 1e-15
+    # CE of training_step (mean over all pixels, ignore_index=3)
+    loss = ref_cpu.seg_ce_loss(batches[0][0], batches[0][1], 3)
+    assert abs(float(loss) - float(g[pre + "train_loss"])) < 1e-6
+
+
+def test_multi_scale_cam_restatement_matches_reference_statements(golden_dir):
+    """ref_cpu.multi_scale_cam against the exec'ed statements of OEEM/classification/prepare_seg_inputs.py:96-138."""
+    from oracle.make_golden_eval import oeem_case
+
+    g = np.load(os.path.join(golden_dir, "oeem_ms_cam.npz"))
+    w, h, scales, crops, poss = oeem_case(3)
+    sizes = [(int(w * s), int(h * s)) for s in scales]
+    got = ref_cpu.multi_scale_cam(crops, poss, sizes, (w, h), 3, 56)
+    assert np.array_equal(got, g["ensemble_cam"])
+
+
+def test_logged_key_fixture_names_the_checkpoint_monitor(golden_dir):
+    import json
+
+    keys = json.load(open(os.path.join(golden_dir, "logged_keys.json")))
+    for k, v in keys.items():
+        assert "validation_miou_mask_epoch" in v["validation_epoch_end"], k

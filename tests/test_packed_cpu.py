@@ -49,3 +49,43 @@ def test_sharded_writers_fill_disjoint_rows(tmp_path):
         w.write_rows(lo, data[lo:hi])
         w.close()
     assert torch.equal(PackedTiles(path).get(names), data)
+
+
+def _shared_writer(rank, path, n, q):
+    from pistoseg_amd.dist import shard_range
+
+    names = [f"t{i}" for i in range(n)]
+    lo, hi = shard_range(n, rank, 4)
+    w = PackedTilesWriter(path, names, (3, 8, 8), shared=True)  # every rank constructs it the same way, concurrently
+    w.write_rows(lo, torch.full((hi - lo, 3, 8, 8), float(rank + 1)))
+    w.close()
+    q.put(rank)
+
+
+def test_shared_writers_race_without_truncating_each_other(tmp_path):
+    """Four processes construct a `shared=True` writer over the same path at once: the file is published atomically by one of them,
+    nobody truncates rows another rank already wrote, and a writer with a different index is refused."""
+    import multiprocessing as mp
+
+    from pistoseg_amd.dist import shard_range
+
+    path, n = str(tmp_path / "shared.pack"), 37
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_shared_writer, args=(r, path, n, q)) for r in range(4)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    got = PackedTiles(path).get([f"t{i}" for i in range(n)])
+    for r in range(4):
+        lo, hi = shard_range(n, r, 4)
+        assert bool((got[lo:hi] == r + 1).all())
+    assert not [f for f in os.listdir(tmp_path) if f.endswith(".tmp")]
+    import pytest
+
+    with pytest.raises(ValueError):
+        PackedTilesWriter(path, [f"u{i}" for i in range(n)], (3, 8, 8), shared=True)
+    with pytest.raises(ValueError):
+        PackedTilesWriter(path, [f"t{i}" for i in range(n)], (3, 8, 9), create=False)

@@ -207,5 +207,22 @@ def test_module_validation_step_and_epoch_end_match_oracle():
     miou_big, fw_big = ref_cpu.miou_from_confusion(cm_big)
     # a handful of near-tie pixels may flip between the device's and the CPU's fp32 logits: IoUs agree to 1e-3
     assert abs(got["validation_miou_patch_epoch"] - miou_patch) < 1e-3 and abs(got["validation_fwiou_patch_epoch"] - fw_patch) < 1e-3
-    assert abs(got["validation_miou_epoch"] - miou_big) < 1e-3 and abs(got["validation_fwiou_epoch"] - fw_big) < 1e-3
+    assert abs(got["validation_miou_mask_epoch"] - miou_big) < 1e-3 and abs(got["validation_fwiou_mask_epoch"] - fw_big) < 1e-3
     assert mod.sliding is None and float(mod.valid_iou.confusion_matrix.sum()) == 0  # reset for the next epoch
+
+
+def test_multi_scale_cam_matches_reference_golden(golden_dir):
+    """OEEM stage 0 accumulation against the fixture minted by exec'ing the reference's own statements
+    (OEEM/classification/prepare_seg_inputs.py:96-138; oracle/make_golden_eval.py)."""
+    import os
+
+    from oracle.make_golden_eval import oeem_case
+    from pistoseg_amd.sliding import MultiScaleCamAccumulator
+
+    g = np.load(os.path.join(golden_dir, "oeem_ms_cam.npz"))["ensemble_cam"]
+    w, h, scales, crops, poss = oeem_case(3)
+    acc = MultiScaleCamAccumulator(3, (w, h), D)
+    for s, cr, pos in zip(scales, crops, poss):
+        acc.add_scale(cr.to(D), pos, (int(w * s), int(h * s)))
+    got = acc.result((32, 32)).cpu().numpy()
+    assert got.shape == g.shape and np.allclose(got, g, rtol=1e-12, atol=1e-13)
