@@ -1,0 +1,61 @@
+/*
+ * pistoseg_hip_debug.h -- testing and ablation hooks of libpistoseg_hip_debug.so (the same sources built with -DPS_DEBUG_HOOKS).
+ *
+ * NOT part of the product ABI: libpistoseg_hip.so exports none of these symbols and its kernel-selection tunables are compile-time
+ * constants.  The debug library exports the whole product ABI (pistoseg_hip.h) plus the process-global switches below, which let the
+ * parity suite force every staging / tiling variant through the same entry points (all variants compute identical results) and let
+ * tools/conv_bench.py, tools/k_sweep.py and tools/hog_probe.py run timing ablations.  Never link the product against this header.
+ */
+#ifndef PISTOSEG_HIP_DEBUG_H
+#define PISTOSEG_HIP_DEBUG_H
+
+#include "pistoseg_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Testing hook: `blocks` workgroups of 256 threads each occupy a CU slot (and `lds_bytes` of its LDS: >= 40 KiB keeps the persistent
+ * conv blocks off that CU) for `usec` microseconds -- a stand-in for a communication kernel sharing the GPU (tools/hog_probe.py). */
+int ps_debug_hog(int32_t blocks, int32_t usec, int32_t lds_bytes, void* stream);
+
+/* Testing hook: how conv operands are staged into LDS: 2 (default) LDS-DMA through buffer descriptors
+ * (buffer_load ... lds; padding rows are out-of-range lanes, which the DMA zero-fills), 1 LDS-DMA with flat
+ * addresses (global_load_lds; padding rows read a zero page), 0 through registers.  All variants compute identical
+ * results; the tests run the parity suite over all of them. */
+void ps_debug_set_glds(int on);
+/* Testing hook: 1 lets large problems use the experimental 256x128 three-stage kernel; 0 (default) uses the 128-pixel kernels. */
+void ps_debug_set_3stage(int on);
+/* Testing hook: 64 / 128 force the cout-tile width of the 2-stage conv kernel, 0 (default) picks by problem size. */
+void ps_debug_set_bn(int bn);
+/* Testing hook: 112 / 128 force the pixel-tile height of the 128-cout conv kernel, 0 (default) picks the better-balanced. */
+void ps_debug_set_bm(int bm);
+/* Timing experiments only (results become WRONG): 1 = the conv kernels stage their first K-steps and then stop loading (consumer-only
+ * rate); 3 = the epilogue touches no memory (per-tile store cost). */
+void ps_debug_set_ablate(int v);
+/* Testing hook: 1 = big problems use the experimental 8-wave ping-pong conv kernel, 0 (default) = never, 2 = always (cout % 128 == 0). */
+void ps_debug_set_pp(int v);
+/* Testing hook: 1 (default) = big problems use the wave-specialised (4 loader + 4 consumer waves) conv kernel, 0 = never, 2 = always. */
+void ps_debug_set_ws(int v);
+/* Testing hook: large-tile (256|224 x 128, one block per CU) wave-specialised kernel: 0 off, 1 (default) chosen by the cost model, 256 / 224 forced. */
+void ps_debug_set_ws2(int v);
+/* Testing hook: window + halo kernel for 3x3 stride-1 layers (width a multiple of 28): 0 off, 1 (default) for big 16-bit problems, 2 forced. */
+void ps_debug_set_halo(int v);
+void ps_debug_set_s2split(int v);  /* stride-2 3x3 data gradient as four parity-class launches: 0 off, 1 big 16-bit problems (default), 2 whenever legal */
+/* Testing hook: 1 (default) = 128x128 weight-gradient tiles use the wave-specialised variant, 0 = the 4-wave kernel. */
+void ps_debug_set_wgrad_ws(int v);
+/* Testing hook: large-tile persistent weight-gradient kernel (256x128 tile, one block per CU): 0 off, 1 (default) for big 16-bit problems, 2 forced. */
+void ps_debug_set_wgrad_ws2(int v);
+/* Timing experiments only (results WRONG): 1 = the large-tile weight-gradient kernel skips its atomics, 2 = plain stores instead. */
+void ps_debug_set_wgrad_ablate(int v);
+/* Tuning hook: per-item overhead (in 64-pixel K-steps) the large-tile weight-gradient kernel's split-K cost model assumes. */
+void ps_debug_set_wgrad_ovh(int v);
+/* Testing hook: cout tiles per super-column of the conv block raster (default 4; 0 = plain row-major). */
+void ps_debug_set_supertile(int v);
+/* Testing hook: weight-gradient block order: 0 pixel range slowest, 1 pixel range fastest, -1 (default) chosen by shape. */
+void ps_debug_set_wgrad_raster(int v);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PISTOSEG_HIP_DEBUG_H */

@@ -30,7 +30,7 @@ class ConvGeom(C.Structure):
     _fields_ = [
         ("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
         ("cin", C.c_int32), ("cout", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32),
-        ("dilation", C.c_int32), ("ldc_x", C.c_int32), ("ldc_y", C.c_int32),
+        ("dilation", C.c_int32), ("ldc_x", C.c_int32), ("ldc_y", C.c_int32), ("tiles_per_block", C.c_int32),
     ]
 
 
@@ -109,24 +109,6 @@ PROTOTYPES = {
     "ps_d4_view": (C.c_int, [_P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "ps_scale_inplace": (C.c_int, [_P, _L, _F, _P]),
     "ps_nonfinite_count": (C.c_int, [_P, _L, _P, _P]),
-    "ps_set_tiles_per_block": (None, [_I]),
-    "ps_debug_hog": (C.c_int, [_I, _I, _I, _P]),
-    "ps_debug_set_glds": (None, [C.c_int]),
-    "ps_debug_set_3stage": (None, [C.c_int]),
-    "ps_debug_set_bn": (None, [C.c_int]),
-    "ps_debug_set_bm": (None, [C.c_int]),
-    "ps_debug_set_ablate": (None, [C.c_int]),
-    "ps_debug_set_pp": (None, [C.c_int]),
-    "ps_debug_set_ws": (None, [C.c_int]),
-    "ps_debug_set_ws2": (None, [C.c_int]),
-    "ps_debug_set_halo": (None, [C.c_int]),
-    "ps_debug_set_s2split": (None, [C.c_int]),
-    "ps_debug_set_wgrad_ws": (None, [C.c_int]),
-    "ps_debug_set_wgrad_ws2": (None, [C.c_int]),
-    "ps_debug_set_wgrad_ablate": (None, [C.c_int]),
-    "ps_debug_set_wgrad_ovh": (None, [C.c_int]),
-    "ps_debug_set_supertile": (None, [C.c_int]),
-    "ps_debug_set_wgrad_raster": (None, [C.c_int]),
     "ps_bgemm": (C.c_int, [_I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P]),
     "ps_softmax_rows": (C.c_int, [_P, _L, _I, _P]),
     "ps_rfm_apply": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
@@ -147,29 +129,72 @@ PROTOTYPES = {
     "ps_minpool_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P]),
 }
 
+# symbols of include/pistoseg_hip_debug.h: exported by libpistoseg_hip_debug.so only (-DPS_DEBUG_HOOKS), never by the product library
+DEBUG_PROTOTYPES = {
+    "ps_debug_hog": (C.c_int, [_I, _I, _I, _P]),
+    "ps_debug_set_glds": (None, [C.c_int]),
+    "ps_debug_set_3stage": (None, [C.c_int]),
+    "ps_debug_set_bn": (None, [C.c_int]),
+    "ps_debug_set_bm": (None, [C.c_int]),
+    "ps_debug_set_ablate": (None, [C.c_int]),
+    "ps_debug_set_pp": (None, [C.c_int]),
+    "ps_debug_set_ws": (None, [C.c_int]),
+    "ps_debug_set_ws2": (None, [C.c_int]),
+    "ps_debug_set_halo": (None, [C.c_int]),
+    "ps_debug_set_s2split": (None, [C.c_int]),
+    "ps_debug_set_wgrad_ws": (None, [C.c_int]),
+    "ps_debug_set_wgrad_ws2": (None, [C.c_int]),
+    "ps_debug_set_wgrad_ablate": (None, [C.c_int]),
+    "ps_debug_set_wgrad_ovh": (None, [C.c_int]),
+    "ps_debug_set_supertile": (None, [C.c_int]),
+    "ps_debug_set_wgrad_raster": (None, [C.c_int]),
+}
+
+DEBUG_LIB_PATH = os.path.join(HERE, "libpistoseg_hip_debug.so")
 _lib: Optional[C.CDLL] = None
+_product: Optional[C.CDLL] = None
+_debug: Optional[C.CDLL] = None
 
 
-def load() -> C.CDLL:
-    """Load the library (once) and bind every declared symbol; raises PsError if anything is missing."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _bind(path: str, protos) -> C.CDLL:
+    if not os.path.exists(path):
         raise PsError(
-            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m pistoseg_amd.build` "
+            f"{path} not found: the HIP extension is not built. Run `python -m pistoseg_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback."
         )
-    lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in PROTOTYPES.items():
+    lib = C.CDLL(path)
+    for name, (res, args) in protos.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:  # pragma: no cover
-            raise PsError(f"{LIB_PATH} does not export {name}") from e
+            raise PsError(f"{path} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
     return lib
+
+
+def load() -> C.CDLL:
+    """The library every op launches through: libpistoseg_hip.so (loaded once, every declared symbol bound; raises PsError if
+    anything is missing) -- unless a test or tool switched the process to the debug build with `use_debug_library()`."""
+    global _lib, _product
+    if _lib is None:
+        _product = _bind(LIB_PATH, PROTOTYPES)
+        _lib = _product
+    return _lib
+
+
+def use_debug_library(on: bool = True) -> C.CDLL:
+    """Testing / ablation only: route every op of this process through libpistoseg_hip_debug.so (the same sources built with
+    -DPS_DEBUG_HOOKS: the full product ABI plus the `ps_debug_*` switches of include/pistoseg_hip_debug.h), or back."""
+    global _lib, _debug
+    load()
+    if on:
+        if _debug is None:
+            _debug = _bind(DEBUG_LIB_PATH, {**PROTOTYPES, **DEBUG_PROTOTYPES})
+        _lib = _debug
+    else:
+        _lib = _product
+    return _lib
 
 
 def check(rc: int, what: str) -> None:

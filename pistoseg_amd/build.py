@@ -11,6 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpistoseg_hip.so")
+DEBUG_LIB = os.path.join(HERE, "libpistoseg_hip_debug.so")
 SOURCES = ["api.cpp", "conv_igemm.hip", "conv_wgrad.hip", "small_ops.hip", "pixel_ops.hip", "rfm_ops.hip", "sliding_ops.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
@@ -30,10 +31,10 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def _build_one(lib: str, objdir: str, extra_flags, force: bool, verbose: bool) -> str:
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "ps_internal.h"), os.path.join(HERE, "..", "include", "pistoseg_hip.h")]
-    objdir = os.path.join(HERE, "build")
+    inc = os.path.join(HERE, "..", "include")
+    headers = [os.path.join(CSRC, "ps_internal.h"), os.path.join(inc, "pistoseg_hip.h"), os.path.join(inc, "pistoseg_hip_debug.h")]
     os.makedirs(objdir, exist_ok=True)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     jobs = []
@@ -41,7 +42,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
         if force or _stale(obj, [src] + headers):
-            cmd = [hipcc, *FLAGS, "-x", "hip", "-c", src, "-o", obj]
+            cmd = [hipcc, *FLAGS, *extra_flags, "-x", "hip", "-c", src, "-o", obj]
             jobs.append((s, cmd))
 
     def run(job):
@@ -57,13 +58,22 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 if r.returncode:
                     raise RuntimeError(f"hipcc failed on {name}")
     objs = [os.path.join(objdir, os.path.splitext(s)[0] + ".o") for s in srcs]
-    if force or jobs or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB]
+    if force or jobs or _stale(lib, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", lib]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             sys.stderr.write(r.stderr)
             raise RuntimeError("link failed")
-    return LIB
+    return lib
+
+
+def build(force: bool = False, verbose: bool = True, debug: bool = True) -> str:
+    """libpistoseg_hip.so = the product (no mutable tunables, no `ps_debug_*` symbols); libpistoseg_hip_debug.so = the same sources with
+    -DPS_DEBUG_HOOKS for the parity suite's variant sweeps and the tools' ablations.  Returns the product library's path."""
+    path = _build_one(LIB, os.path.join(HERE, "build"), [], force, verbose)
+    if debug:
+        _build_one(DEBUG_LIB, os.path.join(HERE, "build", "debug"), ["-DPS_DEBUG_HOOKS"], force, verbose)
+    return path
 
 
 if __name__ == "__main__":

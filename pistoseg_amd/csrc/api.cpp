@@ -34,9 +34,3 @@ int ps_num_cus(void) {
   }
   return cached[dev];
 }
-
-// Work items per block of the persistent kernels: 0 (default) = fully persistent; > 0 when the GPU is shared with concurrently
-// running kernels (set by the trainers while gradient all-reduces overlap the backward).
-static int g_tiles_per_block = 0;
-extern "C" void ps_set_tiles_per_block(int32_t n) { g_tiles_per_block = n < 0 ? 0 : n; }
-int ps_tiles_per_block(void) { return g_tiles_per_block; }

@@ -1492,16 +1492,16 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
   }
 }
 
-static int g_use_glds = 2;  // staging mode: 0 registers, 1 global_load_lds, 2 buffer_load ... lds
-static int g_use_pp = 0;       // experimental ping-pong kernel (correct, slower: r01 measurements)
-static int g_use_ws = 1;       // wave-specialised (loader/consumer) kernel for big problems
-static int g_use_ws2 = 1;
-static int g_use_halo = 1;     // window + halo staging for 3x3 stride-1 layers (width a multiple of 28): 0 off, 1 for big 16-bit problems, 2 forced      // large-tile wave-specialised kernel: 0 off, 1 by cost model, 256 / 224 force that pixel tile
-static int g_use_3stage = 0;  // experimental 256x128 three-stage kernel: correct but slower than two 128x128 blocks per CU (r01 measurements)
-static int g_ablate = 0;
-static int g_supertile = 4;  // measured best of {0,4,8,16} on the wide 28x28 layers (r01)
-static int g_force_bm = 0;  // testing: 112 or 128 forces the pixel-tile height of the 128-cout kernel
-static int g_force_bn = 0;  // testing: 64 or 128 forces the 2-stage tile width
+PS_TUNABLE g_use_glds = 2;  // staging mode: 0 registers, 1 global_load_lds, 2 buffer_load ... lds
+PS_TUNABLE g_use_pp = 0;       // experimental ping-pong kernel (correct, slower: r01 measurements)
+PS_TUNABLE g_use_ws = 1;       // wave-specialised (loader/consumer) kernel for big problems
+PS_TUNABLE g_use_ws2 = 1;
+PS_TUNABLE g_use_halo = 1;     // window + halo staging for 3x3 stride-1 layers (width a multiple of 28): 0 off, 1 for big 16-bit problems, 2 forced      // large-tile wave-specialised kernel: 0 off, 1 by cost model, 256 / 224 force that pixel tile
+PS_TUNABLE g_use_3stage = 0;  // experimental 256x128 three-stage kernel: correct but slower than two 128x128 blocks per CU (r01 measurements)
+PS_TUNABLE g_ablate = 0;
+PS_TUNABLE g_supertile = 4;  // measured best of {0,4,8,16} on the wide 28x28 layers (r01)
+PS_TUNABLE g_force_bm = 0;  // testing: 112 or 128 forces the pixel-tile height of the 128-cout kernel
+PS_TUNABLE g_force_bn = 0;  // testing: 64 or 128 forces the 2-stage tile width
 
 template <typename Tr, int BM, int BN, int WMW, int WNW>
 int launch_igemm(const IgemmArgs& a0, hipStream_t stream) {
@@ -1529,6 +1529,7 @@ int check_geom(const ps_conv_geom* g) {
   PS_REQUIRE(g->stride == 1 || g->stride == 2, "conv: stride %d unsupported (1 or 2)", g->stride);
   PS_REQUIRE(g->dilation >= 1 && g->dilation <= 64, "conv: dilation %d unsupported", g->dilation);
   PS_REQUIRE(g->n > 0 && g->h > 0 && g->w > 0, "conv: empty input %dx%dx%d", g->n, g->h, g->w);
+  PS_REQUIRE(g->tiles_per_block >= 0 && g->tiles_per_block <= 4096, "conv: tiles_per_block %d out of range", g->tiles_per_block);
   const int es = ps_esize(g->dtype);
   PS_REQUIRE((g->cin * es) % 128 == 0 && (g->cout * es) % 128 == 0,
              "conv: cin=%d cout=%d must be multiples of %d channels", g->cin, g->cout, 128 / es);
@@ -1644,7 +1645,7 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
     if (v == PS_CONV_HALO) {
       b.ntm = (a.M / a.Ws + 7) / 8 * (a.Ws / 28);  // blocks of 8 global rows x column blocks of 28
       b.nb = ps_num_cus();
-      b.tpb = ps_tiles_per_block();
+      b.tpb = a.tpb;
       const dim3 hgrid(ps_persistent_grid((long long)b.ntm * b.ntn, b.nb, b.tpb));
       hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr>), hgrid, dim3(512), 2 * 36864 + 3 * 16384, s, b);
       PS_CHECK_LAUNCH("conv_igemm_halo");
@@ -1654,7 +1655,7 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
     b.ntm = (a.M + bm - 1) / bm;
     const dim3 grid((unsigned)(b.ntm * b.ntn));
     b.nb = ps_num_cus();
-    b.tpb = ps_tiles_per_block();
+    b.tpb = a.tpb;
     const dim3 pgrid(ps_persistent_grid((long long)b.ntm * b.ntn, b.nb, b.tpb));  // persistent: one block per CU (per batch)
     if (v == PS_CONV_WS2_256) hipLaunchKernelGGL((conv_igemm_ws2_kernel<Tr, 256>), pgrid, dim3(512), 3 * (256 * 128 + 128 * 128), s, b);
     else if (v == PS_CONV_WS2_224) hipLaunchKernelGGL((conv_igemm_ws2_kernel<Tr, 224>), pgrid, dim3(512), 3 * (224 * 128 + 128 * 128), s, b);
@@ -1680,6 +1681,7 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
+#ifdef PS_DEBUG_HOOKS
 extern "C" void ps_debug_set_glds(int on) { g_use_glds = on; }  // 0 | 1 | 2
 extern "C" void ps_debug_set_3stage(int on) { g_use_3stage = on; }
 extern "C" void ps_debug_set_bn(int bn) { g_force_bn = bn; }
@@ -1690,6 +1692,7 @@ extern "C" void ps_debug_set_ws(int v) { g_use_ws = v; }
 extern "C" void ps_debug_set_ws2(int v) { g_use_ws2 = v; }
 extern "C" void ps_debug_set_halo(int v) { g_use_halo = v; }
 extern "C" void ps_debug_set_supertile(int v) { g_supertile = v; }
+#endif
 
 extern "C" int ps_conv_supported(const ps_conv_geom* g) { return check_geom(g) == PS_OK ? 1 : 0; }
 
@@ -1697,7 +1700,7 @@ extern "C" int ps_conv_variant(const ps_conv_geom* g, int32_t dgrad) {
   if (check_geom(g) != PS_OK) return -1;
   const long long ho = (g->h - 1) / g->stride + 1, wo = (g->w - 1) / g->stride + 1;
   const long long M = dgrad ? (long long)g->n * g->h * g->w : (long long)g->n * ho * wo;
-  if (g_use_3stage || g_use_pp) return PS_CONV_OTHER;
+  if (g_use_3stage + g_use_pp != 0) return PS_CONV_OTHER;
   // both directions of a stride-1 3x3 layer gather on the input grid h x w
   const bool halo_ok = g->ksize == 3 && g->stride == 1 && g->w % 28 == 0 && g->w <= 224 && g->dilation <= 4;
   const int v = pick_ws_variant(M, dgrad ? g->cin : g->cout, ps_esize(g->dtype), halo_ok);
@@ -1722,6 +1725,7 @@ extern "C" int ps_conv2d_fwd(const ps_conv_geom* g, const void* x, const void* w
   a.wrow_bytes = (long long)a.taps * g->cin * es;
   a.Cd = g->cout;
   a.epi = *epi;
+  a.tpb = g->tiles_per_block;
   if (int rc = set_extents(a, (long long)g->n * g->h * g->w * a.pix_bytes, (long long)g->cout * a.wrow_bytes, es)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (g->dtype == PS_BF16) return dispatch_bn<TraitsBF16>(a, s);
@@ -1729,8 +1733,10 @@ extern "C" int ps_conv2d_fwd(const ps_conv_geom* g, const void* x, const void* w
   return dispatch_bn<TraitsF32>(a, s);
 }
 
-static int g_s2split = 1;  // stride-2 3x3 data gradient as four parity-class launches: 0 off, 1 for big 16-bit problems, 2 whenever legal
+PS_TUNABLE g_s2split = 1;  // stride-2 3x3 data gradient as four parity-class launches: 0 off, 1 for big 16-bit problems, 2 whenever legal
+#ifdef PS_DEBUG_HOOKS
 extern "C" void ps_debug_set_s2split(int v) { g_s2split = v; }
+#endif
 
 // Stride-2 3x3 data gradient: an output pixel's parity (p & 1, q & 1) decides which taps meet dy at integer positions -- 1, 2, 2 or 4
 // of the 9.  Gathering all 9 per pixel (and multiplying the zero rows) does 4x the work; one launch per parity class stages and
@@ -1756,7 +1762,7 @@ static int dgrad_s2_split(const IgemmArgs& a0, hipStream_t s) {
       const bool use224 = c224 * 103 < c256 * 100;
       b.ntm = (int)(use224 ? t224 : t256);
       b.nb = ps_num_cus();
-      b.tpb = ps_tiles_per_block();
+      b.tpb = a0.tpb;
       const dim3 pgrid(ps_persistent_grid((long long)b.ntm * b.ntn, b.nb, b.tpb));
       if (use224) hipLaunchKernelGGL((conv_igemm_ws2_kernel<Tr, 224, true>), pgrid, dim3(512), 3 * (224 * 128 + 128 * 128), s, b);
       else hipLaunchKernelGGL((conv_igemm_ws2_kernel<Tr, 256, true>), pgrid, dim3(512), 3 * (256 * 128 + 128 * 128), s, b);
@@ -1789,6 +1795,7 @@ extern "C" int ps_conv2d_dgrad(const ps_conv_geom* g, const void* dy, const void
   a.wrow_bytes = (long long)a.taps * g->cout * es;
   a.Cd = g->cin;
   a.epi = *epi;
+  a.tpb = g->tiles_per_block;
   if (int rc = set_extents(a, (long long)g->n * a.Hs * a.Ws * a.pix_bytes, (long long)g->cin * a.wrow_bytes, es)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dgrad_s2_split_ok(g, epi)) return g->dtype == PS_BF16 ? dgrad_s2_split<TraitsBF16>(a, s) : dgrad_s2_split<TraitsF16>(a, s);

@@ -522,12 +522,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
   }
 }
 
-static int g_wgrad_ws = 1;
-static int g_wgrad_ablate = 0;
-static int g_wgrad_ovh = 16;  // per-item overhead of the persistent kernel in K-step units (atomics + pipeline refill)
-static int g_wgrad_ws2 = 1;  // large-tile persistent kernel for 16-bit operands with cout % 256 == 0, cin % 128 == 0
+PS_TUNABLE g_wgrad_ws = 1;
+PS_TUNABLE g_wgrad_ablate = 0;
+PS_TUNABLE g_wgrad_ovh = 16;  // per-item overhead of the persistent kernel in K-step units (atomics + pipeline refill)
+PS_TUNABLE g_wgrad_ws2 = 1;  // large-tile persistent kernel for 16-bit operands with cout % 256 == 0, cin % 128 == 0
 
-static int g_wgrad_raster = -1;  // -1: by shape (measured r01: pixel-range-slowest wins for 3x3 layers with >= 64 tiles)
+PS_TUNABLE g_wgrad_raster = -1;  // -1: by shape (measured r01: pixel-range-slowest wins for 3x3 layers with >= 64 tiles)
 
 template <typename Tr, int BCO, int BCI>
 int launch_wgrad(WgradArgs a, hipStream_t s) {
@@ -589,7 +589,6 @@ int launch_wgrad_ws2(WgradArgs a, hipStream_t s) {
   const long long per = (a.ksteps + splits - 1) / splits, live = (a.ksteps + per - 1) / per;
   const long long items = tiles * live;
   a.nb = ncu;
-  a.tpb = ps_tiles_per_block();
   const unsigned grid = ps_persistent_grid(items, a.nb, a.tpb);
   hipLaunchKernelGGL((conv_wgrad_ws2_kernel<Tr::F16>), dim3(grid), dim3(512), 3 * 64 * (256 + 128) * 2, s, a);
   PS_CHECK_LAUNCH("conv_wgrad_ws2");
@@ -612,11 +611,13 @@ int dispatch_wgrad(const WgradArgs& a, hipStream_t s) {
 
 }  // namespace
 
+#ifdef PS_DEBUG_HOOKS
 extern "C" void ps_debug_set_wgrad_ws(int v) { g_wgrad_ws = v; }
 extern "C" void ps_debug_set_wgrad_ws2(int v) { g_wgrad_ws2 = v; }
 extern "C" void ps_debug_set_wgrad_ablate(int v) { g_wgrad_ablate = v; }
 extern "C" void ps_debug_set_wgrad_ovh(int v) { g_wgrad_ovh = v; }
 extern "C" void ps_debug_set_wgrad_raster(int v) { g_wgrad_raster = v; }
+#endif
 
 extern "C" int ps_conv_wgrad_variant(const ps_conv_geom* g) {
   if (!g || !ps_conv_supported(g)) return -1;
@@ -639,6 +640,7 @@ extern "C" int ps_conv2d_wgrad(const ps_conv_geom* g, const void* x, const void*
   a.stride = g->stride; a.dil = g->dilation;
   a.taps = g->ksize * g->ksize; a.ctr = g->ksize / 2;
   a.cin = g->cin; a.cout = g->cout;
+  a.tpb = g->tiles_per_block;
   a.x_pix_bytes = (long long)g->ldc_x * es;
   a.dy_pix_bytes = (long long)g->ldc_y * es;
   a.div_hw = make_fastdiv((uint32_t)(a.Ho * a.Wo));

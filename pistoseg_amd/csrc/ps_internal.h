@@ -16,7 +16,14 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 void ps_set_error(const char* fmt, ...);
 int ps_num_cus(void);  // compute units of the current device (api.cpp)
-int ps_tiles_per_block(void);  // ps_set_tiles_per_block()'s value (api.cpp)
+// Kernel-selection / staging tunables.  In the product library they are compile-time constants (no process-global mutable state
+// behind the C-ABI); the testing build (-DPS_DEBUG_HOOKS -> libpistoseg_hip_debug.so, include/pistoseg_hip_debug.h) makes them
+// settable so that the parity suite can force every staging variant and the tools can run ablations.
+#ifdef PS_DEBUG_HOOKS
+#define PS_TUNABLE static int
+#else
+#define PS_TUNABLE static constexpr int
+#endif
 // grid of a persistent kernel over nitems work items (see ps_block_items)
 static inline unsigned ps_persistent_grid(long long nitems, int nb, int tpb) {
   if (tpb <= 0) return (unsigned)(nitems < nb ? nitems : nb);

@@ -907,9 +907,11 @@ __global__ __launch_bounds__(256) void hog_kernel(long long ticks, int* sink) {
 }
 }  // namespace
 
+#ifdef PS_DEBUG_HOOKS
 extern "C" int ps_debug_hog(int32_t blocks, int32_t usec, int32_t lds_bytes, void* stream) {
   PS_REQUIRE(blocks > 0 && usec > 0 && usec <= 2000000 && lds_bytes >= 0 && lds_bytes <= 160 * 1024, "debug_hog: bad argument");
   hipLaunchKernelGGL(hog_kernel, dim3(blocks), dim3(256), (size_t)lds_bytes, static_cast<hipStream_t>(stream), (long long)usec * 100, (int*)nullptr);
   PS_CHECK_LAUNCH("debug_hog");
   return PS_OK;
 }
+#endif

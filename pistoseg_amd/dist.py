@@ -43,7 +43,7 @@ class BucketedAllReduce:
     with a static share of the tiles) would then serialise the share of every block that cannot start (measured with a CU hog,
     tools/hog_probe.py: +63 % on a launch that loses 16 CUs, +0..29 % with 1-2 tiles per block), so from the first bucket launch to
     `finish()` the conv launches are told to cut their work into `shared_tiles_per_block`-tile blocks that the hardware
-    dispatcher re-balances (ps_set_tiles_per_block); forward passes and single-GPU runs keep the fully persistent schedule."""
+    dispatcher re-balances (the `tiles_per_block` launch option of ps_conv_geom); forward passes and single-GPU runs keep the fully persistent schedule."""
 
     def __init__(self, flat: Tensor, buckets: List[Tuple[str, int, int]], group=None, shared_tiles_per_block: int = 1):
         self.flat, self.buckets, self.group = flat, buckets, group
@@ -56,9 +56,9 @@ class BucketedAllReduce:
     def _share_gpu(self, on: bool) -> None:
         if self.comm_stream is None or on == self._sharing:
             return
-        from . import _lib  # device path only: the CPU (gloo) tests never load the HIP library
+        from . import ops  # device path only: the CPU (gloo) tests never load the HIP library
 
-        _lib.load().ps_set_tiles_per_block(self.shared_tiles_per_block if on else 0)
+        ops.TILES_PER_BLOCK = self.shared_tiles_per_block if on else 0  # a per-launch argument of the C-ABI (ps_conv_geom)
         self._sharing = on
 
     def begin_step(self) -> None:

@@ -94,8 +94,14 @@ class ConvSpec:
         return (h - 1) // self.stride + 1, (w - 1) // self.stride + 1
 
 
+# Launch option of the persistent conv kernels, passed to the C-ABI with every launch (ps_conv_geom.tiles_per_block): 0 = one block
+# per CU lives for the whole launch; n > 0 while a communication kernel shares the GPU (set by dist.BucketedAllReduce between its first
+# bucket launch and finish()).  It is read when a launch is ENQUEUED, by the one host thread that enqueues this process's work.
+TILES_PER_BLOCK = 0
+
+
 def _geom(spec: ConvSpec, dtype: int, n: int, h: int, w: int, ldc_x: int, ldc_y: int) -> ConvGeom:
-    return ConvGeom(dtype, n, h, w, spec.cin, spec.cout, spec.ksize, spec.stride, spec.dilation, ldc_x, ldc_y)
+    return ConvGeom(dtype, n, h, w, spec.cin, spec.cout, spec.ksize, spec.stride, spec.dilation, ldc_x, ldc_y, TILES_PER_BLOCK)
 
 
 def _epilogue(mode=PS_EPI_NONE, add0=None, out_raw=None, scale=None, shift=None, drop=None, mask_src=None, add1=None, out=None) -> Epilogue:

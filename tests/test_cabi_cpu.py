@@ -9,14 +9,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    names = set()
-    for fn in os.listdir(os.path.join(ROOT, "include")):
-        if fn.endswith(".h"):
-            text = open(os.path.join(ROOT, "include", fn)).read()
-            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-            names.update(re.findall(r"\b(ps_[a-z0-9_]+)\s*\(", text))
-    return names
+def declared_symbols(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(ps_[a-z0-9_]+)\s*\(", text))
 
 
 @pytest.fixture(scope="module")
@@ -30,12 +26,29 @@ def lib():
 def test_exports_match_header(lib):
     from pistoseg_amd import _lib
 
-    decl = declared_symbols()
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["pistoseg_hip.h", "pistoseg_hip_debug.h"]
+    decl = declared_symbols("pistoseg_hip.h")
     assert decl, "no declarations parsed"
     for name in decl:
-        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+        assert hasattr(lib, name), f"{name} declared in include/pistoseg_hip.h but not exported"
     assert decl == set(_lib.PROTOTYPES), (decl ^ set(_lib.PROTOTYPES))
-    assert lib.ps_version() == 100
+    assert lib.ps_version() == 200
+
+
+def test_product_library_has_no_debug_switches_and_debug_library_has_all(lib):
+    """The product ABI carries no process-global knob: no `ps_debug_*`, no `ps_set_*` (tiles-per-block is a field of ps_conv_geom);
+    the hooks of include/pistoseg_hip_debug.h are exported by libpistoseg_hip_debug.so only."""
+    from pistoseg_amd import _lib
+
+    dbg_decl = declared_symbols("pistoseg_hip_debug.h")
+    assert dbg_decl == set(_lib.DEBUG_PROTOTYPES) and all(n.startswith("ps_debug_") for n in dbg_decl)
+    for name in dbg_decl | {"ps_set_tiles_per_block"}:
+        assert not hasattr(lib, name), f"product library exports {name}"
+    assert not [n for n in _lib.PROTOTYPES if n.startswith(("ps_debug_", "ps_set_"))]
+    dbg = C.CDLL(_lib.DEBUG_LIB_PATH)
+    for name in dbg_decl | declared_symbols("pistoseg_hip.h"):
+        assert hasattr(dbg, name), f"debug library lacks {name}"
+    assert any(f[0] == "tiles_per_block" for f in _lib.ConvGeom._fields_)
 
 
 def test_argument_validation_without_gpu(lib):

@@ -9,6 +9,7 @@ import torch
 
 from oracle import ref_cpu
 from oracle.make_golden import make_inputs
+from _parity import assert_tie_excused
 
 pytestmark = pytest.mark.gpu
 D = torch.device("cuda:0")
@@ -66,7 +67,7 @@ def test_seg_forward_fp32_matches_golden_and_oracle(golden_dir, tag, n, s, c, se
     # ... and end to end it is bit-exact up to ties below the logit error
     mask_e2e = ops.argmax_mask(logits, mode=_lib.PS_MASK_PLAIN, softmax_first=True).cpu()
     ok, ndiff = masks_agree_up_to_ties(ref, torch.from_numpy(g["cam_mask"]), mask_e2e, err)
-    assert ok, f"{ndiff} mask pixels differ beyond tie tolerance"
+    assert_tie_excused(f"seg masks {tag}", ndiff, mask_e2e.numel(), ok)
 
 
 def test_backbone_features_fp32(golden_dir):
@@ -254,3 +255,54 @@ def test_seg_trainer_side_stream_weight_gradients_match_single_stream():
     # move by +-lr in either run, so the yardstick is the difference between two IDENTICAL single-stream runs
     noise = rel_err(pr, p0)
     assert rel_err(p1, p0) <= max(10 * noise, 2e-4), (rel_err(p1, p0), noise)
+
+
+def test_bench_batch_bf16_logits_vs_oracle():
+    """BASELINE configs[1] says "logits checked vs CPU": the exact batch `bench.py` trains on (bs=64, 224x224, seed 1234, He-init weights
+    seed 42, bf16 storage / f32 accumulate) goes through the model in one launch sequence; tiles 0 and 37 are compared with the CPU
+    oracle on the same weights.  bf16 is not the parity path (north_star gates 1e-4 on fp32): tolerance 6 % of the logit range, argmax
+    agreement reported and > 97 %; and per-tile results must not depend on the batch they ride in (tile 37 alone == tile 37 of 64)."""
+    from pistoseg_amd.seg_model import ResNet38dSeg
+    from pistoseg_amd.trainer import init_weights_he
+
+    model = ResNet38dSeg(classes=3, precision="bf16")
+    init_weights_he(model, seed=42)
+    sd = {k: v.detach().clone().float().contiguous() for k, v in model.state_dict().items()}
+    model = model.to(D)
+    model.eval()
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    x = torch.randn(64, 3, 224, 224, generator=g)
+    with torch.no_grad():
+        got = model(x.to(D))
+        pick = [0, 37]
+        got_pick = got[pick].cpu()
+        alone = model(x[37:38].to(D)).cpu()
+        ref = ref_cpu.seg_forward(sd, x[pick])
+    assert torch.equal(alone[0], got_pick[1]), "a tile's logits depend on its batch"
+    e = rel_err(got_pick, ref)
+    agree = float((got_pick.argmax(1) == ref.argmax(1)).float().mean())
+    print(f"[parity] bench batch bf16 vs CPU oracle: max rel err {e:.3e}, argmax agreement {agree:.4f}")
+    assert e < 6e-2 and agree > 0.97, (e, agree)
+
+
+def test_bench_batch_fp32_parity_path_vs_oracle():
+    """The same two tiles of the bench batch on the PARITY path (fp32 storage, exact-f32 MFMA): 1e-4 relative, masks up to ties."""
+    from pistoseg_amd import _lib, ops
+    from pistoseg_amd.seg_model import ResNet38dSeg
+    from pistoseg_amd.trainer import init_weights_he
+
+    model = ResNet38dSeg(classes=3, precision="fp32")
+    init_weights_he(model, seed=42)
+    sd = {k: v.detach().clone().float().contiguous() for k, v in model.state_dict().items()}
+    model = model.to(D)
+    model.eval()
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    x = torch.randn(64, 3, 224, 224, generator=g)[[0, 37]]
+    with torch.no_grad():
+        got = model(x.to(D))
+        ref = ref_cpu.seg_forward(sd, x)
+    err = float((got.cpu() - ref).abs().max())
+    assert err / float(ref.abs().max()) < F32_TOL
+    mask = ops.argmax_mask(got, mode=_lib.PS_MASK_PLAIN, softmax_first=True).cpu()
+    ok, ndiff = masks_agree_up_to_ties(ref, ref_cpu.logits_to_mask(ref), mask, err)
+    assert_tie_excused("bench tiles fp32", ndiff, mask.numel(), ok)

@@ -8,6 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import ref_cpu
+from _parity import assert_tie_excused
 from oracle.make_golden import make_inputs, with_bg
 
 pytestmark = pytest.mark.gpu
@@ -103,8 +104,8 @@ def test_stage2_and_stage4_inference_reductions(golden_dir):
     pm, pc, label = with_bg(pmask, pcam, lab)
     masks = infer.infer_revise_masks(model, x.to(D), pm.to(D), pc.to(D), label)
     for name, m in zip(("pmask_rv_mask", "pcam_rv_mask", "cam_rv_mask"), masks):
-        agree = float((m.cpu().numpy() == gm[name]).mean())
-        assert agree > 0.9995, (name, agree)  # bit-exact up to f32 ties (checked strictly in test_rfm_gpu)
+        ndiff = int((m.cpu().numpy() != gm[name]).sum())
+        assert_tie_excused(f"infer_revise_masks {name}", ndiff, gm[name].size, True)  # the gap itself is checked pixel by pixel in test_rfm_gpu
 
 
 def test_seg_trainer_step_matches_autograd_path_and_torch_adamw():

@@ -10,6 +10,19 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(scope="module", autouse=True)
+def debug_library():
+    """This module sweeps the kernels' staging / tiling variants through the `ps_debug_*` switches: those exist only in
+    libpistoseg_hip_debug.so (same sources, -DPS_DEBUG_HOOKS).  With every switch at its default the debug build launches exactly what
+    the product library launches; the model-level test files run on the product library."""
+    from pistoseg_amd import _lib
+
+    _lib.use_debug_library(True)
+    yield
+    _lib.use_debug_library(False)
+
+
 WS2_DEFAULT = 1  # library default of ps_debug_set_ws2 (restored after tests that force a variant)
 F32_TOL = 1e-4
 BF16_TOL = 1.2e-2
@@ -593,7 +606,7 @@ def test_full_size_layers_kernel_families_agree(case):
 
 @pytest.mark.parametrize("tpb", [1, 2, 5])
 def test_persistent_kernels_batched_work_split_is_exact(tpb):
-    """ps_set_tiles_per_block(n): the persistent kernels' blocks are dispatched in batches and take n work items each (used while
+    """ps_conv_geom.tiles_per_block = n: the persistent kernels' blocks are dispatched in batches and take n work items each (used while
     an all-reduce shares the GPU).  Only the item -> block assignment changes: forward / data gradient are bit-identical to the
     one-batch schedule, the weight gradient up to f32 atomic ordering."""
     from pistoseg_amd import _lib, ops
@@ -621,13 +634,13 @@ def test_persistent_kernels_batched_work_split_is_exact(tpb):
             return y, gx, dw
 
         try:
-            lib.ps_set_tiles_per_block(0)
+            ops.TILES_PER_BLOCK = 0
             lib.ps_debug_set_wgrad_ws2(2)
             ref = run()
-            lib.ps_set_tiles_per_block(tpb)
+            ops.TILES_PER_BLOCK = tpb
             got = run()
         finally:
-            lib.ps_set_tiles_per_block(0)
+            ops.TILES_PER_BLOCK = 0
             lib.ps_debug_set_wgrad_ws2(1)
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
         assert rel_err(got[2].cpu(), ref[2].cpu()) < 1e-5

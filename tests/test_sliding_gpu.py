@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+from _parity import assert_tie_excused
 from oracle import ref_cpu
 
 pytestmark = pytest.mark.gpu
@@ -60,7 +61,7 @@ def test_sliding_window_accumulation_matches_oracle():
         if diff.any():
             p = ref_big[k][0] / ref_big[k][1]
             top2 = np.sort(p, axis=2)[..., -2:]
-            assert ((top2[..., 1] - top2[..., 0])[diff] < 1e-6).all(), f"{int(diff.sum())} mask pixels differ beyond tie tolerance"
+            assert_tie_excused(f"big mask {k}", int(diff.sum()), diff.size, bool(((top2[..., 1] - top2[..., 0])[diff] < 1e-6).all()))
     # confusion matrix through the device-resident mIoUMask
     miou = acc.big_mask_iou(lambda idx: gt[idx])
     cm_ref = sum(ref_cpu.confusion_matrix(ref_cpu.big_mask_predictions(ref_big)[k], gt[k].numpy(), c) for k in sizes)

@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--layers", default="")
     ap.add_argument("--epi", default="raw", help="raw: store only | full: fwd = +residual -> raw + BN/ReLU out, dgrad = ReLU mask + add1 -> out")
     args = ap.parse_args()
-    lib = _lib.load()
+    lib = _lib.use_debug_library()  # the ps_debug_* switches live in libpistoseg_hip_debug.so only
     D = torch.device("cuda:0")
     dt = torch.bfloat16
     variants = [v.split("=") for v in args.variants.split(",")]

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pistoseg_amd import _lib, ops
 
-lib = _lib.load()
+lib = _lib.use_debug_library()  # the ps_debug_* switches live in libpistoseg_hip_debug.so only
 D = torch.device("cuda:0")
 dt = torch.bfloat16
 side = torch.cuda.Stream()
@@ -22,7 +22,7 @@ for name, cin, cout, k, d, H in cases:
     for what, fn in fns.items():
         line = f"{name:30s} {what:5s}"
         for hog, tpb in ((0, 0), (0, 2), (16, 0), (16, 2), (16, 1), (48, 0), (48, 2)):
-            lib.ps_set_tiles_per_block(tpb)
+            ops.TILES_PER_BLOCK = tpb
             ts = []
             for _ in range(3):
                 fn(); torch.cuda.synchronize()
@@ -41,4 +41,4 @@ for name, cin, cout, k, d, H in cases:
                 torch.cuda.synchronize()
             line += f" | hog={hog:2d} tpb={tpb}: {min(ts):7.1f}us"
         print(line, flush=True)
-lib.ps_set_tiles_per_block(0)
+ops.TILES_PER_BLOCK = 0

@@ -3,11 +3,11 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from pistoseg_amd import _lib
+from pistoseg_amd import _lib, ops
 from pistoseg_amd.seg_model import ResNet38dSeg
 from pistoseg_amd.trainer import SegTrainer, init_weights_he
 
-lib = _lib.load()
+lib = _lib.use_debug_library()  # the ps_debug_* switches live in libpistoseg_hip_debug.so only
 D = torch.device("cuda:0")
 model = ResNet38dSeg(3, "bf16"); init_weights_he(model, seed=1); model = model.to(D)
 tr = SegTrainer(model)
@@ -17,7 +17,7 @@ for _ in range(3): tr.train_step(x, y)
 torch.cuda.synchronize()
 for hog in (0, 16, 32):
     for tpb in (0, 2, 1):
-        lib.ps_set_tiles_per_block(tpb)
+        ops.TILES_PER_BLOCK = tpb
         best = 1e9
         for _ in range(2):
             torch.cuda.synchronize()
@@ -32,4 +32,4 @@ for hog in (0, 16, 32):
             best = min(best, (time.perf_counter() - t0) / 8)
             torch.cuda.synchronize()
         print(f"hog={hog:2d} CUs tpb={tpb}: {best*1e3:6.2f} ms/step  {64/best:6.0f} tiles/s", flush=True)
-lib.ps_set_tiles_per_block(0)
+ops.TILES_PER_BLOCK = 0
