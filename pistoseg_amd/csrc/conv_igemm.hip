@@ -1273,11 +1273,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
 //     of the current one (behind that step's weights, so the in-order vmcnt lets it stay in flight for two steps); weights
 //     run two K-steps ahead.
 // ------------------------------------------------------------------------------------------------
-template <typename Tr>
+template <typename Tr, int TW>  // TW = 28 (maps of 224-pixel tiles: 28 / 56 / 112 wide) or 32 (256-pixel tiles: 32 / 64 / 128 wide)
 __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs a) {
   typedef typename Tr::elem T;
-  constexpr int BN = 128, MI = 7, WI = 4, WN = 64, TW = 28, TR = 8;  // tile = 8 rows x 28 columns = 224 pixels
-  constexpr int WJ = 9, WIN_BYTES = WJ * 4 * 1024, B_BYTES = BN * 128;
+  static_assert(TW == 28 || TW == 32, "tile width");
+  constexpr int BN = 128, MI = TW / 4, WI = 4, WN = 64, TR = 8;  // tile = 8 rows x TW columns = 224 | 256 pixels
+  constexpr int WJ = (TW + 8 + 3) / 4, WIN_BYTES = WJ * 4 * 1024, B_BYTES = BN * 128;  // window of <= TW + 8 columns: 9 | 10 DMAs per loader wave
+  static_assert(WJ == 9 || WJ == 10, "vmcnt literals below");
   constexpr int W_OFF = 2 * WIN_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -1289,7 +1291,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
   const int my_tiles = (ntiles - first + G - 1) / G;
   const int total_steps = my_tiles * nwin * 3;
   const int H = a.Hs, W = a.Ws, NH = a.M / W;  // stride 1: produced grid == source grid; NH = global rows n*H + p
-  const int ncb = W / TW;                    // column blocks per row (W is a multiple of 28: 28, 56, 112)
+  const int ncb = W / TW;                    // column blocks per row (W is a multiple of TW)
   const int dabs = a.dstep < 0 ? -a.dstep : a.dstep;
   const int WP = TW + 2 * dabs;              // window columns (<= 36)
 
@@ -1382,11 +1384,18 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
       }
       return true;
     };
-    auto wait_allow = [&](int n) {  // all but the n newest DMAs of this wave have landed (n in {0, 4, 9, 13})
-      if (n == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-      else if (n == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-      else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    auto wait_allow = [&](int n) {  // all but the n newest DMAs of this wave have landed (n in {0, 4, WJ, WJ + 4})
+      if constexpr (WJ == 9) {
+        if (n == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+        else if (n == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        if (n == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        else if (n == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     };
     issue_window();
     issue_weights();
@@ -1399,7 +1408,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
       const int wA = issue_weights() ? 4 : 0;
       int allow;
       if (r == 0) {
-        win_pending = issue_window() ? 9 : 0;
+        win_pending = issue_window() ? WJ : 0;
         allow = wA + win_pending;
       } else if (r == 1) {
         allow = wA + win_pending;
@@ -1414,7 +1423,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
   }
 
   // ================= consumer =================
-  // waves 2x2: wm = column half of the tile (14 columns = 7 fragments of 8 rows x 2 columns), wn = cout half
+  // waves 2x2: wm = column half of the tile (TW / 2 columns = MI fragments of 8 rows x 2 columns), wn = cout half
   const int wm = wave >> 1, wn = wave & 1;
   const int frow = lane & 15, g = lane >> 4;
   const int wfrag = W_OFF + (wn * WN + frow) * 128;
@@ -1427,7 +1436,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
   int xa[MI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
-    const int c = wm * 14 + 2 * mi + (frow >> 3) + dabs;  // window column of the centre tap
+    const int c = wm * (TW / 2) + 2 * mi + (frow >> 3) + dabs;  // window column of the centre tap
     xa[mi] = c * 1024 + tr * 128 + ((g ^ tr) << 4);
   }
   __builtin_amdgcn_s_barrier();  // window 0 / weights of step 0 visible
@@ -1488,7 +1497,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
     int tm, tn;
     ps_tile_of_block(tile, a.ntn, a.ntm, tm, tn, a.supertile);
     const int rb = tm / ncb;
-    conv_epilogue<T, MI, WI, 1>(a, acc, rb * TR * W + (tm - rb * ncb) * TW + wm * 14, tn * BN + wn * WN, lane);
+    conv_epilogue<T, MI, WI, 1>(a, acc, rb * TR * W + (tm - rb * ncb) * TW + wm * (TW / 2), tn * BN + wn * WN, lane);
   }
 }
 
@@ -1586,6 +1595,11 @@ int set_extents(IgemmArgs& a, long long src_bytes, long long wgt_bytes, int es) 
 //   * it beats the two-blocks-per-CU kernel whenever there are >= 2 cout tiles (r01: +5..+12 % on the 28x28 layers, equal on
 //     256-channel 56x56); single-cout-tile layers (128 channels @112x112, 18 K-steps) keep the small tile, whose second
 //     resident block hides the epilogue.
+// Column-block width of the halo kernel's 8-row tiles for a feature map of width w: 28 (224-pixel tiles; the 28 / 56 / 112 / 224-wide
+// maps of 224 x 224 inputs) or 32 (256-pixel tiles; the 32 / 64 / 128 / 256-wide maps of 256 x 256 inputs, stages 2 and 4 of the
+// reference: infer_pseudo_masks.py:50, infer_revise_masks.py:46); 0 if neither divides w.
+static int halo_tile_width(int w) { return (w <= 0 || w > 256) ? 0 : (w % 28 == 0 ? 28 : (w % 32 == 0 ? 32 : 0)); }
+
 static int pick_ws_variant(long long M, int Cd, int esize, bool halo_ok) {
   if (g_use_glds != 2 || Cd % 128 != 0) return 0;
   const long long n128 = Cd / 128;
@@ -1638,16 +1652,18 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
     }
   }
   const int adil = a.dstep < 0 ? -a.dstep : a.dstep;
-  const bool halo_ok = a.taps == 9 && a.mul == 1 && a.div_shift == 0 && a.Hs == a.Ho && a.Ws == a.Wo && a.Ws % 28 == 0 && a.Ws <= 224 && adil <= 4;
+  const bool halo_ok = a.taps == 9 && a.mul == 1 && a.div_shift == 0 && a.Hs == a.Ho && a.Ws == a.Wo && halo_tile_width(a.Ws) != 0 && adil <= 4;
   if (const int v = pick_ws_variant(a.M, a.Cd, (int)sizeof(typename Tr::elem), halo_ok)) {
     IgemmArgs b = a;
     b.ntn = a.Cd / 128;
     if (v == PS_CONV_HALO) {
-      b.ntm = (a.M / a.Ws + 7) / 8 * (a.Ws / 28);  // blocks of 8 global rows x column blocks of 28
+      const int tw = halo_tile_width(a.Ws);
+      b.ntm = (a.M / a.Ws + 7) / 8 * (a.Ws / tw);  // blocks of 8 global rows x column blocks of tw
       b.nb = ps_num_cus();
       b.tpb = a.tpb;
       const dim3 hgrid(ps_persistent_grid((long long)b.ntm * b.ntn, b.nb, b.tpb));
-      hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr>), hgrid, dim3(512), 2 * 36864 + 3 * 16384, s, b);
+      if (tw == 28) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28>), hgrid, dim3(512), 2 * 9 * 4096 + 3 * 16384, s, b);
+      else hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32>), hgrid, dim3(512), 2 * 10 * 4096 + 3 * 16384, s, b);
       PS_CHECK_LAUNCH("conv_igemm_halo");
       return PS_OK;
     }
@@ -1702,7 +1718,7 @@ extern "C" int ps_conv_variant(const ps_conv_geom* g, int32_t dgrad) {
   const long long M = dgrad ? (long long)g->n * g->h * g->w : (long long)g->n * ho * wo;
   if (g_use_3stage + g_use_pp != 0) return PS_CONV_OTHER;
   // both directions of a stride-1 3x3 layer gather on the input grid h x w
-  const bool halo_ok = g->ksize == 3 && g->stride == 1 && g->w % 28 == 0 && g->w <= 224 && g->dilation <= 4;
+  const bool halo_ok = g->ksize == 3 && g->stride == 1 && halo_tile_width(g->w) != 0 && g->dilation <= 4;
   const int v = pick_ws_variant(M, dgrad ? g->cin : g->cout, ps_esize(g->dtype), halo_ok);
   return v ? v : PS_CONV_4WAVE;
 }

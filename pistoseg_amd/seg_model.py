@@ -61,10 +61,20 @@ class ResNet38dSeg(resnet38d.Net):
         params = [p for _, p in self.trainable_conv_params()]
         if torch.is_grad_enabled() and params:
             return _SegFunction.apply(self, x, *params)
-        drop = self.sample_dropout(x.shape[0], x.device) if self.training else {}
+        n, _, h, w = x.shape
+        limit = self.max_tiles_per_launch(h, w)
+        if n > limit:  # the kernels address a tensor through 32-bit buffer offsets (< 2 GiB each): big inference batches
+            return torch.cat([self.forward(x[i:i + limit]) for i in range(0, n, limit)], 0)  # (d4 TTA: 8 views x N) go in slices
+        drop = self.sample_dropout(n, x.device) if self.training else {}
         feats, _ = self.run_backbone(x, save=False, drop=drop)
         logits, _ = self.head_forward(feats["conv6"], drop.get("dropout7"), x.shape[-2:])
         return logits
+
+    def max_tiles_per_launch(self, h: int, w: int) -> int:
+        """Largest batch one forward plan can take: its biggest tensor (conv1a's 64-channel output at full resolution) must stay
+        below 2 GiB, the range of the kernels' buffer descriptors (ps_conv2d_fwd rejects larger problems)."""
+        esize = 4 if self.precision == "fp32" else 2
+        return max(1, ((1 << 31) - 1) // (h * w * 64 * esize))
 
     def new_grad_buffers(self, device) -> Dict[str, Tensor]:
         """Zeroed f32 gradient buffers in the kernels' [cout][kh][kw][cin] layout, one per trainable conv."""

@@ -91,14 +91,15 @@ def _run(rank, world, port, backend, kind, out):
         if world > 1:
             assert len(tr.reducer.buckets) >= 3  # several buckets so the overlap path is exercised
             assert dist.get_backend(pg) == backend
+        init = tr.p_flat[::499].cpu().numpy()
         losses = [step() for _ in range(2)]
         torch.cuda.synchronize()
         f9 = {k: tr.p_flat[o:o + n].cpu().numpy() for k, (o, n) in tr.offsets.items() if k.startswith("f9_")}
-        out.put((world, rank, losses, tr.p_flat[::499].cpu().numpy(), f9))  # every 499th weight (numpy: plain pickle)
+        out.put((world, rank, losses, tr.p_flat[::499].cpu().numpy(), f9, init))  # every 499th weight (numpy: plain pickle)
     except Exception as e:  # pragma: no cover
         import traceback
 
-        out.put((world, rank, "ERR " + repr(e) + traceback.format_exc(), None, None))
+        out.put((world, rank, "ERR " + repr(e) + traceback.format_exc(), None, None, None))
     finally:
         if world > 1:
             dist.destroy_process_group()
@@ -133,10 +134,15 @@ def test_two_rank_step_equals_single_process_step(kind):
     d = abs(r0[3] - single[3])
     if kind == "seg":
         assert float(d.mean()) < 1e-6 and float(d.max()) <= 2 * 2 * 1e-3 * 1.1  # Adam sign noise bound, see test_modules_gpu
-    else:  # plain SGD: the update is linear in the gradient, only the summation order of the weight gradients differs
-        assert float(d.mean()) < 1e-7 and float(d.max()) <= 1e-4, (float(d.mean()), float(d.max()))
+    else:
+        # plain SGD: the update is linear in the gradient.  Between a 4-tile step and two 2-tile steps the weight gradients are summed
+        # in a different order (f32 atomics) and step 2 starts from parameters that already differ in the last bits, so the
+        # parameters agree to a small fraction of the distance they moved -- not bit for bit.
+        upd = float(abs(single[3] - single[5]).max())
+        print(f"rfm: max |update| {upd:.3e}, max |dp| {float(d.max()):.3e}, mean |dp| {float(d.mean()):.3e}")
+        assert float(d.max()) <= 5e-3 * upd and float(d.mean()) <= 1e-4 * upd, (float(d.max()), float(d.mean()), upd)
         for k in r0[4]:  # the packed f9 gradient was unpacked into both arena slots before their bucket was reduced
-            assert float(abs(r0[4][k] - single[4][k]).max()) <= 1e-4, k
+            assert float(abs(r0[4][k] - single[4][k]).max()) <= 5e-3 * upd, k
     print(f"{kind}: backend {backend}, losses {r0[2]} / {r1[2]} vs single {single[2]}, max |dp| {float(d.max()):.2e}")
 
 

@@ -456,6 +456,11 @@ def test_conv_pipelined_kernels_are_bit_identical_to_two_stage(case, dtype):
     # are real neighbour columns; h = 12 is not a multiple of 8; every dilation of the net; 1 .. 4 K-lines; 1 .. 3 cout tiles
     (3, 28, 28, 128, 128, 1), (2, 28, 28, 64, 256, 2), (3, 28, 28, 256, 128, 4), (1, 28, 28, 128, 256, 4), (5, 28, 28, 64, 128, 1),
     (7, 28, 28, 192, 384, 2), (2, 56, 56, 64, 128, 1), (1, 112, 112, 64, 128, 1), (1, 56, 84, 128, 128, 2), (1, 12, 56, 64, 256, 4),
+    # width a multiple of 32 (the maps of 256 x 256 inputs, stages 2 and 4): tiles of 8 rows x 32 columns = 256 pixels, windows of up
+    # to 40 columns (10 DMAs per loader wave); 32 x 32 maps = 4 whole tiles per image, 64 / 96 / 128-wide maps have 2-4 column blocks;
+    # h = 20 is not a multiple of 8 (tiles straddle images); every dilation; odd n
+    (3, 32, 32, 128, 128, 1), (2, 32, 32, 64, 256, 2), (3, 32, 32, 256, 128, 4), (5, 32, 32, 192, 384, 4), (2, 64, 64, 64, 128, 1),
+    (1, 128, 128, 64, 128, 1), (1, 40, 96, 128, 128, 2), (3, 20, 64, 64, 256, 4), (1, 32, 256, 64, 128, 1),
 ])
 def test_conv_halo_window_kernel(case, dtype):
     """conv_igemm_halo_kernel (pixel window + halo staged once per tap row, K order (K-line, ty, tx)) forced on small problems:
