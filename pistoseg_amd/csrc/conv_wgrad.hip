@@ -371,14 +371,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
       unsigned char* sg = smem + slot * STAGE;
       unsigned char* sx = sg + G_BYTES;
       const int gso = ks * KP * (int)a.dy_pix_bytes;
+      const bool stage = !(a.ablate == 3 && issued >= 3);  // timing experiment (results WRONG): consumers run on stale LDS contents
 #pragma unroll
-      for (int j = 0; j < NIG; ++j) BLDS16(rsG, sg + (wave * NIG + j) * 1024, goff[j], gso);
+      for (int j = 0; j < NIG; ++j)
+        if (stage) BLDS16(rsG, sg + (wave * NIG + j) * 1024, goff[j], gso);
 #pragma unroll
       for (int j = 0; j < NIX; ++j) {
         const int y = xp[j] * a.stride + dy_off, xx = xq[j] * a.stride + dx_off;
         const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)xx < (unsigned)a.W && xn[j] < n_img;
         const unsigned off = ok ? (unsigned)(((xn[j] * a.H + y) * a.W + xx) * (int)a.x_pix_bytes) + xchunk[j] : PAD_ROW;
-        BLDS16(rsX, sx + (wave * NIX + j) * 1024, off, 0);
+        if (stage) BLDS16(rsX, sx + (wave * NIX + j) * 1024, off, 0);
         int q = xq[j] + a.dq;  // advance this lane's pixel by KP
         const int c1 = q >= a.Wo;
         q -= c1 ? a.Wo : 0;
