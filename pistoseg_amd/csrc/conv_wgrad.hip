@@ -11,6 +11,7 @@
 // Block = 4 waves (2x2), tile BCO x BCI in {64,128}^2, one tap and one pixel range (split-K) per block;
 // partial sums are added to the f32 gradient with global_atomic_add_f32 (64-byte row segments).
 #include <algorithm>
+#include <type_traits>
 
 #include "ps_internal.h"
 
@@ -427,37 +428,52 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
   const int a_base = (8 * g + q4) * RBG + (p4 & 1) * 8 + (((wr * 16) + (p4 >> 1)) << 4);
   const int b_base = G_BYTES + (8 * g + q4) * RBX + (p4 & 1) * 8 + ((((wc ^ (s3 >> 2)) << 3) + (p4 >> 1)) << 4);
 
-  auto rd = [&](const unsigned char* st, int kk, bf16x8 (&af)[MI], bf16x8 (&bf)[NI]) {
+  auto mfma1 = [&](f32x4& c, const bf16x8& x, const bf16x8& y) {
+    if constexpr (F16) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
+    else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
+  };
+  // One K-half (32 pixels): the 2 x (MI + NI) = 24 transposed reads of (stage st, K-half kk) into (afn, bfn), INTERLEAVED with the
+  // MI x NI = 32 MFMAs on (afo, bfo), whose operands are already in registers: 3 reads, 4 MFMAs, 3 reads, 4 MFMAs, ...  A burst of
+  // 24 LDS instructions in front of the MFMAs (the first version) left the matrix pipe idle for their issue time twice per
+  // K-step -- this wave is its SIMD's only MFMA source: the consumers alone (loads ablated) ran at 1200-1360 TFLOP/s.  The order
+  // is pinned with scheduling barriers (hipcc otherwise hoists every read to the top).
+  auto half = [&](auto do_mma, const unsigned char* st, int kk, bf16x8 (&afn)[MI], bf16x8 (&bfn)[NI], const bf16x8 (&afo)[MI],
+                  const bf16x8 (&bfo)[NI], f32x4 (&acc)[MI][NI]) {  // do_mma: std::true_type / std::false_type (an item's first half step)
     int z;
     asm volatile("s_mov_b32 %0, 0" : "=s"(z));  // opaque zero: keeps the address arithmetic inside the loop (see above)
     const int sd = s3 + z;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int roff = (kk * 32 + 4 * h);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
+    constexpr int NR = 2 * (MI + NI), NM = MI * NI;  // 24 reads, 32 MFMAs: groups of 3 reads + 4 MFMAs
+    auto read1 = [&](int r) {  // r: 0..15 = A fragment r >> 1, half r & 1; 16..23 = B fragment (r - 16) >> 1, half (r - 16) & 1
+      if (r < 2 * MI) {
+        const int i = r >> 1, h = r & 1, roff = kk * 32 + 4 * h;
         const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(st + a_base + roff * RBG + ((i ^ sd) << 5)));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) af[i][4 * h + e] = t[e];
-      }
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
+        for (int e = 0; e < 4; ++e) afn[i][4 * h + e] = t[e];
+      } else {
+        const int j = (r - 2 * MI) >> 1, h = r & 1, roff = kk * 32 + 4 * h;
         const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(st + b_base + roff * RBX + ((j ^ (sd & 3)) << 5)));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bf[j][4 * h + e] = t[e];
+        for (int e = 0; e < 4; ++e) bfn[j][4 * h + e] = t[e];
+      }
+    };
+#pragma unroll
+    for (int grp = 0; grp < 8; ++grp) {
+#pragma unroll
+      for (int r = 3 * grp; r < 3 * grp + 3; ++r) read1(r);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (decltype(do_mma)::value) {
+#pragma unroll
+        for (int q = 4 * grp; q < 4 * grp + 4; ++q) mfma1(acc[q >> 2][q & 3], afo[q >> 2], bfo[q & 3]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    static_assert(NR == 24 && NM == 32, "interleave pattern");
   };
   auto mma = [&](f32x4 (&acc)[MI][NI], const bf16x8 (&af)[MI], const bf16x8 (&bf)[NI]) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        if constexpr (F16)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[i]), __builtin_bit_cast(f16x8, bf[j]), acc[i][j], 0, 0, 0);
-        else
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-      }
+      for (int j = 0; j < NI; ++j) mfma1(acc[i][j], af[i], bf[j]);
   };
 
   __builtin_amdgcn_s_barrier();  // step 0 visible
@@ -472,18 +488,22 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
 #pragma unroll
       for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 af0[MI], bf0[NI], af1[MI], bf1[NI];
-    for (int ks = ks0; ks < ks1; ++ks) {
+    {  // first K-step of the item (ks1 > ks0 always): nothing to overlap its first reads with
       const unsigned char* st = smem + cur * STAGE;
-      rd(st, 0, af0, bf0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (ks > ks0) mma(acc, af1, bf1);  // previous step's second half: operands already in registers
-      __builtin_amdgcn_sched_barrier(0);
+      half(std::false_type{}, st, 0, af0, bf0, af1, bf1, acc);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      rd(st, 1, af1, bf1);
+      half(std::true_type{}, st, 1, af1, bf1, af0, bf0, acc);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      cur = (cur == 2) ? 0 : cur + 1;
+    }
+    for (int ks = ks0 + 1; ks < ks1; ++ks) {
+      const unsigned char* st = smem + cur * STAGE;
+      half(std::true_type{}, st, 0, af0, bf0, af1, bf1, acc);  // this step's first half is read behind the previous step's second-half MFMAs
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      mma(acc, af0, bf0);
-      __builtin_amdgcn_sched_barrier(0);
+      half(std::true_type{}, st, 1, af1, bf1, af0, bf0, acc);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this ring slot may be refilled after the barrier
       __builtin_amdgcn_s_barrier();
       cur = (cur == 2) ? 0 : cur + 1;
