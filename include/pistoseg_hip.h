@@ -99,9 +99,7 @@ enum {
   PS_CONV_WS2_256 = 4,  /* conv_igemm_ws2_kernel<256>: 256x128 tile, one block per CU, 3-stage ring */
   PS_CONV_WS2_224 = 5,  /* conv_igemm_ws2_kernel<224> */
   PS_CONV_OTHER = 6,    /* an experimental kernel forced through the testing hooks */
-  PS_CONV_HALO = 7,     /* conv_igemm_halo_kernel: 3x3 stride-1, width % 28 == 0 (224x128 tile of 8 rows x 28 columns) or % 32 == 0 (256x128, 8 x 32), pixel window + halo staged once per tap row */
-  PS_CONV_BIG_256 = 8, /* conv_igemm_big_kernel<256>: 256x256 tile, 4 waves (one per SIMD, 512 VGPRs) that stage and compute; 1x1 layers, cout % 256 == 0 */
-  PS_CONV_BIG_224 = 9   /* conv_igemm_big_kernel<224>: 224x256 tile */
+  PS_CONV_HALO = 7      /* conv_igemm_halo_kernel: 3x3 stride-1, width % 28 == 0 (224x128 tile of 8 rows x 28 columns) or % 32 == 0 (256x128, 8 x 32), pixel window + halo staged once per tap row */
 };
 int ps_conv_variant(const ps_conv_geom* g, int32_t dgrad);
 /* 1 if ps_conv2d_wgrad will launch conv_wgrad_ws2_kernel (256x128 tile, persistent) for this geometry, 0 for conv_wgrad_kernel, -1 unsupported. */

@@ -41,8 +41,6 @@ void ps_debug_set_ws(int v);
 void ps_debug_set_ws2(int v);
 /* Testing hook: window + halo kernel for 3x3 stride-1 layers (width a multiple of 28): 0 off, 1 (default) for big 16-bit problems, 2 forced. */
 void ps_debug_set_halo(int v);
-/* Testing hook: big-tile (224|256 x 256, one wave per SIMD) kernel for 1x1 layers: 0 off, 1 (default) big 16-bit problems, 2 forced. */
-void ps_debug_set_big(int v);
 void ps_debug_set_s2split(int v);  /* stride-2 3x3 data gradient as four parity-class launches: 0 off, 1 big 16-bit problems (default), 2 whenever legal */
 /* Testing hook: 1 (default) = 128x128 weight-gradient tiles use the wave-specialised variant, 0 = the 4-wave kernel. */
 void ps_debug_set_wgrad_ws(int v);

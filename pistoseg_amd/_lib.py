@@ -141,7 +141,6 @@ DEBUG_PROTOTYPES = {
     "ps_debug_set_ws": (None, [C.c_int]),
     "ps_debug_set_ws2": (None, [C.c_int]),
     "ps_debug_set_halo": (None, [C.c_int]),
-    "ps_debug_set_big": (None, [C.c_int]),
     "ps_debug_set_s2split": (None, [C.c_int]),
     "ps_debug_set_wgrad_ws": (None, [C.c_int]),
     "ps_debug_set_wgrad_ws2": (None, [C.c_int]),

@@ -61,22 +61,12 @@ __device__ __forceinline__ void ps_tile_of_block(int bid, int ntn, int ntm, int&
 
 struct TraitsBF16 {
   typedef __bf16 elem;
-  // The same MFMA with its register classes pinned: accumulator in the AGPR half of the unified file, operands in VGPRs.  The big-tile
-  // kernel needs 256 accumulator registers + 128 operand registers per wave; left to itself hipcc puts some operand fragments into
-  // AGPRs as well, runs out of them and spills ACCUMULATORS to scratch inside the K loop while 150 VGPRs sit unused.
-  static __device__ __forceinline__ void mma_a(const u32x4& w, const u32x4& x, f32x4& acc) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(x));
-  }
   static __device__ __forceinline__ void mma(const u32x4& w, const u32x4& x, f32x4& acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
   }
 };
 struct TraitsF16 {
   typedef _Float16 elem;
-  // (see TraitsBF16::mma_a)
-  static __device__ __forceinline__ void mma_a(const u32x4& w, const u32x4& x, f32x4& acc) {
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(x));
-  }
   static __device__ __forceinline__ void mma(const u32x4& w, const u32x4& x, f32x4& acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
   }
@@ -171,9 +161,7 @@ struct Raw8 {
 // rows past the end are dropped by the range check (no predication, no 64-bit address arithmetic), and no load is left pending on
 // any path, so the next tile's first MFMAs need no vmcnt wait.  Layers with dropout (per-row multipliers; b6 / b7 only) keep the
 // row-by-row order.  (f32 tensors: 8 channels at a time to bound the registers.)
-// GS: channel distance between consecutive lane groups g (default: the CH channels this call handles per lane; the big-tile kernel,
-// whose lanes own 32 contiguous channels, calls it once per 16-channel half with GS = 32).
-template <typename T, int MI, int WI, int MAP = 0, int CW = (sizeof(T) == 2 ? 4 * WI : 8), int GS = 4 * WI>  // MAP: 0 rows = pixels in order, 1 halo kernel's 8 x 2 patches, 2 parity sub-grid
+template <typename T, int MI, int WI, int MAP = 0, int CW = (sizeof(T) == 2 ? 4 * WI : 8)>  // MAP: 0 rows = pixels in order, 1 halo kernel's 8 x 2 patches, 2 parity sub-grid
 __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[MI][WI], int mbase, int cbase, int lane) {
   constexpr bool COLMAP = MAP == 1;
   constexpr int CH = 4 * WI;  // 16 or 8 channels per lane, handled CW at a time
@@ -203,7 +191,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
   };
 #pragma unroll
   for (int c0 = 0; c0 < CH; c0 += CW) {
-    const int cb = cbase + GS * g + c0;
+    const int cb = cbase + CH * g + c0;
     float sc[CW], sh[CW];
     auto load_vec = [&](const float* p, float* v) {  // CW consecutive floats (16-byte aligned: cb is a multiple of 8)
 #pragma unroll
@@ -1513,227 +1501,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Big-tile kernel: BM x 256 (BM = 256 or 224 pixels x 256 couts), FOUR waves (2x2, each (BM/2) x 128: 8|7 pixel fragments x 8
-// cout fragments = 256|224 accumulator registers), ONE wave per SIMD -- so every wave has the whole 512-entry register file --
-// and each wave both stages (LDS-DMA) and computes.
-//   The 8-wave kernels above are bound by the L2 -> LDS fill path, not by the matrix pipe (r02: the weight-gradient
-//   consumers alone run 25-30 % faster than with their loaders): a (224|256) x 128 tile stages (BM + 128) x 128 B per 64-deep K-step,
-//   81-87 FLOP per staged byte.  Their 256-VGPR limit (2 waves per SIMD) caps the tile; with one wave per SIMD a 256 x 256 tile
-//   fits (256 accumulators + 2 x 64 fragment registers), staging (BM + 256) x 128 B for twice the MFMAs: 128 FLOP/B, and half
-//   the LDS fragment traffic per MFMA.  The price is that the MFMA waves issue the DMAs themselves (16 per wave and K-step,
-//   spread one per four MFMAs); no loader waves means no partner on the SIMD to hide a stall, so the pipeline is explicit:
-//     step s:  [first-half MFMAs  || second-half fragment reads]  wait(LDS reads, DMA of step s+1)  barrier
-//              [second-half MFMAs || first-half reads of step s+1 || issue DMA of step s+2 into the stage just released]
-//   Two LDS stages of (BM + 256) x 128 B = 128 | 120 KiB; a DMA has a whole K-step (~1.2 us) to land.
-// Serves the 1x1 stride-1 layers with >= 256 produced channels (plain GEMMs: produced pixel m reads source row m).
-// ------------------------------------------------------------------------------------------------
-// An accumulator quad moved from the AGPR half of the register file into VGPRs HERE (volatile asm keeps its place): left to the
-// register allocator, the AGPR -> VGPR copies of all 256 accumulator registers are placed right behind the K loop, all at once, and the
-// epilogue spills by the hundred.
-__device__ __forceinline__ f32x4 agpr_quad_to_vgpr(const f32x4& q) {
-  f32x4 v;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float x;
-    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(q[r]));
-    v[r] = x;
-  }
-  return v;
-}
-
-template <typename Tr, int BM>
-__global__ __launch_bounds__(256, 1) void conv_igemm_big_kernel(const IgemmArgs a) {
-  typedef typename Tr::elem T;
-  constexpr int BN = 256, MI = BM / 32, WI = 8, WM = 16 * MI, WN = 128;
-  constexpr int AJ = BM / 32, BJ = BN / 32;               // DMA instructions (1 KiB = 8 rows) per wave per K-step: 8|7 + 8
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  static_assert(BM == 256 || BM == 224, "pixel tile");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int first, G, ntiles;  // this block's tiles: first, first + G, ... < ntiles
-  ps_block_items(blockIdx.x, gridDim.x, a.ntm * a.ntn, a.nb, a.tpb, first, G, ntiles);
-  const int nsteps = a.klines;  // one tap
-  const int my_tiles = (ntiles - first + G - 1) / G;  // >= 1
-  const int total_steps = my_tiles * nsteps;
-
-  // ---------------- staging state ----------------
-  // A plain GEMM (1x1, stride 1): produced pixel m reads source row m.  DMA instruction t = 4 j + wave of a K-step stages tile rows
-  // 8 t .. 8 t + 7 = 32 j + r0 + (0..7 by lane), r0 = 8 wave + (lane >> 3): the lane part of every address is ONE register per operand
-  // and everything that changes with j, the K-line and the tile is a scalar (the DMA's soffset) -- no per-row address arrays, no
-  // divisions in the MFMA waves.  Rows past the tensor's end fall outside the buffer descriptor and are zero-filled by the DMA.
-  const int srow = lane >> 3, r0 = 8 * wave + srow;
-  const int chunk_off = ((lane & 7) ^ srow) << 4;
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, (int)a.src_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, 0, (int)a.wgt_bytes, 0x00020000);
-  const unsigned a_lane = (unsigned)(r0 * (int)a.pix_bytes) + chunk_off;
-  // B-tile row rb = 32 j + r0 holds the cout that makes lane group g = rho >> 2 of a consumer own 4 * WI = 32 CONTIGUOUS couts:
-  // cout = n0 + 128 (j >> 2) + 8 (j & 3)  [scalar]  +  32 (rho >> 2) + 4 (r0 >> 4) + (rho & 3), rho = r0 & 15  [lane]
-  const unsigned w_lane = (unsigned)((32 * ((r0 & 15) >> 2) + 4 * (r0 >> 4) + (r0 & 3)) * (int)a.wrow_bytes) + chunk_off;
-  int l_kl = 0, l_tile = first, l_slot = 0, issued = 0;
-  int l_a0 = 0, l_w0 = 0;  // scalar byte offsets of the tile being staged: its first pixel row / its first cout row
-  auto tile_setup = [&](int tile) __attribute__((always_inline)) {
-    int tm, tn;
-    ps_tile_of_block(tile, a.ntn, a.ntm, tm, tn, a.supertile);
-    l_a0 = __builtin_amdgcn_readfirstlane(tm * BM * (int)a.pix_bytes);
-    l_w0 = __builtin_amdgcn_readfirstlane(tn * BN * (int)a.wrow_bytes);
-    l_kl = 0;
-  };
-  // one DMA instruction of the K-step being staged: i in [0, AJ + BJ)
-  auto dma1 = [&](int i) __attribute__((always_inline)) {
-    unsigned char* sa = smem + l_slot * STAGE;
-    if (i < AJ) {
-      BLDS16(rsA, sa + (i * 4 + wave) * 1024, a_lane, l_a0 + i * 32 * (int)a.pix_bytes + l_kl * 128);
-    } else {
-      const int jb = i - AJ;
-      BLDS16(rsB, sa + A_BYTES + (jb * 4 + wave) * 1024, w_lane, l_w0 + (128 * (jb >> 2) + 8 * (jb & 3)) * (int)a.wrow_bytes + l_kl * 128);
-    }
-  };
-  auto dma_advance = [&]() __attribute__((always_inline)) {  // after the last DMA of a K-step: move the cursor to the next step of the flat sequence
-    ++issued;
-    l_slot ^= 1;
-    if (++l_kl == a.klines && issued < total_steps) {
-      l_tile += G;
-      tile_setup(l_tile);
-    }
-  };
-  auto issue_step_burst = [&]() __attribute__((always_inline)) {  // prologue only: a whole K-step back to back
-    if (issued >= total_steps) return;
-#pragma unroll
-    for (int i = 0; i < AJ + BJ; ++i) dma1(i);
-    dma_advance();
-  };
-
-  // ---------------- compute state ----------------
-  const int wm = wave >> 1, wn = wave & 1;
-  const int frow = lane & 15, g = lane >> 4;
-  const int xfrag = (wm * WM + frow) * 128, wfrag = A_BYTES + (wn * WN + frow) * 128;
-  const int sw = lane & 7;
-  const int coff0 = (g ^ sw) << 4, coff1 = ((g + 4) ^ sw) << 4;
-  u32x4 wf0[WI], xf0[MI], wf1[WI], xf1[MI];  // fragments of the first / second K-half of a step
-  constexpr int NR = WI + MI, NM = MI * WI;   // 16|15 fragment reads, 64|56 MFMAs per K-half
-
-  tile_setup(l_tile);
-  issue_step_burst();  // step 0 -> stage 0
-  issue_step_burst();  // step 1 -> stage 1
-  if (total_steps > 1) {
-    if constexpr (AJ + BJ == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();  // step 0 visible
-  {  // first-half fragments of step 0: nothing to overlap them with
-    const unsigned char* st = smem;
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      if (r < WI) wf0[r] = *reinterpret_cast<const u32x4*>(st + wfrag + r * 2048 + coff0);
-      else xf0[r - WI] = *reinterpret_cast<const u32x4*>(st + xfrag + (r - WI) * 2048 + coff0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
-
-  int cur = 0, gs = 0;
-  for (int tile = first; tile < ntiles; tile += G) {
-    f32x4 acc[MI][WI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int i = 0; i < WI; ++i) acc[mi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < nsteps; ++s, ++gs) {
-      const unsigned char* st = smem + cur * STAGE;
-      // ---- phase A: first-half MFMAs (wf0, xf0) || second-half fragment reads of this stage (one read per four MFMAs)
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        if (r < WI) wf1[r] = *reinterpret_cast<const u32x4*>(st + wfrag + r * 2048 + coff1);
-        else xf1[r - WI] = *reinterpret_cast<const u32x4*>(st + xfrag + (r - WI) * 2048 + coff1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = r * 4; q < (r + 1) * 4 && q < NM; ++q) Tr::mma_a(wf0[q % WI], xf0[q / WI], acc[q / WI][q % WI]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int q = NR * 4; q < NM; ++q) Tr::mma_a(wf0[q % WI], xf0[q / WI], acc[q / WI][q % WI]);
-      __builtin_amdgcn_sched_barrier(0);
-      // every read of this stage is done; the DMA of step gs + 1 (issued one K-step ago) has landed
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      cur ^= 1;
-      // ---- phase B: second-half MFMAs (wf1, xf1) || first-half reads of step gs + 1 (other stage) || DMA of step gs + 2 into the
-      //      stage just released
-      const bool more_dma = issued < total_steps;        // uniform
-      const bool next_in_tile = s + 1 < nsteps;
-      const unsigned char* sn = smem + cur * STAGE;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        // the DMAs go out in the first half of the phase, two per group: the last one then has >= 3/4 of a K-step to land
-        if (r < 8 && more_dma) {
-          if (2 * r < AJ + BJ) dma1(2 * r);
-          if (2 * r + 1 < AJ + BJ) dma1(2 * r + 1);
-        }
-        if (next_in_tile && r < NR) {
-          if (r < WI) wf0[r] = *reinterpret_cast<const u32x4*>(sn + wfrag + r * 2048 + coff0);
-          else xf0[r - WI] = *reinterpret_cast<const u32x4*>(sn + xfrag + (r - WI) * 2048 + coff0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = r * 4; q < (r + 1) * 4 && q < NM; ++q) Tr::mma_a(wf1[q % WI], xf1[q / WI], acc[q / WI][q % WI]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (more_dma) dma_advance();
-      __builtin_amdgcn_sched_barrier(0);
-      if (next_in_tile) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    // the MFMAs are inline asm: the compiler's hazard recogniser does not see them; let the last ones retire before the epilogue reads
-    // the accumulators (8-pass MFMA -> VALU read: <= 18 wait states)
-    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-    int tm, tn;
-    ps_tile_of_block(tile, a.ntn, a.ntm, tm, tn, a.supertile);
-    // a lane owns 32 contiguous channels (8 fragments) of MI x 16 pixels: the epilogue runs per (16-channel half, group of <= 4 fragment
-    // rows) on a VGPR copy of those 16 accumulator quads (they live in AGPRs; in-place arithmetic on all 256 registers made hipcc pull
-    // everything into VGPRs at once and spill by the hundred)
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      {
-        f32x4 loc[4][4];
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) loc[mi][i] = agpr_quad_to_vgpr(acc[mi][4 * hh + i]);
-        conv_epilogue<T, 4, 4, 0, 16, 32>(a, loc, tm * BM + wm * WM, tn * BN + wn * WN + 16 * hh, lane);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      {
-        constexpr int MR = MI - 4;  // 4 | 3
-        f32x4 loc[MR][4];
-#pragma unroll
-        for (int mi = 0; mi < MR; ++mi)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) loc[mi][i] = agpr_quad_to_vgpr(acc[4 + mi][4 * hh + i]);
-        conv_epilogue<T, MR, 4, 0, 16, 32>(a, loc, tm * BM + wm * WM + 64, tn * BN + wn * WN + 16 * hh, lane);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (tile + G < ntiles) {  // first-half fragments of the next tile's first step (its stage was made visible by the last barrier)
-      const unsigned char* sn = smem + cur * STAGE;
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        if (r < WI) wf0[r] = *reinterpret_cast<const u32x4*>(sn + wfrag + r * 2048 + coff0);
-        else xf0[r - WI] = *reinterpret_cast<const u32x4*>(sn + xfrag + (r - WI) * 2048 + coff0);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-  }
-}
-
 PS_TUNABLE g_use_glds = 2;  // staging mode: 0 registers, 1 global_load_lds, 2 buffer_load ... lds
 PS_TUNABLE g_use_pp = 0;       // experimental ping-pong kernel (correct, slower: r01 measurements)
 PS_TUNABLE g_use_ws = 1;       // wave-specialised (loader/consumer) kernel for big problems
 PS_TUNABLE g_use_ws2 = 1;
 PS_TUNABLE g_use_halo = 1;     // window + halo staging for 3x3 stride-1 layers (width a multiple of 28): 0 off, 1 for big 16-bit problems, 2 forced      // large-tile wave-specialised kernel: 0 off, 1 by cost model, 256 / 224 force that pixel tile
-PS_TUNABLE g_use_big = 1;     // big-tile (BM x 256, one wave per SIMD) kernel for 1x1 layers with >= 256 produced channels: 0 off, 1 big 16-bit problems, 2 forced
 PS_TUNABLE g_use_3stage = 0;  // experimental 256x128 three-stage kernel: correct but slower than two 128x128 blocks per CU (r01 measurements)
 PS_TUNABLE g_ablate = 0;
 PS_TUNABLE g_supertile = 4;  // measured best of {0,4,8,16} on the wide 28x28 layers (r01)
@@ -1828,15 +1600,9 @@ int set_extents(IgemmArgs& a, long long src_bytes, long long wgt_bytes, int es) 
 // reference: infer_pseudo_masks.py:50, infer_revise_masks.py:46); 0 if neither divides w.
 static int halo_tile_width(int w) { return (w <= 0 || w > 256) ? 0 : (w % 28 == 0 ? 28 : (w % 32 == 0 ? 32 : 0)); }
 
-static int pick_ws_variant(long long M, int Cd, int esize, bool halo_ok, bool gemm1x1 = false) {
+static int pick_ws_variant(long long M, int Cd, int esize, bool halo_ok) {
   if (g_use_glds != 2 || Cd % 128 != 0) return 0;
   const long long n128 = Cd / 128;
-  // 1x1 layers (plain GEMMs) with >= 256 produced channels: the big tile (BM x 256, one wave per SIMD) halves the staged bytes per FLOP
-  if (gemm1x1 && g_use_big && esize == 2 && Cd % 256 == 0 && (g_use_big == 2 || ((M + 255) / 256) * (Cd / 256) >= 256)) {
-    const long long n256 = Cd / 256, t256 = (M + 255) / 256, t224 = (M + 223) / 224;
-    const long long c256 = ((t256 * n256 + 255) / 256) * 256, c224 = ((t224 * n256 + 255) / 256) * 224;
-    return c224 * 103 < c256 * 100 ? PS_CONV_BIG_224 : PS_CONV_BIG_256;
-  }
   // 3x3 stride-1 layers whose 224-pixel tiles are whole feature-map rows: window + halo staging (less LDS fill traffic)
   if (halo_ok && g_use_halo && (g_use_halo == 2 || (g_use_ws2 == 1 && esize == 2 && ((M + 223) / 224) * n128 >= 256))) return PS_CONV_HALO;
   if (g_use_ws2 && (g_use_ws2 > 1 || (esize == 2 && n128 >= 2 && ((M + 255) / 256) * n128 >= 256))) {
@@ -1887,23 +1653,9 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
   }
   const int adil = a.dstep < 0 ? -a.dstep : a.dstep;
   const bool halo_ok = a.taps == 9 && a.mul == 1 && a.div_shift == 0 && a.Hs == a.Ho && a.Ws == a.Wo && halo_tile_width(a.Ws) != 0 && adil <= 4;
-  if (const int v = pick_ws_variant(a.M, a.Cd, (int)sizeof(typename Tr::elem), halo_ok, a.taps == 1 && a.mul == 1 && a.div_shift == 0 && a.Hs == a.Ho && a.Ws == a.Wo)) {
+  if (const int v = pick_ws_variant(a.M, a.Cd, (int)sizeof(typename Tr::elem), halo_ok)) {
     IgemmArgs b = a;
     b.ntn = a.Cd / 128;
-    if constexpr (sizeof(typename Tr::elem) == 2) {
-      if (v == PS_CONV_BIG_256 || v == PS_CONV_BIG_224) {
-        const int bm = v == PS_CONV_BIG_256 ? 256 : 224;
-        b.ntn = a.Cd / 256;
-        b.ntm = (a.M + bm - 1) / bm;
-        b.nb = ps_num_cus();
-        b.tpb = a.tpb;
-        const dim3 bgrid(ps_persistent_grid((long long)b.ntm * b.ntn, b.nb, b.tpb));
-        if (bm == 256) hipLaunchKernelGGL((conv_igemm_big_kernel<Tr, 256>), bgrid, dim3(256), 2 * (256 + 256) * 128, s, b);
-        else hipLaunchKernelGGL((conv_igemm_big_kernel<Tr, 224>), bgrid, dim3(256), 2 * (224 + 256) * 128, s, b);
-        PS_CHECK_LAUNCH("conv_igemm_big");
-        return PS_OK;
-      }
-    }
     if (v == PS_CONV_HALO) {
       const int tw = halo_tile_width(a.Ws);
       b.ntm = (a.M / a.Ws + 7) / 8 * (a.Ws / tw);  // blocks of 8 global rows x column blocks of tw
@@ -1955,7 +1707,6 @@ extern "C" void ps_debug_set_pp(int v) { g_use_pp = v; }
 extern "C" void ps_debug_set_ws(int v) { g_use_ws = v; }
 extern "C" void ps_debug_set_ws2(int v) { g_use_ws2 = v; }
 extern "C" void ps_debug_set_halo(int v) { g_use_halo = v; }
-extern "C" void ps_debug_set_big(int v) { g_use_big = v; }
 extern "C" void ps_debug_set_supertile(int v) { g_supertile = v; }
 #endif
 
@@ -1968,7 +1719,7 @@ extern "C" int ps_conv_variant(const ps_conv_geom* g, int32_t dgrad) {
   if (g_use_3stage + g_use_pp != 0) return PS_CONV_OTHER;
   // both directions of a stride-1 3x3 layer gather on the input grid h x w
   const bool halo_ok = g->ksize == 3 && g->stride == 1 && halo_tile_width(g->w) != 0 && g->dilation <= 4;
-  const int v = pick_ws_variant(M, dgrad ? g->cin : g->cout, ps_esize(g->dtype), halo_ok, g->ksize == 1 && g->stride == 1);
+  const int v = pick_ws_variant(M, dgrad ? g->cin : g->cout, ps_esize(g->dtype), halo_ok);
   return v ? v : PS_CONV_4WAVE;
 }
 

@@ -772,78 +772,3 @@ def test_stride2_dgrad_parity_class_launches_are_bit_identical(case, dtype):
     wt = wd.float().cpu().permute(3, 0, 1, 2).contiguous()  # [cin][kh][kw][cout] -> OIHW of the forward conv
     ref = torch.nn.grad.conv2d_input((n, cin, h, w), wt, q(gy.float().cpu()).permute(0, 3, 1, 2), stride=2, padding=1)
     assert rel_err(outs[1][1].float().cpu().permute(0, 3, 1, 2), ref) < TOL[dtype]
-
-
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("case", [
-    # (n, h, w, cin, cout, drop): 1x1 stride-1 layers = plain GEMMs on the big-tile kernel (224|256 pixels x 256 couts, 4 waves that stage
-    # AND compute, accumulators in AGPRs).  Ragged pixel counts (zero-filled tail rows), 1 .. 8 K-steps, 1 .. 3 cout tiles, one and
-    # several tiles per persistent block, waves whose rows straddle two images with per-image dropout multipliers
-    (2, 13, 10, 256, 256, False), (3, 9, 11, 64, 512, False), (5, 28, 28, 512, 256, True), (2, 28, 28, 128, 768, True),
-    (40, 28, 28, 192, 512, False), (1, 7, 5, 320, 256, True),
-])
-def test_conv_big_tile_gemm_kernel(case, dtype):
-    """conv_igemm_big_kernel forced on small problems: forward with the full epilogue (residual in, raw out, BN+ReLU[+dropout] out) and
-    the data gradient with the ReLU-backward epilogue (mask, scale, dropout, add) against the CPU; agreement with the 8-wave kernels
-    on the same data; two runs bit-identical (race screen)."""
-    from pistoseg_amd import _lib, ops
-
-    lib = _lib.load()
-    n, h, w, cin, cout, use_drop = case
-    g = torch.Generator().manual_seed(h + cin + cout)
-    q = quant(dtype)
-    x = q(torch.randn(n, cin, h, w, generator=g)).requires_grad_(True)
-    wt = q(torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5)
-    y = F.conv2d(x, wt)
-    res = q(torch.randn(y.shape, generator=g))
-    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
-    drop = ((torch.rand(n, cout, generator=g) >= 0.3).float() / 0.7) if use_drop else None
-    act = F.relu((y + res) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
-    if use_drop:
-        act = act * drop.view(n, cout, 1, 1)
-    gy = q(torch.randn(y.shape, generator=g))
-    y.backward(gy)
-    # data gradient with the ReLU-backward epilogue: out = (mask > 0 ? dx * s * dropin : 0) + add1
-    mask = q(torch.randn(n, cin, h, w, generator=g))
-    isc = torch.rand(cin, generator=g) + 0.5
-    dropin = ((torch.rand(n, cin, generator=g) >= 0.3).float() / 0.7) if use_drop else None
-    add1 = q(torch.randn(n, cin, h, w, generator=g))
-    gx_full = x.grad * isc.view(1, -1, 1, 1)
-    if use_drop:
-        gx_full = gx_full * dropin.view(n, cin, 1, 1)
-    gx_ref = torch.where(mask > 0, gx_full, torch.zeros(())) + add1
-    tol = TOL[dtype]
-    spec = ops.ConvSpec(cin, cout, 1, 1, 1)
-    D = dev()
-    xd, wf, wd = nhwc(x.detach()).to(D, dtype), w_fwd_layout(wt).to(D, dtype), w_dgrad_layout(wt).to(D, dtype)
-    resd, gyd, maskd, add1d = nhwc(res).to(D, dtype), nhwc(gy).to(D, dtype), nhwc(mask).to(D, dtype), nhwc(add1).to(D, dtype)
-    dd = None if drop is None else drop.to(D)
-    ddin = None if dropin is None else dropin.to(D)
-
-    def run():
-        out_raw = torch.full((n, h, w, cout), float("nan"), device=D, dtype=dtype)
-        out_act = torch.full((n, h, w, cout), float("nan"), device=D, dtype=dtype)
-        ops.conv2d_fwd(spec, xd, wf, add0=resd, out_raw=out_raw, bn_scale=scale.to(D), bn_shift=shift.to(D), drop=dd, out_act=out_act)
-        gx = torch.full((n, h, w, cin), float("nan"), device=D, dtype=dtype)
-        ops.conv2d_dgrad(spec, gyd, wd, (h, w), mask_src=maskd, bn_scale=isc.to(D), drop=ddin, add1=add1d, out=gx)
-        return out_raw, out_act, gx
-
-    try:
-        lib.ps_debug_set_big(2)
-        g1 = _lib.ConvGeom(_lib.PS_BF16 if dtype == torch.bfloat16 else _lib.PS_F16, n, h, w, cin, cout, 1, 1, 1, cin, cout, 0)
-        import ctypes as C
-
-        assert int(lib.ps_conv_variant(C.byref(g1), 0)) in (8, 9)  # PS_CONV_BIG_256 / _224 really serve this launch
-        if cin % 256 == 0:
-            assert int(lib.ps_conv_variant(C.byref(g1), 1)) in (8, 9)
-        got = [run() for _ in range(2)]
-        lib.ps_debug_set_big(0)
-        other = run()
-    finally:
-        lib.ps_debug_set_big(1)
-    refs = (nhwc((y + res).detach()), nhwc(act.detach()), nhwc(gx_ref))
-    for trial in got:
-        for a_, r_, o_ in zip(trial, refs, other):
-            assert rel_err(a_.float().cpu(), r_) < tol
-            assert rel_err(a_.float().cpu(), o_.float().cpu()) < max(tol, 1e-5)
-    assert all(torch.equal(a_, b_) for a_, b_ in zip(got[0], got[1]))

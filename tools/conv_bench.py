@@ -72,7 +72,6 @@ def main():
                     lib.ps_debug_set_ws(1)
                     lib.ps_debug_set_ws2(1)
                     lib.ps_debug_set_halo(1)
-                    lib.ps_debug_set_big(1)
                     lib.ps_debug_set_ablate(0)
                     lib.ps_debug_set_wgrad_ws2(1)
                     lib.ps_debug_set_wgrad_ablate(0)
