@@ -354,6 +354,15 @@ int ps_d4_view(const float* src, float* dst, int64_t planes, int32_t side, int32
 /* x /= divisor (the 'mean' merge of the eight views). */
 int ps_scale_inplace(float* x, int64_t n, float divisor, void* stream);
 
+/* Dropout2d multipliers of one training step in ONE launch.  out: flat f32 buffer of plan->nseg <= 8 segments (one per Dropout2d
+ * module: [n, channels] each, segment k = elements [end[k-1], end[k])); out[e] = (u >= p[k]) / (1 - p[k]) with u uniform on a 24-bit
+ * grid from Philox4x32-10 (key = seed, counter = (e / 4, offset)): the same (seed, offset) always gives the same masks, a new offset
+ * per step a new draw.  replaces: the Bernoulli draw inside nn.Dropout2d (models/resnet38d.py:63,67,85,90; models/revise_net.py:11,50);
+ * the multiplication is fused into the conv / fc8 kernels (ps_epilogue.drop).  torch's own RNG stream cannot be reproduced: parity
+ * tests inject the masks on both sides. */
+typedef struct ps_dropout_plan { int32_t nseg; int32_t _pad; int64_t end[8]; float p[8]; } ps_dropout_plan;
+int ps_dropout2d_masks(float* out, const ps_dropout_plan* plan, uint64_t seed, uint64_t offset, void* stream);
+
 /* *count += number of inf/nan elements of g[0..n) (caller zeroes count).  Used by fp16 dynamic loss scaling: an overflowed
  * activation gradient reaches the f32 gradient arena as inf/nan, and the step is then skipped. */
 int ps_nonfinite_count(const float* g, int64_t n, int32_t* count, void* stream);

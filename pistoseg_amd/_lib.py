@@ -45,6 +45,10 @@ class Epilogue(C.Structure):
     ]
 
 
+class DropoutPlan(C.Structure):  # ps_dropout_plan
+    _fields_ = [("nseg", C.c_int32), ("_pad", C.c_int32), ("end", C.c_int64 * 8), ("p", C.c_float * 8)]
+
+
 class WtItem(C.Structure):  # ps_wt_item
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("cout", C.c_int32), ("taps", C.c_int32), ("cin", C.c_int32), ("dst_ld", C.c_int32)]
 
@@ -109,6 +113,7 @@ PROTOTYPES = {
     "ps_d4_view": (C.c_int, [_P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "ps_scale_inplace": (C.c_int, [_P, _L, _F, _P]),
     "ps_nonfinite_count": (C.c_int, [_P, _L, _P, _P]),
+    "ps_dropout2d_masks": (C.c_int, [_P, C.POINTER(DropoutPlan), C.c_uint64, C.c_uint64, _P]),
     "ps_bgemm": (C.c_int, [_I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _L, _F, _P]),
     "ps_softmax_rows": (C.c_int, [_P, _L, _I, _P]),
     "ps_rfm_apply": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
@@ -141,6 +146,7 @@ DEBUG_PROTOTYPES = {
     "ps_debug_set_ws": (None, [C.c_int]),
     "ps_debug_set_ws2": (None, [C.c_int]),
     "ps_debug_set_halo": (None, [C.c_int]),
+    "ps_debug_set_halo_ring": (None, [C.c_int]),
     "ps_debug_set_s2split": (None, [C.c_int]),
     "ps_debug_set_wgrad_ws": (None, [C.c_int]),
     "ps_debug_set_wgrad_ws2": (None, [C.c_int]),
@@ -150,7 +156,7 @@ DEBUG_PROTOTYPES = {
     "ps_debug_set_wgrad_raster": (None, [C.c_int]),
 }
 
-DEBUG_LIB_PATH = os.path.join(HERE, "libpistoseg_hip_debug.so")
+DEBUG_LIB_PATH = os.environ.get("PISTOSEG_HIP_DEBUG_LIB") or os.path.join(HERE, "libpistoseg_hip_debug.so")  # override: A/B builds
 _lib: Optional[C.CDLL] = None
 _product: Optional[C.CDLL] = None
 _debug: Optional[C.CDLL] = None

@@ -76,5 +76,12 @@ def build(force: bool = False, verbose: bool = True, debug: bool = True) -> str:
     return path
 
 
+def build_variant(tag: str, defines, verbose: bool = True) -> str:
+    """An A/B build of the debug library with extra -D defines: pistoseg_amd/libpistoseg_hip_debug_<tag>.so (load it with
+    PISTOSEG_HIP_DEBUG_LIB=<path>).  Optimisation harness only."""
+    lib = os.path.join(HERE, f"libpistoseg_hip_debug_{tag}.so")
+    return _build_one(lib, os.path.join(HERE, "build", "ab_" + tag), ["-DPS_DEBUG_HOOKS", *[f"-D{d}" for d in defines]], False, verbose)
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))

@@ -15,6 +15,10 @@
 #include "ps_internal.h"
 #include <type_traits>
 
+#ifndef PS_READ_PER
+#define PS_READ_PER 2  // MFMAs between two fragment reads of the consumers' software pipeline (A/B builds: tools/ab_build.py)
+#endif
+
 namespace {
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_line[256];  // source of padding rows
@@ -1202,7 +1206,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
     // pinned with scheduling barriers; hipcc otherwise hoists all reads to the top).
     auto half = [&](const unsigned char* st, int coff, u32x4 (&wfn)[WI], u32x4 (&xfn)[MI], const u32x4 (&wfo)[WI], const u32x4 (&xfo)[MI],
                     bool do_mma) {
-      constexpr int NR = WI + MI, NM = MI * WI, PER = 2;
+      constexpr int NR = WI + MI, NM = MI * WI, PER = PS_READ_PER;
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         if (r < WI) wfn[r] = *reinterpret_cast<const u32x4*>(st + wfrag + r * 2048 + coff);
@@ -1273,13 +1277,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
 //     of the current one (behind that step's weights, so the in-order vmcnt lets it stay in flight for two steps); weights
 //     run two K-steps ahead.
 // ------------------------------------------------------------------------------------------------
-template <typename Tr, int TW>  // TW = 28 (maps of 224-pixel tiles: 28 / 56 / 112 wide) or 32 (256-pixel tiles: 32 / 64 / 128 wide)
+template <typename Tr, int TW, int NW = 3>  // TW = 28 (maps of 224-pixel tiles: 28 / 56 / 112 wide) or 32 (256-pixel tiles: 32 / 64 / 128 wide); NW = weight ring depth
 __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs a) {
   typedef typename Tr::elem T;
   static_assert(TW == 28 || TW == 32, "tile width");
   constexpr int BN = 128, MI = TW / 4, WI = 4, WN = 64, TR = 8;  // tile = 8 rows x TW columns = 224 | 256 pixels
   constexpr int WJ = (TW + 8 + 3) / 4, WIN_BYTES = WJ * 4 * 1024, B_BYTES = BN * 128;  // window of <= TW + 8 columns: 9 | 10 DMAs per loader wave
-  static_assert(WJ == 9 || WJ == 10, "vmcnt literals below");
+  static_assert(WJ == 9 || WJ == 10, "window DMAs per loader wave");
+  static_assert(NW >= 3 && NW <= 5 && 2 * WIN_BYTES + NW * B_BYTES <= 160 * 1024, "LDS budget");
   constexpr int W_OFF = 2 * WIN_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -1373,7 +1378,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
 #pragma unroll
       for (int j = 0; j < 4; ++j) BLDS16(rsB, dst + (j * 4 + lw) * 1024, woff[j], wk);
       --b_left;
-      b_slot = (b_slot == 2) ? 0 : b_slot + 1;
+      b_slot = (b_slot == NW - 1) ? 0 : b_slot + 1;
       if (++b_tap == 9) {
         b_tap = 0;
         if (++b_kl == a.klines) {
@@ -1384,36 +1389,43 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
       }
       return true;
     };
-    auto wait_allow = [&](int n) {  // all but the n newest DMAs of this wave have landed (n in {0, 4, WJ, WJ + 4})
-      if constexpr (WJ == 9) {
-        if (n == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-        else if (n == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      } else {
-        if (n == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-        else if (n == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // s_waitcnt vmcnt(n): all but the n newest DMAs of this wave have landed (the count needs a literal)
+    auto wait_allow = [&](int n) {
+      switch (n) {
+#define PS_VMCNT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+        PS_VMCNT_CASE(4) PS_VMCNT_CASE(8) PS_VMCNT_CASE(12) PS_VMCNT_CASE(16)
+        PS_VMCNT_CASE(9) PS_VMCNT_CASE(13) PS_VMCNT_CASE(17) PS_VMCNT_CASE(21) PS_VMCNT_CASE(25)
+        PS_VMCNT_CASE(10) PS_VMCNT_CASE(14) PS_VMCNT_CASE(18) PS_VMCNT_CASE(22) PS_VMCNT_CASE(26)
+#undef PS_VMCNT_CASE
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
       }
     };
+    // The weights run NW - 1 K-steps ahead, the next window is issued during the first step of the current one.  The pipeline is bound
+    // by (bytes in flight) / (fill latency) -- a K-step took the same ~0.7 us with 7 or 8 pixel fragments per wave (r02: 224- vs
+    // 256-pixel tiles), i.e. it waits for its operands, and with a 3-deep weight ring only 32 KiB of weights + one window were in flight
+    // per CU.  vmcnt is ONE in-order queue: to consume the weights of step gs + 1 everything issued after them may stay in flight
+    // -- the younger weight steps and, until its own third step, the window issued behind them.
+    int w_issued = 0;        // weight K-steps issued so far
+    int after_win = 0;       // weight K-steps issued after the window that is still pending
+    bool win_pending = false;
     issue_window();
-    issue_weights();
-    wait_allow(issue_weights() ? 4 : 0);
-    __builtin_amdgcn_s_barrier();  // window 0 and the weights of step 0 are visible
-    int r = 0, win_pending = 0;
+    for (int i = 0; i < NW - 1; ++i) w_issued += issue_weights() ? 1 : 0;
+    wait_allow(4 * (w_issued > 0 ? w_issued - 1 : 0));  // window 0 (oldest) and the weights of step 0 have landed
+    __builtin_amdgcn_s_barrier();
+    int r = 0;
     for (int gs = 0; gs < total_steps; ++gs) {
-      // issue order inside a step: weights of step gs+2 first, then (first step of a window) the NEXT window -- the in-order
-      // vmcnt then lets the window stay in flight until the end of the current window's third step
-      const int wA = issue_weights() ? 4 : 0;
-      int allow;
+      if (issue_weights()) { ++w_issued; ++after_win; }   // weights of step gs + NW - 1
       if (r == 0) {
-        win_pending = issue_window() ? WJ : 0;
-        allow = wA + win_pending;
-      } else if (r == 1) {
-        allow = wA + win_pending;
+        win_pending = issue_window();                     // the NEXT window, behind this step's weights
+        after_win = 0;
+      }
+      const int younger = w_issued - (gs + 2) > 0 ? w_issued - (gs + 2) : 0;  // weight steps issued after those of step gs + 1
+      int allow;
+      if (r == 2) {  // the next window must have landed as well: only the weight steps issued after it may stay in flight
+        allow = 4 * (win_pending ? (younger < after_win ? younger : after_win) : younger);
+        win_pending = false;
       } else {
-        allow = wA;
+        allow = 4 * younger + (win_pending ? WJ : 0);
       }
       wait_allow(allow);
       __builtin_amdgcn_s_barrier();
@@ -1453,7 +1465,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
     // (see conv_igemm_ws2_kernel); a pixel fragment address = centre address + scalar (window buffer, tap column) [^ K-half].
     auto half = [&](const unsigned char* wst, int wcoff, int soff, int flip, u32x4 (&wfn)[WI], u32x4 (&xfn)[MI], const u32x4 (&wfo)[WI],
                     const u32x4 (&xfo)[MI], bool do_mma) {
-      constexpr int NR = WI + MI, NM = MI * WI, PER = 2;
+      constexpr int NR = WI + MI, NM = MI * WI, PER = PS_READ_PER;
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         if (r < WI) wfn[r] = *reinterpret_cast<const u32x4*>(wst + r * 2048 + wcoff);
@@ -1480,7 +1492,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
       half(wst, coff1, soff, 64, wf1, xf1, wf0, xf0, true);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      cur = (cur == 2) ? 0 : cur + 1;
+      cur = (cur == NW - 1) ? 0 : cur + 1;
     };
     // first K-step of the tile peeled (no previous MFMAs to overlap its reads with), then tx = 1, 2, 0, 1, 2, ...
     kstep(0, true);
@@ -1506,6 +1518,7 @@ PS_TUNABLE g_use_pp = 0;       // experimental ping-pong kernel (correct, slower
 PS_TUNABLE g_use_ws = 1;       // wave-specialised (loader/consumer) kernel for big problems
 PS_TUNABLE g_use_ws2 = 1;
 PS_TUNABLE g_use_halo = 1;     // window + halo staging for 3x3 stride-1 layers (width a multiple of 28): 0 off, 1 for big 16-bit problems, 2 forced      // large-tile wave-specialised kernel: 0 off, 1 by cost model, 256 / 224 force that pixel tile
+PS_TUNABLE g_halo_ring = 3;   // weight ring depth of the halo kernel (3 | 4 | 5 stages of 16 KiB; 256-pixel tiles: <= 4)
 PS_TUNABLE g_use_3stage = 0;  // experimental 256x128 three-stage kernel: correct but slower than two 128x128 blocks per CU (r01 measurements)
 PS_TUNABLE g_ablate = 0;
 PS_TUNABLE g_supertile = 4;  // measured best of {0,4,8,16} on the wide 28x28 layers (r01)
@@ -1662,8 +1675,14 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
       b.nb = ps_num_cus();
       b.tpb = a.tpb;
       const dim3 hgrid(ps_persistent_grid((long long)b.ntm * b.ntn, b.nb, b.tpb));
-      if (tw == 28) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28>), hgrid, dim3(512), 2 * 9 * 4096 + 3 * 16384, s, b);
-      else hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32>), hgrid, dim3(512), 2 * 10 * 4096 + 3 * 16384, s, b);
+      if (tw == 28) {
+        if (g_halo_ring == 5) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 5>), hgrid, dim3(512), 2 * 9 * 4096 + 5 * 16384, s, b);
+        else if (g_halo_ring == 4) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 4>), hgrid, dim3(512), 2 * 9 * 4096 + 4 * 16384, s, b);
+        else hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 3>), hgrid, dim3(512), 2 * 9 * 4096 + 3 * 16384, s, b);
+      } else {
+        if (g_halo_ring >= 4) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32, 4>), hgrid, dim3(512), 2 * 10 * 4096 + 4 * 16384, s, b);
+        else hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32, 3>), hgrid, dim3(512), 2 * 10 * 4096 + 3 * 16384, s, b);
+      }
       PS_CHECK_LAUNCH("conv_igemm_halo");
       return PS_OK;
     }
@@ -1707,6 +1726,7 @@ extern "C" void ps_debug_set_pp(int v) { g_use_pp = v; }
 extern "C" void ps_debug_set_ws(int v) { g_use_ws = v; }
 extern "C" void ps_debug_set_ws2(int v) { g_use_ws2 = v; }
 extern "C" void ps_debug_set_halo(int v) { g_use_halo = v; }
+extern "C" void ps_debug_set_halo_ring(int v) { g_halo_ring = v; }
 extern "C" void ps_debug_set_supertile(int v) { g_supertile = v; }
 #endif
 

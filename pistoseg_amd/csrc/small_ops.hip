@@ -891,9 +891,59 @@ extern "C" int ps_copy_rows(const void* src, int64_t src_ld_bytes, void* dst, in
   return PS_OK;
 }
 
+namespace {
+// ------------------------------------------------------------------------------------------------
+// Dropout2d multipliers for a whole training step in ONE launch: a flat f32 buffer of up to 8 segments (one per Dropout2d of the
+// net: [n, channels] each), element e of segment k = (u >= p_k) / (1 - p_k) with u uniform from Philox4x32-10 keyed by the seed,
+// counter = (e / 4, offset).  replaces: the Bernoulli draw of nn.Dropout2d (resnet38d.py:63,67,85,90; revise_net.py:11,50) --
+// the multiply itself is fused into the conv epilogues.  (No RNG parity with torch is possible or claimed: tests inject masks.)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+__global__ __launch_bounds__(256) void dropout2d_masks_kernel(float* __restrict__ out, ps_dropout_plan plan, uint64_t seed, uint64_t offset) {
+  const long long total = plan.end[plan.nseg - 1];
+  const long long q = (long long)blockIdx.x * 256 + threadIdx.x;  // one Philox block = 4 elements
+  if (q * 4 >= total) return;
+  uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long long e = q * 4 + i;
+    if (e >= total) break;
+    int k = 0;
+    while (k < plan.nseg - 1 && e >= plan.end[k]) ++k;
+    const float u = (float)(c[i] >> 8) * (1.0f / 16777216.0f);  // [0, 1) on a 24-bit grid
+    const float p = plan.p[k];
+    out[e] = u >= p ? 1.0f / (1.0f - p) : 0.0f;
+  }
+}
+}  // namespace
+
+extern "C" int ps_dropout2d_masks(float* out, const ps_dropout_plan* plan, uint64_t seed, uint64_t offset, void* stream) {
+  PS_REQUIRE(out && plan && plan->nseg >= 1 && plan->nseg <= 8, "dropout2d_masks: bad argument");
+  long long prev = 0;
+  for (int k = 0; k < plan->nseg; ++k) {
+    PS_REQUIRE(plan->end[k] >= prev && plan->p[k] >= 0.f && plan->p[k] < 1.f, "dropout2d_masks: segment %d: end %lld, p %f", k, (long long)plan->end[k],
+               (double)plan->p[k]);
+    prev = plan->end[k];
+  }
+  if (prev == 0) return PS_OK;
+  hipLaunchKernelGGL(dropout2d_masks_kernel, dim3((unsigned)((prev + 1023) / 1024)), dim3(256), 0, static_cast<hipStream_t>(stream), out, *plan, seed, offset);
+  PS_CHECK_LAUNCH("dropout2d_masks");
+  return PS_OK;
+}
+
+namespace {
+
 // Testing hook: `blocks` workgroups of 256 threads that each hold a CU slot for `usec` microseconds (spin on the 100 MHz real-time
 // counter) -- stands in for a communication kernel running beside the persistent conv kernels (tools/hog_probe.py).
-namespace {
 __global__ __launch_bounds__(256) void hog_kernel(long long ticks, int* sink) {
   extern __shared__ int hog_lds[];  // dynamic LDS only serves to keep other workgroups off this CU
   if (sink) hog_lds[threadIdx.x] = 0;

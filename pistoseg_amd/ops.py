@@ -374,6 +374,27 @@ def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, p_shadow: Optional[Te
     )
 
 
+def dropout2d_masks(segments, n: int, device, seed: int, offset: int):
+    """segments: [(name, channels, p)] -> {name: [n, channels] f32 multipliers (0 or 1/(1-p))}, all drawn by ONE launch into one flat
+    buffer (Philox4x32-10 keyed by (seed, offset); nn.Dropout2d's Bernoulli draw, resnet38d.py:63,67,85,90, revise_net.py:11,50)."""
+    assert 1 <= len(segments) <= 8
+    plan = _lib.DropoutPlan()
+    plan.nseg = len(segments)
+    off = 0
+    for k, (_, c, p) in enumerate(segments):
+        off += n * c
+        plan.end[k], plan.p[k] = off, p
+    flat = torch.empty(off, device=device, dtype=torch.float32)
+    _require_gpu(flat)
+    lib = _lib.load()
+    _lib.check(lib.ps_dropout2d_masks(flat.data_ptr(), C.byref(plan), seed & (2**64 - 1), offset & (2**64 - 1), _stream()), "ps_dropout2d_masks")
+    out, lo = {}, 0
+    for name, c, _ in segments:
+        out[name] = flat[lo:lo + n * c].view(n, c)
+        lo += n * c
+    return out
+
+
 def nonfinite_count(g: Tensor) -> Tensor:
     """1-element int32 device tensor: number of inf/nan entries of the f32 tensor g."""
     _require_gpu(g)

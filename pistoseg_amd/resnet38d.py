@@ -124,6 +124,7 @@ class Net(nn.Module):
         self._weights_epoch = 0           # bumped by code that rewrites parameter memory behind torch's back
         self._bf16_shadow: Dict[str, Tensor] = {}  # param name -> bf16 W_fwd view kept fresh by the fused optimiser
         self._shadow_version: Dict[str, int] = {}  # param name -> the parameter's torch version the shadow was last derived at
+        self._drop_seed, self._drop_calls = None, 0  # Philox key / per-call counter of the Dropout2d masks (sample_dropout)
         self._wd_plan: Dict[str, Tuple] = {}       # cache key -> (deps, [(src fn, dst view, cout, taps, cin)]): see refresh_dgrad_weights
         self.train(True)  # apply the freezing rules from the start (the reference's scripts always call train())
 
@@ -287,17 +288,24 @@ class Net(nn.Module):
 
         return self._cached("bn:" + key, (bn.weight, bn.bias, bn.running_mean, bn.running_var), make, raw_pointer_updates=False)
 
-    def sample_dropout(self, n: int, device) -> Dict[str, Tensor]:
-        """Per-(sample, channel) Dropout2d multipliers for a training forward (resnet38d.py:63,67,85,90)."""
-        out = {}
+    def dropout_segments(self):
+        """(name, channels, p) of every Dropout2d of the net (resnet38d.py:63,67,85,90), in a fixed order."""
+        segs = []
         for name, kind, cin, cmid, cout, stride, fdil, dil, p in self.units:
-            if kind != "bot":
-                continue
-            for tag, c in (("dropout_2b1", cout // 4), ("dropout_2b2", cout // 2)):
-                if p > 0:
-                    keep = torch.rand((n, c), device=device) >= p
-                    out[f"{name}.{tag}"] = keep.to(torch.float32) / (1.0 - p)
-        return out
+            if kind == "bot" and p > 0:
+                segs += [(f"{name}.dropout_2b1", cout // 4, p), (f"{name}.dropout_2b2", cout // 2, p)]
+        return segs
+
+    def sample_dropout(self, n: int, device) -> Dict[str, Tensor]:
+        """Per-(sample, channel) Dropout2d multipliers for a training forward: one HIP launch for all of them (Philox keyed by torch's
+        seed at first use + a per-call counter, so `torch.manual_seed` makes training runs repeatable)."""
+        segs = self.dropout_segments()
+        if not segs:
+            return {}
+        if self._drop_seed is None:
+            self._drop_seed = int(torch.initial_seed())
+        self._drop_calls += 1
+        return ops.dropout2d_masks(segs, n, device, self._drop_seed, self._drop_calls)
 
     def unit_specs(self, name, kind, cin, cmid, cout, stride, fdil, dil):
         if kind == "res":

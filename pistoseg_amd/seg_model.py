@@ -30,11 +30,8 @@ class ResNet38dSeg(resnet38d.Net):
         self.classes = classes
         self.train(True)
 
-    def sample_dropout(self, n: int, device) -> Dict[str, Tensor]:
-        out = super().sample_dropout(n, device)
-        keep = torch.rand((n, 4096), device=device) >= 0.5
-        out["dropout7"] = keep.to(torch.float32) * 2.0
-        return out
+    def dropout_segments(self):
+        return super().dropout_segments() + [("dropout7", 4096, 0.5)]  # revise_net.py:11,50
 
     # ------------------------------------------------------------------ head
     def head_forward(self, conv6: Tensor, drop7: Optional[Tensor], out_hw) -> (Tensor, Tensor):

@@ -23,6 +23,7 @@ def debug_library():
     _lib.use_debug_library(False)
 
 
+HALO_RING_DEFAULT = 3  # library default of ps_debug_set_halo_ring
 WS2_DEFAULT = 1  # library default of ps_debug_set_ws2 (restored after tests that force a variant)
 F32_TOL = 1e-4
 BF16_TOL = 1.2e-2
@@ -463,6 +464,18 @@ def test_conv_pipelined_kernels_are_bit_identical_to_two_stage(case, dtype):
     (1, 128, 128, 64, 128, 1), (1, 40, 96, 128, 128, 2), (3, 20, 64, 64, 256, 4), (1, 32, 256, 64, 128, 1),
 ])
 def test_conv_halo_window_kernel(case, dtype):
+    _halo_case(case, dtype, 3)
+
+
+@pytest.mark.parametrize("ring", [4, 5])
+@pytest.mark.parametrize("case", [(3, 28, 28, 256, 128, 4), (7, 28, 28, 192, 384, 2), (2, 56, 56, 64, 128, 1), (1, 12, 56, 64, 256, 4),
+                                  (5, 32, 32, 192, 384, 4), (3, 20, 64, 64, 256, 4)])
+def test_conv_halo_weight_ring_depths(case, ring):
+    """The halo kernel with its weights 3 / 4 K-steps ahead (ring of 4 / 5 stages; 256-pixel tiles cap at 4): same results."""
+    _halo_case(case, torch.bfloat16, ring)
+
+
+def _halo_case(case, dtype, ring):
     """conv_igemm_halo_kernel (pixel window + halo staged once per tap row, K order (K-line, ty, tx)) forced on small problems:
     forward with the full epilogue and the data gradient against the CPU, plus agreement with the gathered-tile kernels."""
     from pistoseg_amd import _lib, ops
@@ -495,11 +508,13 @@ def test_conv_halo_window_kernel(case, dtype):
 
     try:
         lib.ps_debug_set_halo(2)
+        lib.ps_debug_set_halo_ring(ring)
         got = [run() for _ in range(2)]
         lib.ps_debug_set_halo(0)
         other = run()
     finally:
         lib.ps_debug_set_halo(1)
+        lib.ps_debug_set_halo_ring(HALO_RING_DEFAULT)
     refs = (nhwc((y + res).detach()), nhwc(act.detach()), nhwc(x.grad))
     for trial in got:
         for a_, r_, o_ in zip(trial, refs, other):
@@ -772,3 +787,37 @@ def test_stride2_dgrad_parity_class_launches_are_bit_identical(case, dtype):
     wt = wd.float().cpu().permute(3, 0, 1, 2).contiguous()  # [cin][kh][kw][cout] -> OIHW of the forward conv
     ref = torch.nn.grad.conv2d_input((n, cin, h, w), wt, q(gy.float().cpu()).permute(0, 3, 1, 2), stride=2, padding=1)
     assert rel_err(outs[1][1].float().cpu().permute(0, 3, 1, 2), ref) < TOL[dtype]
+
+
+def test_dropout2d_masks_kernel():
+    """One launch draws every Dropout2d mask of a step: values in {0, 1/(1-p)}, keep rate 1-p per segment, repeatable per (seed, offset),
+    fresh per offset; the model's sample_dropout hands out views of that one buffer under the names the plans use."""
+    from pistoseg_amd import ops
+    from pistoseg_amd.seg_model import ResNet38dSeg
+
+    D = dev()
+    segs = [("a", 512, 0.3), ("b", 1024, 0.3), ("c", 4096, 0.5), ("d", 7, 0.0)]
+    n = 64
+    m1 = ops.dropout2d_masks(segs, n, D, seed=1234, offset=1)
+    m1b = ops.dropout2d_masks(segs, n, D, seed=1234, offset=1)
+    m2 = ops.dropout2d_masks(segs, n, D, seed=1234, offset=2)
+    m3 = ops.dropout2d_masks(segs, n, D, seed=1235, offset=1)
+    for name, c, p in segs:
+        t = m1[name]
+        assert tuple(t.shape) == (n, c) and t.dtype == torch.float32
+        vals = torch.unique(t).cpu().tolist()
+        assert all(abs(v) < 1e-12 or abs(v - 1.0 / (1.0 - p)) < 1e-6 for v in vals), (name, vals)
+        keep = float((t > 0).float().mean())
+        assert abs(keep - (1.0 - p)) < 4.0 * (p * (1 - p) / (n * c)) ** 0.5 + 1e-9, (name, keep)
+        assert torch.equal(t, m1b[name])
+        if p > 0:
+            assert not torch.equal(t, m2[name]) and not torch.equal(t, m3[name])
+    # rows (samples) are not copies of each other, channels neither
+    assert not torch.equal(m1["c"][0], m1["c"][1]) and not torch.equal(m1["c"][:, 0], m1["c"][:, 1])
+    model = ResNet38dSeg(3, "bf16")
+    torch.manual_seed(7)
+    d1 = model.sample_dropout(4, D)
+    assert sorted(d1) == ["b6.dropout_2b1", "b6.dropout_2b2", "b7.dropout_2b1", "b7.dropout_2b2", "dropout7"]
+    assert tuple(d1["b7.dropout_2b2"].shape) == (4, 2048) and tuple(d1["dropout7"].shape) == (4, 4096)
+    d2 = model.sample_dropout(4, D)
+    assert not torch.equal(d1["dropout7"], d2["dropout7"])

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--what", default="fwd,dgrad,wgrad")
     ap.add_argument("--variants", default="3stage=0,3stage=1")
     ap.add_argument("--layers", default="")
+    ap.add_argument("--halo-ring", type=int, default=3)
     ap.add_argument("--epi", default="raw", help="raw: store only | full: fwd = +residual -> raw + BN/ReLU out, dgrad = ReLU mask + add1 -> out")
     args = ap.parse_args()
     lib = _lib.use_debug_library()  # the ps_debug_* switches live in libpistoseg_hip_debug.so only
@@ -72,6 +73,7 @@ def main():
                     lib.ps_debug_set_ws(1)
                     lib.ps_debug_set_ws2(1)
                     lib.ps_debug_set_halo(1)
+                    lib.ps_debug_set_halo_ring(args.halo_ring)
                     lib.ps_debug_set_ablate(0)
                     lib.ps_debug_set_wgrad_ws2(1)
                     lib.ps_debug_set_wgrad_ablate(0)

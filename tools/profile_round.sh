@@ -1,15 +1,36 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>     e.g. r01e
+# usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>     e.g. r02b
 # (the profiled passes run with --no-overlap: weight gradients on the launch stream, so that every kernel's duration is exclusive
 #  and comparable with bench.py's live per-kernel events; the un-profiled line is the default, overlapped, run)
 # writes gpurun_out/prof_<tag>/..., gpurun_out/<tag>_*.json|csv|txt (copy into profiles/ afterwards)
+# PMC counters are collected in their OWN passes with --kernel-trace only (never with --stats / trace domains).
 set -o pipefail
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-overlap > gpurun_out/${tag}_bench_profiled.json 2> gpurun_out/${tag}_bench_profiled.err &&
-cp $(find gpurun_out/prof_${tag} -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_kernel_stats.csv &&
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_${tag}_fetch -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-infer --no-overlap > /dev/null 2>&1 &&
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_${tag}_write -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-infer --no-overlap > /dev/null 2>&1 &&
-python tools/pmc_traffic.py gpurun_out/pmc_${tag}_fetch gpurun_out/pmc_${tag}_write gpurun_out/${tag}_pmc_hbm_traffic.json &&
+PMC_ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-infer --no-overlap"
+# --- BASELINE configs[1]: bs=64 bf16 (the headline)
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-overlap > gpurun_out/${tag}_bench_train_bs64_bf16.json 2> gpurun_out/${tag}_bench_profiled.err &&
+cp $(find gpurun_out/prof_${tag} -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_bench_train_bs64_bf16_kernel_stats.csv &&
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_${tag}_fetch -- python bench.py $PMC_ARGS > /dev/null 2>&1 &&
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_${tag}_write -- python bench.py $PMC_ARGS > /dev/null 2>&1 &&
+python tools/pmc_traffic.py gpurun_out/pmc_${tag}_fetch gpurun_out/pmc_${tag}_write gpurun_out/${tag}_pmc_hbm_traffic.json > /dev/null &&
+rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_${tag}_mfma_1 -- python bench.py $PMC_ARGS > /dev/null 2>&1 &&
+python tools/pmc_mfma_report.py gpurun_out/pmc_${tag}_mfma_1 > gpurun_out/${tag}_pmc_mfma_busy_train_step.txt &&
 python bench.py --steps 10 --warmup 3 > gpurun_out/${tag}_bench_unprofiled.json 2> gpurun_out/${tag}_bench_unprofiled.err &&
-python tools/step_profile.py > gpurun_out/${tag}_step_profile_per_launch.txt 2>&1
+python tools/step_profile.py > gpurun_out/${tag}_step_profile_per_launch.txt 2>&1 &&
+# --- the PARITY path: fp32 storage, exact-f32 MFMA (157 TFLOP/s matrix peak)
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_fp32 -- python bench.py --precision fp32 --steps 3 --warmup 1 --no-cpu-baseline --no-overlap > gpurun_out/${tag}_bench_fp32_parity_path.json 2>> gpurun_out/${tag}_bench_profiled.err &&
+cp $(find gpurun_out/prof_${tag}_fp32 -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_bench_fp32_parity_path_kernel_stats.csv &&
+# --- BASELINE configs[4]: BCSS 4-class, fp16 MFMA path, bs=128 -- bench line + HBM / MFMA counters
+CFG5="--precision fp16 --classes 4 --batch 128"
+python bench.py $CFG5 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_cfg5_fp16_bs128.json 2>> gpurun_out/${tag}_bench_profiled.err &&
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_${tag}_c5_fetch -- python bench.py $CFG5 $PMC_ARGS > /dev/null 2>&1 &&
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_${tag}_c5_write -- python bench.py $CFG5 $PMC_ARGS > /dev/null 2>&1 &&
+python tools/pmc_traffic.py gpurun_out/pmc_${tag}_c5_fetch gpurun_out/pmc_${tag}_c5_write gpurun_out/${tag}_cfg5_fp16_bs128_pmc_hbm_traffic.json > /dev/null &&
+rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_${tag}_c5_mfma_1 -- python bench.py $CFG5 $PMC_ARGS > /dev/null 2>&1 &&
+python tools/pmc_mfma_report.py gpurun_out/pmc_${tag}_c5_mfma_1 > gpurun_out/${tag}_cfg5_fp16_bs128_pmc_mfma_busy.txt &&
+# --- other configs: [3] RFM stage 3, [2] stage-2 inference (with and without d4 TTA), S=256
+python bench.py --workload rfm --batch 32 --steps 8 --warmup 3 > gpurun_out/${tag}_bench_cfg4_rfm_bs32.json 2>> gpurun_out/${tag}_bench_profiled.err &&
+python bench.py --workload infer2 --steps 20 > gpurun_out/${tag}_bench_cfg3_infer2.json 2>> gpurun_out/${tag}_bench_profiled.err &&
+python bench.py --workload infer2 --steps 20 --tta > gpurun_out/${tag}_bench_cfg3_infer2_tta.json 2>> gpurun_out/${tag}_bench_profiled.err &&
+python bench.py --tile 256 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_tile256.json 2>> gpurun_out/${tag}_bench_profiled.err
