@@ -911,6 +911,7 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_ws_kernel(const IgemmArgs a
 
   if (wave >= 4) {
     // ================= loader =================
+    PS_LOADER_SETPRIO();
     const int lw = wave - 4;
     const int srow = lane >> 3;
     const int chunk_off = ((lane & 7) ^ srow) << 4;
@@ -1081,6 +1082,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
 
   if (wave >= 4) {
     // ================= loader =================
+    PS_LOADER_SETPRIO();
     const int lw = wave - 4;
     const int srow = lane >> 3;
     const int chunk_off = ((lane & 7) ^ srow) << 4;
@@ -1302,6 +1304,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
 
   if (wave >= 4) {
     // ================= loader =================
+    PS_LOADER_SETPRIO();
     const int lw = wave - 4;
     const int srow = lane >> 3;              // window row this lane stages (of every window column)
     const int chunk_off = ((lane & 7) ^ srow) << 4;

@@ -31,6 +31,16 @@ static inline unsigned ps_persistent_grid(long long nitems, int nb, int tpb) {
   return (unsigned)(full * nb + (rem < nb ? rem : nb));
 }
 
+// Static wave priority of the LOADER waves of the wave-specialised kernels (A/B builds: -DPS_LOADER_PRIO=n).
+#ifndef PS_LOADER_PRIO
+#define PS_LOADER_PRIO 0
+#endif
+#if PS_LOADER_PRIO > 0
+#define PS_LOADER_SETPRIO() __builtin_amdgcn_s_setprio(PS_LOADER_PRIO)
+#else
+#define PS_LOADER_SETPRIO() ((void)0)
+#endif
+
 #define PS_REQUIRE(cond, ...)            \
   do {                                   \
     if (!(cond)) {                       \

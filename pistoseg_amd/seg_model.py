@@ -108,11 +108,29 @@ class _SegFunction(torch.autograd.Function):
         return (None, None) + tuple(grads[n].permute(0, 3, 1, 2) for n in ctx.names)
 
 
-def create_model(arch: str, encoder_name: Optional[str] = None, in_channels: int = 3, classes: int = 3, precision: str = "bf16", **_):
+def create_model(arch: str, encoder_name: Optional[str] = None, in_channels: int = 3, classes: int = 3, precision: str = "bf16", **kw):
     """Plug point mirroring `smp.create_model(args.model, encoder_name=args.encoder, in_channels=3,
-    classes=args.num_classes, ...)` (models/segmentation_module.py:72-81).  Only the in-tree ResNet38-d is
-    provided; smp architectures (UnetPlusPlus/efficientnet) are third-party and out of scope."""
+    classes=args.num_classes, ...)` (models/segmentation_module.py:72-81).
+
+    `--model ResNet38d` gives the in-tree MI355X model.  Any other name is an smp architecture (run.sh's defaults are
+    UnetPlusPlus / efficientnet-b0 / -b3: third-party bodies, out of this hot path's scope): it is handed to
+    `segmentation_models_pytorch.create_model` unchanged when that package is installed, so an unmodified run.sh keeps working on
+    PyTorch-ROCm eager kernels; without smp it is an error -- or, with PISTOSEG_SUBSTITUTE_MODEL=1, the ResNet38-d model stands in."""
+    import os
+
     if arch.lower() in ("resnet38d", "resnet38-d", "resnet38d_seg"):
         assert in_channels == 3
         return ResNet38dSeg(classes=classes, precision=precision)
-    raise ValueError(f"pistoseg_amd provides --model ResNet38d only (got {arch!r}); smp models are not part of the hot path")
+    try:
+        import segmentation_models_pytorch as smp
+    except ImportError:
+        smp = None
+    if smp is not None:
+        return smp.create_model(arch, encoder_name=encoder_name, in_channels=in_channels, classes=classes, **kw)
+    if os.environ.get("PISTOSEG_SUBSTITUTE_MODEL") == "1":
+        import warnings
+
+        warnings.warn(f"segmentation_models_pytorch is not installed: --model {arch} / --encoder {encoder_name} replaced by the ResNet38-d model")
+        return ResNet38dSeg(classes=classes, precision=precision)
+    raise ValueError(f"--model {arch!r} is an smp architecture and segmentation_models_pytorch is not installed; pistoseg_amd itself provides "
+                     f"--model ResNet38d (set PISTOSEG_SUBSTITUTE_MODEL=1 to let it stand in)")

@@ -59,8 +59,9 @@ class _Shell(LightningModule):
         self.train_iou = mIoUMask(num_classes=args.num_classes)
         self.valid_iou = mIoUMask(num_classes=args.num_classes)
         self.test_iou = mIoUMask(num_classes=args.num_classes)
+        extra = {"decoder_attention_type": "scse"} if "Unet" in args.model else {}  # segmentation_module.py:72-77 (smp models only)
         self.model = create_model(args.model, encoder_name=getattr(args, "encoder", None), in_channels=3, classes=args.num_classes,
-                                  precision=getattr(args, "precision", "bf16"))
+                                  precision=getattr(args, "precision", "bf16"), **extra)
         if getattr(args, "tta", False):  # mosaic_module.py:75-76 / segmentation_module.py keep a factory, applied by the scripts
             self.tta_wrapper = partial(SegmentationTTAWrapper, merge_mode="mean")
         self.save_hyperparameters()

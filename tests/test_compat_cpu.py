@@ -41,3 +41,27 @@ def test_utils_shim_overlays_a_utils_module_further_down_the_path(tmp_path):
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "pistoseg_amd", "compat"), str(tmp_path)]))
     r = subprocess.run([sys.executable, "-c", code], env=env, cwd="/tmp", capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def test_create_model_plug_point_handles_smp_names():
+    """run.sh's default model names are smp architectures: without smp they are refused with a pointer to --model ResNet38d, or replaced
+    when PISTOSEG_SUBSTITUTE_MODEL=1; `ResNet38d` always gives the in-tree model."""
+    import importlib.util
+
+    import pytest
+
+    from pistoseg_amd.seg_model import ResNet38dSeg, create_model
+
+    assert isinstance(create_model("ResNet38d", encoder_name="resnet38d", classes=4), ResNet38dSeg)
+    if importlib.util.find_spec("segmentation_models_pytorch") is not None:
+        pytest.skip("smp installed: names are delegated to it")
+    os.environ.pop("PISTOSEG_SUBSTITUTE_MODEL", None)
+    with pytest.raises(ValueError, match="ResNet38d"):
+        create_model("UnetPlusPlus", encoder_name="efficientnet-b0", classes=3, decoder_attention_type="scse")
+    os.environ["PISTOSEG_SUBSTITUTE_MODEL"] = "1"
+    try:
+        with pytest.warns(UserWarning):
+            m = create_model("UnetPlusPlus", encoder_name="efficientnet-b0", classes=3, decoder_attention_type="scse")
+        assert isinstance(m, ResNet38dSeg) and m.classes == 3
+    finally:
+        os.environ.pop("PISTOSEG_SUBSTITUTE_MODEL", None)
