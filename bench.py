@@ -59,6 +59,7 @@ def parse():
                          "stage-2 loop (infer_pseudo_masks.py:116-154) over this rank's shard of --steps x --batch tiles")
     ap.add_argument("--tta", action="store_true", help="infer2: d4 test-time augmentation (8 views per tile) as infer_pseudo_masks.py:96")
     ap.add_argument("--pack", default=None, help="infer2: write logits_32x32 of every rank into this ONE packed file")
+    ap.add_argument("--streams", type=int, default=2, help="infer2: HIP streams that consecutive (independent) batches alternate between")
     return ap.parse_args()
 
 
@@ -280,7 +281,7 @@ def infer2_bench(args, world, rank, dev, dist_on):
 
     def one_pass():
         return infer.infer_pseudo_masks(model, _Shard(shard, total), _Shard(lab.to(dev), total), _Shard(tissue, total), batch_size=n,
-                                        rank=rank, world=world, tta=args.tta, writer=writer)
+                                        rank=rank, world=world, tta=args.tta, writer=writer, streams=args.streams)
 
     for _ in range(max(1, min(args.warmup, 2))):
         one_pass()
@@ -317,7 +318,7 @@ def infer2_bench(args, world, rank, dev, dist_on):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2]: infer_pseudo_masks.py stage-2 loop over {total} synthetic tiles sharded by contiguous ranges, "
                                    f"{c}-class ResNet38-d seg model, forward{' x8 d4 views' if args.tta else ''} + 32x32 downsample + mask/entropy",
-                       "per_gpu_batch": n, "tiles_per_gpu": per_rank, "tile": s, "parallelism": f"dp{world}", "packed_output": bool(args.pack)},
+                       "per_gpu_batch": n, "tiles_per_gpu": per_rank, "tile": s, "parallelism": f"dp{world}", "packed_output": bool(args.pack), "streams": args.streams},
             "infer_conv_tflops_per_gpu": round(value / world * views * GFLOP_FWD_PER_TILE * (s / 224.0) ** 2 / 1e3, 1),
             "roofline_tail": {"bound": "hbm", "kernel": "bilinear_fwd(32x32) + argmax_mask(fill, entropy)", "achieved": round(tail_bytes / (tail * 1e-3) / 1e9, 1),
                               "peak": 8000.0, "unit": "GB/s", "frac": round(tail_bytes / (tail * 1e-3) / 8e12, 4), "bytes_per_batch": tail_bytes,

@@ -33,13 +33,16 @@ def get_mask_pred_and_entropy(logits: Tensor, tissue: Optional[Tensor], patch_la
 
 @torch.no_grad()
 def infer_pseudo_masks(model, images: Tensor, patch_label: Tensor, tissue: Optional[Tensor] = None, batch_size: int = 64,
-                       rank: int = 0, world: int = 1, tta: bool = False, writer=None):
+                       rank: int = 0, world: int = 1, tta: bool = False, writer=None, streams: int = 1):
     """Stage 2 (infer_pseudo_masks.py:116-154) over this rank's contiguous shard of `images` ([T,3,H,W], host or device): per batch
     forward (x8 d4 views when tta, wrapped exactly where the reference wraps: :96) -> `interpolate_tensor` to 32x32 (:126) ->
     `get_mask_pred_and_entropy` (:137).  Returns (lo, hi, logits_32x32 [t,C,32,32], mask uint8 [t,H,W], entropy [t,H,W]); no
     collective on the data path.  `writer` (packed.PackedTilesWriter over ALL T tiles) receives this rank's rows [lo, hi) of the
     32x32 logits -- the reference's one `logits_32x32/<name>.pt` per tile (:127) as rows of one file -- in a single device->host
-    copy after the loop, so the launch stream never waits for the host inside the loop."""
+    copy after the loop, so the launch stream never waits for the host inside the loop.
+    streams=2: consecutive batches alternate between two HIP streams.  Batches are independent, and a persistent conv launch whose tile
+    count is not a multiple of the CU count (512-channel layers at bs=64: 3.5 rounds) leaves half the chip idle in its last round --
+    the other batch's launch takes those CUs (the same effect the training backward gets from its weight-gradient stream)."""
     dev = next(model.parameters()).device
     if tta:
         from .tta import SegmentationTTAWrapper
@@ -48,19 +51,40 @@ def infer_pseudo_masks(model, images: Tensor, patch_label: Tensor, tissue: Optio
     lo, hi = shard_range(images.shape[0], rank, world)
     small, masks, ents = [], [], []
     model.eval()
-    for s in range(lo, hi, batch_size):
+    main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+    side = [main] + [torch.cuda.Stream(device=dev) for _ in range(max(1, streams) - 1)] if main is not None else [None]
+    for st in side[1:]:
+        st.wait_stream(main)  # inputs produced on the caller's stream
+    for bi, s in enumerate(range(lo, hi, batch_size)):
         e = min(hi, s + batch_size)
-        x = images[s:e].to(dev, non_blocking=True)
-        logits = model(x)
-        small.append(interpolate_tensor(logits))
-        m, en = get_mask_pred_and_entropy(logits, None if tissue is None else tissue[s:e].to(dev), patch_label[s:e].to(dev))
-        masks.append(m)
-        ents.append(en)
+        st = side[bi % len(side)]
+        ctx = torch.cuda.stream(st) if st is not None and st is not main else _NullCtx()
+        with ctx:
+            x = images[s:e].to(dev, non_blocking=True)
+            logits = model(x)
+            small.append(interpolate_tensor(logits))
+            m, en = get_mask_pred_and_entropy(logits, None if tissue is None else tissue[s:e].to(dev), patch_label[s:e].to(dev))
+            masks.append(m)
+            ents.append(en)
+            if st is not None and st is not main:
+                x.record_stream(st)                  # possibly a view of the caller's tensor (allocated on the caller's stream)
+                for t in (small[-1], m, en):
+                    t.record_stream(main)            # allocated on `st`, consumed by the concatenation on the caller's stream
+    for st in side[1:]:
+        main.wait_stream(st)
     cat = lambda xs: torch.cat(xs, 0) if xs else None
     small = cat(small)
     if writer is not None and small is not None:
         writer.write_rows(lo, small)
     return lo, hi, small, cat(masks), cat(ents)
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 @torch.no_grad()

@@ -29,8 +29,8 @@ def oracle_stage2(sd, x, tissue, labels, tta):
     return logits, torch.stack(small), np.stack(masks), np.stack(ents)
 
 
-@pytest.mark.parametrize("tta,world", [(False, 2), (False, 3), (True, 2)])
-def test_infer_pseudo_masks_sharded_matches_oracle_composition(tmp_path, tta, world):
+@pytest.mark.parametrize("tta,world,streams", [(False, 2, 1), (False, 3, 2), (True, 2, 2)])
+def test_infer_pseudo_masks_sharded_matches_oracle_composition(tmp_path, tta, world, streams):
     from pistoseg_amd import infer
     from pistoseg_amd.packed import PackedTiles, PackedTilesWriter
     from pistoseg_amd.seg_model import ResNet38dSeg
@@ -52,7 +52,7 @@ def test_infer_pseudo_masks_sharded_matches_oracle_composition(tmp_path, tta, wo
     covered = []
     for rank in range(world):  # every rank's call, one after the other on the test GPU; nothing is exchanged between them
         writer = PackedTilesWriter(pack, names, (c, 32, 32), shared=True)
-        lo, hi, small, masks, ents = infer.infer_pseudo_masks(model, x, labels, tissue, batch_size=2, rank=rank, world=world, tta=tta, writer=writer)
+        lo, hi, small, masks, ents = infer.infer_pseudo_masks(model, x, labels, tissue, batch_size=2, rank=rank, world=world, tta=tta, writer=writer, streams=streams)
         writer.close()
         covered.append((lo, hi))
         if hi > lo:
@@ -89,3 +89,31 @@ def test_infer_pseudo_masks_sharded_matches_oracle_composition(tmp_path, tta, wo
     ent_err = max(float(np.abs(got_ent[i] - ref_ent[i]).max()) for i in range(T))
     assert ent_err < 2e-3, ent_err
     print(f"[parity] stage 2 (tta={tta}, {world} shards): logits_32 err {err:.2e} (range {scale:.2f}), entropy err {ent_err:.2e}")
+
+
+def test_packed_tiles_to_device_and_stage3_indexing(tmp_path):
+    """SURVEY 8f row 3 on the device: a pack written from device tensors (stage-2 logits, f32) and one converted from float64 `.npy` CAMs
+    are brought into HBM whole (`to_device`) and indexed with a batch's tile indices, as stage 3 consumes them -- values bit-identical
+    to what RefineDataset's per-file loaders return (revise_pseudo_labels.py:57-60: torch.load(...), torch.from_numpy(cam).float())."""
+    from pistoseg_amd.packed import PackedTiles, PackedTilesWriter, pack_cam_dir
+
+    g = torch.Generator().manual_seed(9)
+    names = [f"img{i:03d}-[1, 0, 1]" for i in range(13)]
+    logits = torch.randn(13, 3, 32, 32, generator=g)
+    w = PackedTilesWriter(str(tmp_path / "logits.pack"), names, (3, 32, 32))
+    w.write_rows(0, logits[:7].to(D))       # device tensors, as infer_pseudo_masks hands them over
+    w.write_rows(7, logits[7:].to(D))
+    w.close()
+    cam_dir = tmp_path / "cam"
+    cam_dir.mkdir()
+    cams = torch.randn(13, 3, 32, 32, generator=g, dtype=torch.float64)
+    for n_, c_ in zip(names, cams):
+        np.save(cam_dir / (n_ + ".npy"), c_.numpy())
+    pc = pack_cam_dir(str(cam_dir), str(tmp_path / "cam.pack"))
+    pl = PackedTiles(str(tmp_path / "logits.pack"))
+    dl, dc = pl.to_device(D), pc.to_device(D)
+    assert dl.is_cuda and dl.dtype == torch.float32 and tuple(dl.shape) == (13, 3, 32, 32)
+    idx = torch.tensor([pl.index[n_] for n_ in (names[5], names[0], names[12])], device=D)
+    assert torch.equal(dl[idx].cpu(), logits[[5, 0, 12]])
+    order = [pc.index[n_] for n_ in names]
+    assert torch.equal(dc.cpu()[order], cams.to(torch.float32))  # the float64 -> float32 cast of the reference's loader, bit for bit
