@@ -59,7 +59,7 @@ def parse():
                          "stage-2 loop (infer_pseudo_masks.py:116-154) over this rank's shard of --steps x --batch tiles")
     ap.add_argument("--tta", action="store_true", help="infer2: d4 test-time augmentation (8 views per tile) as infer_pseudo_masks.py:96")
     ap.add_argument("--pack", default=None, help="infer2: write logits_32x32 of every rank into this ONE packed file")
-    ap.add_argument("--streams", type=int, default=2, help="infer2: HIP streams that consecutive (independent) batches alternate between")
+    ap.add_argument("--streams", type=int, default=1, help="infer2: HIP streams that consecutive (independent) batches alternate between")
     return ap.parse_args()
 
 

@@ -40,9 +40,10 @@ def infer_pseudo_masks(model, images: Tensor, patch_label: Tensor, tissue: Optio
     collective on the data path.  `writer` (packed.PackedTilesWriter over ALL T tiles) receives this rank's rows [lo, hi) of the
     32x32 logits -- the reference's one `logits_32x32/<name>.pt` per tile (:127) as rows of one file -- in a single device->host
     copy after the loop, so the launch stream never waits for the host inside the loop.
-    streams=2: consecutive batches alternate between two HIP streams.  Batches are independent, and a persistent conv launch whose tile
-    count is not a multiple of the CU count (512-channel layers at bs=64: 3.5 rounds) leaves half the chip idle in its last round --
-    the other batch's launch takes those CUs (the same effect the training backward gets from its weight-gradient stream)."""
+    streams=2: consecutive (independent) batches alternate between two HIP streams, so that another batch's launch can take the CUs
+    a persistent launch leaves idle in its partial last round (512-channel layers at bs=64: 3.5 rounds).  Measured r02 (bs=64, 224x224):
+    5637 tiles/s on one stream, 5480 on two, 5504 on three -- the second kernel's blocks start late on the CUs the first still holds
+    and then serialise their static tile share (the CU-hog effect of DESIGN 6); the default stays 1."""
     dev = next(model.parameters()).device
     if tta:
         from .tta import SegmentationTTAWrapper
