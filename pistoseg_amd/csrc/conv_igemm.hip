@@ -1279,6 +1279,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
 //     of the current one (behind that step's weights, so the in-order vmcnt lets it stay in flight for two steps); weights
 //     run two K-steps ahead.
 // ------------------------------------------------------------------------------------------------
+// A/B build -DPS_HALO_NO_LOADS (results WRONG): the halo kernel's loaders stage only the first window / weight steps of a block -- the
+// consumers' rate with nothing arriving in LDS.  (left = items still to issue, counted down from the block's total)
+#ifdef PS_HALO_NO_LOADS
+#define PS_HALO_STAGE(left, total) ((left) >= (total) - 4)
+#else
+#define PS_HALO_STAGE(left, total) true
+#endif
+
 template <typename Tr, int TW, int NW = 3>  // TW = 28 (maps of 224-pixel tiles: 28 / 56 / 112 wide) or 32 (256-pixel tiles: 32 / 64 / 128 wide); NW = weight ring depth
 __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs a) {
   typedef typename Tr::elem T;
@@ -1343,7 +1351,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
 #pragma unroll
       for (int j = 0; j < WJ; ++j) {
         const bool ok = row_ok && (unsigned)(a_X0 + tcol[j]) < (unsigned)W;  // left / right of the image: zero padding
-        BLDS16(rsA, dst + (j * 4 + lw) * 1024, ok ? (unsigned)(base + tcol[j] * (int)a.pix_bytes) : PAD_ROW, ko);
+        if (PS_HALO_STAGE(a_left, my_tiles * nwin)) BLDS16(rsA, dst + (j * 4 + lw) * 1024, ok ? (unsigned)(base + tcol[j] * (int)a.pix_bytes) : PAD_ROW, ko);
       }
       --a_left;
       a_buf ^= 1;
@@ -1379,7 +1387,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
       unsigned char* dst = smem + W_OFF + b_slot * B_BYTES;
       const int wk = b_tap * tap_bytes + b_kl * 128;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) BLDS16(rsB, dst + (j * 4 + lw) * 1024, woff[j], wk);
+      for (int j = 0; j < 4; ++j)
+        if (PS_HALO_STAGE(b_left, total_steps)) BLDS16(rsB, dst + (j * 4 + lw) * 1024, woff[j], wk);
       --b_left;
       b_slot = (b_slot == NW - 1) ? 0 : b_slot + 1;
       if (++b_tap == 9) {
@@ -1489,11 +1498,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
     auto kstep = [&](int tx, bool first_of_tile) {
       const unsigned char* wst = smem + cur * B_BYTES + wfrag;
       const int soff = wbuf * WIN_BYTES + (tx - 1) * a.dstep * 1024;
+#ifndef PS_HALO_NO_CONSUMERS  // (A/B build, results WRONG: the consumers only keep the barriers -- what the loaders alone sustain)
       half(wst, coff0, soff, 0, wf0, xf0, wf1, xf1, !first_of_tile);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       half(wst, coff1, soff, 64, wf1, xf1, wf0, xf0, true);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
       __builtin_amdgcn_s_barrier();
       cur = (cur == NW - 1) ? 0 : cur + 1;
     };
