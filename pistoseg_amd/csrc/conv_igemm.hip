@@ -1279,6 +1279,18 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
 //     of the current one (behind that step's weights, so the in-order vmcnt lets it stay in flight for two steps); weights
 //     run two K-steps ahead.
 // ------------------------------------------------------------------------------------------------
+// Diagnostic build -DPS_HALO_STAMPS: the halo kernel's consumer waves time the three segments of a K-step with s_memtime (read right
+// behind the existing lgkmcnt(0) waits / the barrier, where the LDS queue is empty) and add them up per wave: [first half: reads +
+// MFMAs + wait], [second half], [barrier].  ps_debug_read_stamps copies the sums out.  (+ ~3 short SMEM round trips per K-step.)
+#ifdef PS_HALO_STAMPS
+__device__ unsigned long long g_halo_stamps[256 * 4 * 6];  // [block][consumer wave][seg0, seg1, seg2, steps, shader cycles, 100 MHz ticks]
+#define PS_STAMP(var)                                            \
+  do {                                                           \
+    var = __builtin_amdgcn_s_memtime();                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           \
+  } while (0)
+#endif
+
 // A/B build -DPS_HALO_NO_LOADS (results WRONG): the halo kernel's loaders stage only the first window / weight steps of a block -- the
 // consumers' rate with nothing arriving in LDS.  (left = items still to issue, counted down from the block's total)
 #ifdef PS_HALO_NO_LOADS
@@ -1466,6 +1478,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
   __builtin_amdgcn_s_barrier();  // window 0 / weights of step 0 visible
 
   int cur = 0, wbuf = 0;
+#ifdef PS_HALO_STAMPS
+  unsigned long long st_seg0 = 0, st_seg1 = 0, st_seg2 = 0, st_steps = 0, st_prev;
+  PS_STAMP(st_prev);
+  const unsigned long long st_c0 = st_prev, st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int tile = first; tile < ntiles; tile += G) {
     f32x4 acc[MI][WI];
 #pragma unroll
@@ -1480,8 +1497,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
       constexpr int NR = WI + MI, NM = MI * WI, PER = PS_READ_PER;
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
+#ifndef PS_HALO_NO_READS  // (diagnostic build, results WRONG: MFMAs on stale registers -- the bare MFMA stream between the barriers)
         if (r < WI) wfn[r] = *reinterpret_cast<const u32x4*>(wst + r * 2048 + wcoff);
         else xfn[r - WI] = *reinterpret_cast<const u32x4*>(smem + ((xa[r - WI] ^ flip) + soff));
+#else
+        if (r < WI) asm volatile("" : "+v"(wfn[r]));
+        else asm volatile("" : "+v"(xfn[r - WI]));
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if (do_mma) {
 #pragma unroll
@@ -1501,11 +1523,26 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
 #ifndef PS_HALO_NO_CONSUMERS  // (A/B build, results WRONG: the consumers only keep the barriers -- what the loaders alone sustain)
       half(wst, coff0, soff, 0, wf0, xf0, wf1, xf1, !first_of_tile);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef PS_HALO_STAMPS
+      unsigned long long t_a, t_b, t_c;
+      PS_STAMP(t_a);
+      st_seg0 += t_a - st_prev;
+#endif
       __builtin_amdgcn_sched_barrier(0);
       half(wst, coff1, soff, 64, wf1, xf1, wf0, xf0, true);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef PS_HALO_STAMPS
+      PS_STAMP(t_b);
+      st_seg1 += t_b - t_a;
+#endif
 #endif
       __builtin_amdgcn_s_barrier();
+#ifdef PS_HALO_STAMPS
+      PS_STAMP(t_c);
+      st_seg2 += t_c - t_b;
+      st_prev = t_c;
+      ++st_steps;
+#endif
       cur = (cur == NW - 1) ? 0 : cur + 1;
     };
     // first K-step of the tile peeled (no previous MFMAs to overlap its reads with), then tx = 1, 2, 0, 1, 2, ...
@@ -1524,7 +1561,17 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
     ps_tile_of_block(tile, a.ntn, a.ntm, tm, tn, a.supertile);
     const int rb = tm / ncb;
     conv_epilogue<T, MI, WI, 1>(a, acc, rb * TR * W + (tm - rb * ncb) * TW + wm * (TW / 2), tn * BN + wn * WN, lane);
+#ifdef PS_HALO_STAMPS
+    PS_STAMP(st_prev);  // the epilogue is not part of segment 0 of the next tile's first step
+#endif
   }
+#ifdef PS_HALO_STAMPS
+  if (lane == 0 && blockIdx.x < 256) {
+    unsigned long long* o = g_halo_stamps + (blockIdx.x * 4 + wave) * 6;
+    o[0] = st_seg0; o[1] = st_seg1; o[2] = st_seg2; o[3] = st_steps;
+    o[4] = __builtin_amdgcn_s_memtime() - st_c0; o[5] = __builtin_amdgcn_s_memrealtime() - st_r0;
+  }
+#endif
 }
 
 PS_TUNABLE g_use_glds = 2;  // staging mode: 0 registers, 1 global_load_lds, 2 buffer_load ... lds
@@ -1740,6 +1787,11 @@ extern "C" void ps_debug_set_pp(int v) { g_use_pp = v; }
 extern "C" void ps_debug_set_ws(int v) { g_use_ws = v; }
 extern "C" void ps_debug_set_ws2(int v) { g_use_ws2 = v; }
 extern "C" void ps_debug_set_halo(int v) { g_use_halo = v; }
+#ifdef PS_HALO_STAMPS
+extern "C" int ps_debug_read_stamps(unsigned long long* host_out) {  // 256 x 4 x 4 values; synchronises the device
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_halo_stamps), sizeof(g_halo_stamps)) == hipSuccess ? 0 : -2;
+}
+#endif
 extern "C" void ps_debug_set_halo_ring(int v) { g_halo_ring = v; }
 extern "C" void ps_debug_set_supertile(int v) { g_supertile = v; }
 #endif
