@@ -43,6 +43,8 @@ void ps_debug_set_ws2(int v);
 void ps_debug_set_halo(int v);
 /* Tuning hook: weight ring depth of the halo kernel: 3, 4 or 5 stages of 16 KiB (256-pixel tiles: at most 4). */
 void ps_debug_set_halo_ring(int v);
+/* Testing hook: halo kernel, partial last round as a second launch of 64-cout half tiles: 0 off, 1 (default) on. */
+void ps_debug_set_halo_tail(int v);
 void ps_debug_set_s2split(int v);  /* stride-2 3x3 data gradient as four parity-class launches: 0 off, 1 big 16-bit problems (default), 2 whenever legal */
 /* Testing hook: 1 (default) = 128x128 weight-gradient tiles use the wave-specialised variant, 0 = the 4-wave kernel. */
 void ps_debug_set_wgrad_ws(int v);

@@ -45,6 +45,7 @@ struct IgemmArgs {
   // class's sub-grid, pixel (p', q') of it is pixel (oy + 2p', ox + 2q') of the full Hf x Wf gradient, and only the taps in tap_mask
   // (those that hit dy at integer positions for this parity) are staged and multiplied.  epi_M = rows of the full tensor.
   int tap_mask, oy, ox, Hf, Wf;
+  int tm0;                    // halo kernel: first pixel tile of this launch (a layer's tail tiles go to a second launch as 64-cout half tiles)
   ps_epilogue epi;
 };
 
@@ -1299,11 +1300,16 @@ __device__ unsigned long long g_halo_stamps[256 * 4 * 6];  // [block][consumer w
 #define PS_HALO_STAGE(left, total) true
 #endif
 
-template <typename Tr, int TW, int NW = 3>  // TW = 28 (maps of 224-pixel tiles: 28 / 56 / 112 wide) or 32 (256-pixel tiles: 32 / 64 / 128 wide); NW = weight ring depth
+// WI = cout fragments per consumer wave: 4 = the 128-cout tile; 2 = a 64-cout HALF tile (8 KiB of weights per K-step, half the MFMAs):
+// the tiles of a launch's partial last round are issued as half tiles by a second launch (see the dispatcher: a 3.5-round layer leaves
+// half the chip idle for a whole round; as half tiles the same work occupies every CU for ~0.6 of a round).
+template <typename Tr, int TW, int NW = 3, int WI = 4>  // TW = 28 (maps of 224-pixel tiles: 28 / 56 / 112 wide) or 32 (256-pixel tiles: 32 / 64 / 128 wide); NW = weight ring depth
 __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs a) {
   typedef typename Tr::elem T;
   static_assert(TW == 28 || TW == 32, "tile width");
-  constexpr int BN = 128, MI = TW / 4, WI = 4, WN = 64, TR = 8;  // tile = 8 rows x TW columns = 224 | 256 pixels
+  static_assert(WI == 4 || WI == 2, "cout fragments per wave");
+  constexpr int BN = 32 * WI, MI = TW / 4, WN = 16 * WI, TR = 8;  // tile = 8 rows x TW columns = 224 | 256 pixels, BN = 128 | 64 couts
+  constexpr int WPW = BN / 32;  // weight DMA instructions per loader wave and K-step (4 | 2)
   constexpr int WJ = (TW + 8 + 3) / 4, WIN_BYTES = WJ * 4 * 1024, B_BYTES = BN * 128;  // window of <= TW + 8 columns: 9 | 10 DMAs per loader wave
   static_assert(WJ == 9 || WJ == 10, "window DMAs per loader wave");
   static_assert(NW >= 3 && NW <= 5 && 2 * WIN_BYTES + NW * B_BYTES <= 160 * 1024, "LDS budget");
@@ -1346,6 +1352,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
     auto window_tile_setup = [&](int tile) {
       int tm, tn;
       ps_tile_of_block(tile, a.ntn, a.ntm, tm, tn, a.supertile);
+      tm += a.tm0;
       const int rb = tm / ncb;
       a_R0 = rb * TR;
       a_X0 = (tm - rb * ncb) * TW;
@@ -1379,13 +1386,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
     };
     // --- cursor of the next WEIGHT tile to stage: (tile, K-line, tap)
     int b_tile = first, b_kl = 0, b_tap = 0, b_slot = 0, b_left = total_steps;
-    unsigned woff[4];
+    unsigned woff[WPW];
     auto weights_setup = [&](int tile) {
       int tm, tn;
       ps_tile_of_block(tile, a.ntn, a.ntm, tm, tn, a.supertile);
+      tm += a.tm0;
       const int n0 = tn * BN;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < WPW; ++j) {
         const int rb = (j * 4 + lw) * 8 + srow;
         const int wg = rb / WN, within = rb % WN, fi = within >> 4, rho = within & 15;
         const int cout = n0 + wg * WN + 4 * WI * (rho >> 2) + 4 * fi + (rho & 3);
@@ -1399,7 +1407,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
       unsigned char* dst = smem + W_OFF + b_slot * B_BYTES;
       const int wk = b_tap * tap_bytes + b_kl * 128;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < WPW; ++j)
         if (PS_HALO_STAGE(b_left, total_steps)) BLDS16(rsB, dst + (j * 4 + lw) * 1024, woff[j], wk);
       --b_left;
       b_slot = (b_slot == NW - 1) ? 0 : b_slot + 1;
@@ -1417,8 +1425,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
     auto wait_allow = [&](int n) {
       switch (n) {
 #define PS_VMCNT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-        PS_VMCNT_CASE(4) PS_VMCNT_CASE(8) PS_VMCNT_CASE(12) PS_VMCNT_CASE(16)
-        PS_VMCNT_CASE(9) PS_VMCNT_CASE(13) PS_VMCNT_CASE(17) PS_VMCNT_CASE(21) PS_VMCNT_CASE(25)
+        PS_VMCNT_CASE(2) PS_VMCNT_CASE(4) PS_VMCNT_CASE(6) PS_VMCNT_CASE(8) PS_VMCNT_CASE(12) PS_VMCNT_CASE(16)
+        PS_VMCNT_CASE(9) PS_VMCNT_CASE(11) PS_VMCNT_CASE(13) PS_VMCNT_CASE(15) PS_VMCNT_CASE(17) PS_VMCNT_CASE(21) PS_VMCNT_CASE(25)
         PS_VMCNT_CASE(10) PS_VMCNT_CASE(14) PS_VMCNT_CASE(18) PS_VMCNT_CASE(22) PS_VMCNT_CASE(26)
 #undef PS_VMCNT_CASE
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -1434,7 +1442,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
     bool win_pending = false;
     issue_window();
     for (int i = 0; i < NW - 1; ++i) w_issued += issue_weights() ? 1 : 0;
-    wait_allow(4 * (w_issued > 0 ? w_issued - 1 : 0));  // window 0 (oldest) and the weights of step 0 have landed
+    wait_allow(WPW * (w_issued > 0 ? w_issued - 1 : 0));  // window 0 (oldest) and the weights of step 0 have landed
     __builtin_amdgcn_s_barrier();
     int r = 0;
     for (int gs = 0; gs < total_steps; ++gs) {
@@ -1446,10 +1454,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
       const int younger = w_issued - (gs + 2) > 0 ? w_issued - (gs + 2) : 0;  // weight steps issued after those of step gs + 1
       int allow;
       if (r == 2) {  // the next window must have landed as well: only the weight steps issued after it may stay in flight
-        allow = 4 * (win_pending ? (younger < after_win ? younger : after_win) : younger);
+        allow = WPW * (win_pending ? (younger < after_win ? younger : after_win) : younger);
         win_pending = false;
       } else {
-        allow = 4 * younger + (win_pending ? WJ : 0);
+        allow = WPW * younger + (win_pending ? WJ : 0);
       }
       wait_allow(allow);
       __builtin_amdgcn_s_barrier();
@@ -1559,6 +1567,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
       for (int i = 0; i < WI; ++i) Tr::mma(wf1[i], xf1[mi], acc[mi][i]);
     int tm, tn;
     ps_tile_of_block(tile, a.ntn, a.ntm, tm, tn, a.supertile);
+      tm += a.tm0;
     const int rb = tm / ncb;
     conv_epilogue<T, MI, WI, 1>(a, acc, rb * TR * W + (tm - rb * ncb) * TW + wm * (TW / 2), tn * BN + wn * WN, lane);
 #ifdef PS_HALO_STAMPS
@@ -1579,6 +1588,7 @@ PS_TUNABLE g_use_pp = 0;       // experimental ping-pong kernel (correct, slower
 PS_TUNABLE g_use_ws = 1;       // wave-specialised (loader/consumer) kernel for big problems
 PS_TUNABLE g_use_ws2 = 1;
 PS_TUNABLE g_use_halo = 1;     // window + halo staging for 3x3 stride-1 layers (width a multiple of 28): 0 off, 1 for big 16-bit problems, 2 forced      // large-tile wave-specialised kernel: 0 off, 1 by cost model, 256 / 224 force that pixel tile
+PS_TUNABLE g_halo_tail = 1;   // halo kernel: a partial last round (<= half the CUs) as a second launch of 64-cout half tiles: 0 off, 1 on
 PS_TUNABLE g_halo_ring = 3;   // weight ring depth of the halo kernel (3 | 4 | 5 stages of 16 KiB; 256-pixel tiles: <= 4)
 PS_TUNABLE g_use_3stage = 0;  // experimental 256x128 three-stage kernel: correct but slower than two 128x128 blocks per CU (r01 measurements)
 PS_TUNABLE g_ablate = 0;
@@ -1735,6 +1745,15 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
       b.ntm = (a.M / a.Ws + 7) / 8 * (a.Ws / tw);  // blocks of 8 global rows x column blocks of tw
       b.nb = ps_num_cus();
       b.tpb = a.tpb;
+      // The partial last round.  With T = ntm x ntn tiles on nb CUs, R = T mod nb <= nb / 2 tiles would keep R CUs busy for a whole round
+      // (512-channel layers at bs=64: 896 tiles = 3.5 rounds).  Those R tiles -- whole pixel tiles, R % ntn == 0 -- go to a second launch
+      // as 2 R half tiles of 64 couts (half the MFMAs, 8 instead of 16 KiB of weights per K-step: ~0.6 of a round on every CU).
+      int tail_ptiles = 0;
+      if constexpr (sizeof(typename Tr::elem) == 2) {
+        const long long T = (long long)b.ntm * b.ntn, R = T % b.nb;
+        if (g_halo_tail && a.tpb == 0 && T > b.nb && R > 0 && 2 * R <= b.nb && R % b.ntn == 0 && a.Cd % 64 == 0) tail_ptiles = (int)(R / b.ntn);
+      }
+      b.ntm -= tail_ptiles;
       const dim3 hgrid(ps_persistent_grid((long long)b.ntm * b.ntn, b.nb, b.tpb));
       if (tw == 28) {
         if (g_halo_ring == 5) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 5>), hgrid, dim3(512), 2 * 9 * 4096 + 5 * 16384, s, b);
@@ -1745,6 +1764,18 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
         else hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32, 3>), hgrid, dim3(512), 2 * 10 * 4096 + 3 * 16384, s, b);
       }
       PS_CHECK_LAUNCH("conv_igemm_halo");
+      if constexpr (sizeof(typename Tr::elem) == 2) {
+        if (tail_ptiles > 0) {
+          IgemmArgs c = b;
+          c.tm0 = b.ntm;
+          c.ntm = tail_ptiles;
+          c.ntn = a.Cd / 64;
+          const dim3 tgrid(ps_persistent_grid((long long)c.ntm * c.ntn, c.nb, 0));
+          if (tw == 28) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 3, 2>), tgrid, dim3(512), 2 * 9 * 4096 + 3 * 8192, s, c);
+          else hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32, 3, 2>), tgrid, dim3(512), 2 * 10 * 4096 + 3 * 8192, s, c);
+          PS_CHECK_LAUNCH("conv_igemm_halo<tail>");
+        }
+      }
       return PS_OK;
     }
     const int bm = v == PS_CONV_WS2_256 ? 256 : v == PS_CONV_WS2_224 ? 224 : v == PS_CONV_WS_128 ? 128 : 112;
@@ -1793,6 +1824,7 @@ extern "C" int ps_debug_read_stamps(unsigned long long* host_out) {  // 256 x 4 
 }
 #endif
 extern "C" void ps_debug_set_halo_ring(int v) { g_halo_ring = v; }
+extern "C" void ps_debug_set_halo_tail(int v) { g_halo_tail = v; }
 extern "C" void ps_debug_set_supertile(int v) { g_supertile = v; }
 #endif
 

@@ -821,3 +821,59 @@ def test_dropout2d_masks_kernel():
     assert tuple(d1["b7.dropout_2b2"].shape) == (4, 2048) and tuple(d1["dropout7"].shape) == (4, 4096)
     d2 = model.sample_dropout(4, D)
     assert not torch.equal(d1["dropout7"], d2["dropout7"])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [
+    # (n, h, w, cin, cout, d): tile counts that leave a partial last round of <= half the 256 CUs, in whole pixel tiles:
+    # 24 x 784 / 224 = 84 pixel tiles x 4 cout tiles = 336 = 256 + 80;  20 x 1024 / 256 = 80 x 4 = 320 = 256 + 64 (256-pixel tiles);
+    # 9 x 56 x 56 / 224 = 126 x 3 = 378 = 256 + 122 with 122 % 3 != 0 -> NOT split (the tail must be whole pixel tiles)
+    (24, 28, 28, 64, 512, 1), (24, 28, 28, 128, 512, 4), (20, 32, 32, 64, 512, 2), (9, 56, 56, 64, 384, 1),
+])
+def test_conv_halo_tail_as_half_tiles(case, dtype):
+    """The partial last round of a halo launch goes to a second launch of 64-cout half tiles: same MFMA chain per output element, so
+    forward (full epilogue) and data gradient are BIT-IDENTICAL to the single-launch schedule, and match the CPU."""
+    from pistoseg_amd import _lib, ops
+
+    lib = _lib.load()
+    n, h, w, cin, cout, d = case
+    g = torch.Generator().manual_seed(h + cin + cout + d)
+    q = quant(dtype)
+    x = q(torch.randn(n, cin, h, w, generator=g)).requires_grad_(True)
+    wt = q(torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5)
+    y = F.conv2d(x, wt, padding=d, dilation=d)
+    res = q(torch.randn(y.shape, generator=g))
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    act = F.relu((y + res) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    spec = ops.ConvSpec(cin, cout, 3, 1, d)
+    D = dev()
+    xd, wf = nhwc(x.detach()).to(D, dtype), w_fwd_layout(wt).to(D, dtype)
+    resd = nhwc(res).to(D, dtype)
+    # the data gradient of a layer with `cout` INPUT channels produces `cout` channels: use the transposed role of the same weights
+    gy = q(torch.randn(n, cin, h, w, generator=g))
+    wt_t = q(torch.randn(cin, cout, 3, 3, generator=g) * 0.05)  # conv cout -> cin; its dgrad produces cout channels
+    gx_ref = torch.nn.grad.conv2d_input((n, cout, h, w), wt_t, gy, padding=d, dilation=d)
+    spec_t = ops.ConvSpec(cout, cin, 3, 1, d)
+    gyd, wdt = nhwc(gy).to(D, dtype), w_dgrad_layout(wt_t).to(D, dtype)
+
+    def run():
+        out_raw = torch.full((n, h, w, cout), float("nan"), device=D, dtype=dtype)
+        out_act = torch.full((n, h, w, cout), float("nan"), device=D, dtype=dtype)
+        ops.conv2d_fwd(spec, xd, wf, add0=resd, out_raw=out_raw, bn_scale=scale.to(D), bn_shift=shift.to(D), out_act=out_act)
+        gx = torch.full((n, h, w, cout), float("nan"), device=D, dtype=dtype)
+        ops.conv2d_dgrad(spec_t, gyd, wdt, (h, w), out_raw=gx)
+        return out_raw, out_act, gx
+
+    try:
+        lib.ps_debug_set_halo_tail(1)
+        split = [run() for _ in range(2)]
+        lib.ps_debug_set_halo_tail(0)
+        single = run()
+    finally:
+        lib.ps_debug_set_halo_tail(1)
+    for a_, b_ in zip(split[0], single):
+        assert torch.equal(a_, b_)
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(split[0], split[1]))
+    tol = TOL[dtype]
+    for a_, r_ in zip(split[0], (nhwc((y + res).detach()), nhwc(act.detach()), nhwc(gx_ref))):
+        assert rel_err(a_.float().cpu(), r_) < tol
