@@ -120,9 +120,8 @@ def pmc_traffic(kernel_label):
         data = json.load(open(files[-1]))
     except Exception:
         return None
-    stem = kernel_label.split("<")[0]
-    for k, v in data.items():
-        if stem in k:
+    for k, v in data.items():  # keys are kernel families "name<dtype>" (tools/pmc_traffic.py); older files: truncated kernel names
+        if k == kernel_label or kernel_label.split("<")[0] in k:
             return {"bytes_per_launch": round(v["hbm_bytes_per_launch_corrected"]), "source": os.path.basename(files[-1])}
     return None
 
@@ -151,6 +150,8 @@ def roofline_leg(run_step, precision):
         "bound": "mfma", "kernel": name, "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": pmc_traffic(name),
         "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 1),
+        "launch_note": "a launch = one C-ABI call; a halo conv launch is one main dispatch (128-cout tiles) plus, for layers whose tile count leaves a "
+                       "partial last round, one tail dispatch (64-cout half tiles): in rocprofv3 stats add both rows' total time and divide by the main row's calls",
         "flops_per_launch_avg": d["flops"] / d["launches"], "all_conv_kernels": kernels,
     }
 

@@ -1,17 +1,26 @@
-"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (two output dirs) into profiles/<tag>_pmc_hbm_traffic.json:
-per kernel mean per dispatch (KiB) and hbm_bytes_per_launch_corrected = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 reports half of
-wide streaming reads, /opt/skills/guides/MI355X_MICROARCH.md, HBM section)."""
-import csv, glob, json, sys, collections
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (two output dirs) into profiles/<tag>_pmc_hbm_traffic.json: per kernel FAMILY
+(kernel name + storage type, template tiling arguments dropped) the mean HBM-side bytes per API LAUNCH:
+hbm_bytes_per_launch_corrected = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over every dispatch of the family / launches, where
+launches = C-ABI calls: one dispatch each, except that a halo conv launch = one main dispatch <.., 4> plus, for layers with a partial last
+round, one tail dispatch <.., 2>, and a stride-2 data gradient = four parity-class dispatches <.., true>.  FETCH_SIZE is doubled: gfx950 reports half of wide streaming reads
+(/opt/skills/guides/MI355X_MICROARCH.md, HBM section)."""
+import collections, csv, glob, json, re, sys
 
 fetch_dir, write_dir, out = sys.argv[1:4]
 
 
+def family(name):
+    stem = re.sub(r"[<(].*", "", name.replace("void ", "").replace("(anonymous namespace)::", ""))
+    dt = "bf16" if ("TraitsBF16" in name or "DF16b" in name) else "f16" if ("TraitsF16" in name or "IDF16_" in name) else "f32" if "TraitsF32" in name else ""
+    return (stem + (f"<{dt}>" if dt else ""))[:100]
+
+
 def collect(d, counter):
-    agg = collections.defaultdict(list)
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
-                agg[r["Kernel_Name"][:60]].append(float(r["Counter_Value"]))
+                agg[family(r["Kernel_Name"])][r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return agg
 
 
@@ -20,9 +29,21 @@ res = {}
 for k in sorted(set(fe) | set(wr)):
     if not ("conv_" in k or "adamw" in k or "fc8" in k or "conv1a" in k):
         continue
-    f, w = fe.get(k, [0.0]), wr.get(k, [0.0])
-    fa, wa = sum(f) / len(f), sum(w) / len(w)
-    res[k] = {"launches": len(f), "fetch_kib_avg": fa, "write_kib_avg": wa, "hbm_bytes_per_launch_corrected": (2 * fa + wa) * 1024,
-              "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB units; FETCH_SIZE doubled (gfx950 reports half of wide streaming reads)"}
+    f, w = fe.get(k, {}), wr.get(k, {})
+    def api_launches(d):
+        n = 0.0
+        for name, v in d.items():
+            if "conv_igemm_halo_kernel" in name and name.rstrip().endswith(", 2>((anonymous namespace)::IgemmArgs)"):
+                continue                       # tail dispatch of a launch already counted through its main dispatch
+            n += len(v) / 4.0 if ("conv_igemm_ws2_kernel" in name and "true>" in name) else len(v)
+        return max(n, 1.0)
+
+    launches = api_launches(f if f else w)
+    ft, wt = sum(sum(v) for v in f.values()), sum(sum(v) for v in w.values())
+    res[k] = {"launches": launches, "dispatches": sum(len(v) for v in f.values()), "instantiations": sorted(len(v) for v in f.values()),
+              "fetch_kib_per_launch": ft / launches, "write_kib_per_launch": wt / launches,
+              "hbm_bytes_per_launch_corrected": (2 * ft + wt) / launches * 1024,
+              "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB units; FETCH_SIZE doubled (gfx950 reports half of wide streaming reads); "
+                      "summed over all dispatches of the family, per API launch"}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: round(v["hbm_bytes_per_launch_corrected"] / 1e6, 1) for k, v in res.items()}, indent=1))
