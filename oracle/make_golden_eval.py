@@ -14,6 +14,8 @@ truths the methods read with PIL come from small PNGs written to a temp director
                                   ModelCheckpoint(monitor='validation_miou_mask_epoch'), segmentation_train.py:108-117)
   tests/golden/seg_eval.npz       sliding-window evaluation: per-image averaged probability canvases (f64), logged metric values,
                                   CE / mIoU values of training_step
+  tests/golden/mxnet_key_map.json MXNet -> torch parameter names: the reference's convert_mxnet_to_torch (models/resnet38d.py:215-263) run on a
+                                  stand-in `mxnet.nd.load` that returns one tagged array per parameter name of the ResNet38 ImageNet checkpoint
   tests/golden/oeem_ms_cam.npz    OEEM stage 0 multi-scale CAM accumulation (OEEM/classification/prepare_seg_inputs.py:96-138):
                                   the statements of the per-image loop body exec'ed with a stub `net_cam` returning canned CAM crops
 
@@ -201,6 +203,48 @@ def run_oeem(ref: str):
     return {"ensemble_cam": ns["ensemble_cam"]}
 
 
+def mxnet_param_names():
+    """The parameter names of the MXNet ResNet38 ImageNet checkpoint, written out from its architecture (unit `<stage>a`, `<stage>b<k>`;
+    branch2a / branch2b1 [/ branch2b2] / branch1; BatchNorm gamma, beta + moving_mean, moving_var) -- shared with the tests."""
+    names = ["arg:conv1a_weight", "arg:linear1000_weight", "arg:linear1000_bias"]
+    units = {2: 2, 3: 2, 4: 5, 5: 2, 6: 0, 7: 0}  # stage -> number of b<k> units after the a unit
+    for st, extra in units.items():
+        for u in ["a"] + [f"b{k}" for k in range(1, extra + 1)]:
+            branches = ["branch2a", "branch2b1"] + (["branch2b2"] if st >= 6 else [])
+            for br in branches:
+                names.append(f"arg:res{st}{u}_{br}_weight")
+                names += [f"arg:bn{st}{u}_{br}_gamma", f"arg:bn{st}{u}_{br}_beta", f"aux:bn{st}{u}_{br}_moving_mean", f"aux:bn{st}{u}_{br}_moving_var"]
+            if u == "a":
+                names.append(f"arg:res{st}{u}_branch1_weight")
+    names += ["arg:bn7_gamma", "arg:bn7_beta", "aux:bn7_moving_mean", "aux:bn7_moving_var"]
+    return names
+
+
+def run_mxnet_names(ref: str):
+    """models/resnet38d.py:215-263 executed with a stand-in `mxnet` module whose nd.load returns one tagged array per name."""
+    import types
+
+    import models.resnet38d as R38
+
+    class _Arr:
+        def __init__(self, i):
+            self.i = i
+
+        def asnumpy(self):
+            return np.array([float(self.i)], dtype=np.float32)
+
+    names = mxnet_param_names()
+    fake = types.ModuleType("mxnet")
+    fake.nd = types.SimpleNamespace(load=lambda fn: {n: _Arr(i) for i, n in enumerate(names)})
+    sys.modules["mxnet"] = fake
+    try:
+        out = R38.convert_mxnet_to_torch("unused.params")
+    finally:
+        del sys.modules["mxnet"]
+    inv = {int(v.item()): k for k, v in out.items()}
+    return {n: inv.get(i) for i, n in enumerate(names)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -234,6 +278,8 @@ def main():
         json.dump(all_keys, f, indent=1, sort_keys=True)
     np.savez_compressed(os.path.join(a.out, "seg_eval.npz"), **npz)
     np.savez_compressed(os.path.join(a.out, "oeem_ms_cam.npz"), **run_oeem(a.ref))
+    with open(os.path.join(a.out, "mxnet_key_map.json"), "w") as f:
+        json.dump(run_mxnet_names(a.ref), f, indent=0, sort_keys=True)
     print("wrote logged_keys.json, seg_eval.npz, oeem_ms_cam.npz ->", a.out)
 
 

@@ -538,3 +538,42 @@ class Net(nn.Module):
     def trainable_conv_params(self) -> List[Tuple[str, nn.Parameter]]:
         """(name, parameter) of every conv weight that currently requires grad, in state-dict order."""
         return [(k, p) for k, p in self.named_parameters() if p.dim() == 4 and p.requires_grad]
+
+
+_MX_BN = {"beta": "bias", "gamma": "weight", "mean": "running_mean", "var": "running_var"}
+
+
+def mxnet_key_to_torch(key: str) -> Optional[str]:
+    """One parameter name of the ImageNet ResNet38 MXNet checkpoint (`ilsvrc-cls_rna-a1_cls1000_ep-0001.params`: `arg:res3b1_branch2a_weight`,
+    `aux:bn5a_branch2b1_moving_var`, `arg:bn7_gamma`, `arg:conv1a_weight`, `arg:linear1000_*`) -> this net's state-dict key, or None for
+    the 1000-way classifier.  Unit `<stage>a` is `b<stage>`, `<stage>b<k>` is `b<stage>_<k>` (models/resnet38d.py:215-263)."""
+    toks = key.split("_")
+    head = toks[0]
+    if "conv1a" in head:
+        return "conv1a.weight"
+    if "linear1000" in head:
+        return None
+    if len(toks) > 1 and "branch" in toks[1]:
+        unit = f"b{head[-2]}" if head[-1] == "a" else f"b{head[-3]}_{head[-1]}"
+        if "res" in head:
+            return f"{unit}.conv_{toks[1]}.weight"
+        return f"{unit}.bn_{toks[1]}.{_MX_BN[toks[-1]]}"
+    return "bn7." + _MX_BN[toks[-1]]
+
+
+def convert_mxnet_to_torch(source) -> Dict[str, Tensor]:
+    """Mirror of the reference's `convert_mxnet_to_torch(filename)` (models/resnet38d.py:215-263; used by revise_pseudo_labels.py:179-181 for
+    `.params` checkpoints).  `source`: a path (needs the `mxnet` package, as the reference does) or an already loaded {name: array} mapping
+    (arrays with `.asnumpy()` or anything `numpy.asarray` takes)."""
+    import numpy as np
+
+    if isinstance(source, (str, bytes)) or hasattr(source, "__fspath__"):
+        import mxnet  # third-party, absent from the MI355X image: the reference imports it lazily in the same place
+
+        source = mxnet.nd.load(source)
+    out: Dict[str, Tensor] = {}
+    for k, v in source.items():
+        name = mxnet_key_to_torch(k)
+        if name is not None:
+            out[name] = torch.from_numpy(np.asarray(v.asnumpy() if hasattr(v, "asnumpy") else v))
+    return out

@@ -65,3 +65,39 @@ def test_create_model_plug_point_handles_smp_names():
         assert isinstance(m, ResNet38dSeg) and m.classes == 3
     finally:
         os.environ.pop("PISTOSEG_SUBSTITUTE_MODEL", None)
+
+
+def test_convert_mxnet_to_torch_matches_reference_key_map():
+    """`convert_mxnet_to_torch` (models/resnet38d.py:215-263; ImageNet `.params` init of stage 3, revise_pseudo_labels.py:179-181) against the
+    name map minted by running the reference's function on a stand-in mxnet loader (tests/golden/mxnet_key_map.json): every parameter of the
+    MXNet checkpoint lands on the same state-dict key, the 1000-way classifier is dropped, and the result fills every backbone tensor."""
+    import json
+
+    import torch
+
+    from oracle.make_golden_eval import mxnet_param_names
+    from pistoseg_amd.resnet38d import Net, convert_mxnet_to_torch, mxnet_key_to_torch
+
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "mxnet_key_map.json")))
+    names = mxnet_param_names()
+    assert sorted(names) == sorted(want)
+    assert {n: mxnet_key_to_torch(n) for n in names} == want
+
+    class Arr:  # what mxnet.nd.load hands back: objects with .asnumpy()
+        def __init__(self, a):
+            self.a = a
+
+        def asnumpy(self):
+            return self.a
+
+    net = Net(precision="fp32")
+    sd = net.state_dict()
+    rs = np.random.RandomState(0)
+    src = {n: Arr(rs.standard_normal(tuple(sd[t].shape)).astype(np.float32)) for n, t in want.items() if t is not None}
+    src["arg:linear1000_weight"] = Arr(np.zeros((1000, 4096), np.float32))
+    out = convert_mxnet_to_torch(src)
+    assert set(out) == {t for t in want.values() if t is not None}
+    res = net.load_state_dict(out, strict=False)
+    assert not res.unexpected_keys and all(k.endswith("num_batches_tracked") for k in res.missing_keys)
+    k = "b5_1.conv_branch2a.weight"
+    assert torch.equal(net.state_dict()[k], torch.from_numpy(src["arg:res5b1_branch2a_weight"].a))
