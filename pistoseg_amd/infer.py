@@ -7,6 +7,7 @@ PNG / palette / resize post-processing stays host-side I/O (out of scope, SURVEY
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Optional
 
 import torch
@@ -59,7 +60,7 @@ def infer_pseudo_masks(model, images: Tensor, patch_label: Tensor, tissue: Optio
     for bi, s in enumerate(range(lo, hi, batch_size)):
         e = min(hi, s + batch_size)
         st = side[bi % len(side)]
-        ctx = torch.cuda.stream(st) if st is not None and st is not main else _NullCtx()
+        ctx = torch.cuda.stream(st) if st is not None and st is not main else contextlib.nullcontext()
         with ctx:
             x = images[s:e].to(dev, non_blocking=True)
             logits = model(x)
@@ -78,14 +79,6 @@ def infer_pseudo_masks(model, images: Tensor, patch_label: Tensor, tissue: Optio
     if writer is not None and small is not None:
         writer.write_rows(lo, small)
     return lo, hi, small, cat(masks), cat(ents)
-
-
-class _NullCtx:
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *a):
-        return False
 
 
 @torch.no_grad()
