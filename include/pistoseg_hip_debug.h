@@ -45,8 +45,6 @@ void ps_debug_set_halo(int v);
 void ps_debug_set_halo_ring(int v);
 /* Testing hook: halo kernel, partial last round as a second launch of 64-cout half tiles: 0 off, 1 (default) on. */
 void ps_debug_set_halo_tail(int v);
-/* Testing hook: waves of a halo kernel block: 8 (default: 4 consumers + 4 loaders) or 12 (8 consumers of half the cout span + 4 loaders). */
-void ps_debug_set_halo_waves(int v);
 void ps_debug_set_s2split(int v);  /* stride-2 3x3 data gradient as four parity-class launches: 0 off, 1 big 16-bit problems (default), 2 whenever legal */
 /* Testing hook: 1 (default) = 128x128 weight-gradient tiles use the wave-specialised variant, 0 = the 4-wave kernel. */
 void ps_debug_set_wgrad_ws(int v);

@@ -1303,17 +1303,12 @@ __device__ unsigned long long g_halo_stamps[256 * 4 * 6];  // [block][consumer w
 // WI = cout fragments per consumer wave: 4 = the 128-cout tile; 2 = a 64-cout HALF tile (8 KiB of weights per K-step, half the MFMAs):
 // the tiles of a launch's partial last round are issued as half tiles by a second launch (see the dispatcher: a 3.5-round layer leaves
 // half the chip idle for a whole round; as half tiles the same work occupies every CU for ~0.6 of a round).
-// CW = consumer waves: 4 (2 x 2: one per SIMD beside a loader wave) or, with WI = 2, 8 (2 pixel halves x 4 cout quarters of the 128-cout tile:
-// TWO consumer waves per SIMD, 12 waves in the block, <= 168 VGPRs each): a wave's fragment reads cost ~8 issue cycles each between its
-// own MFMAs; with a second consumer wave on the SIMD one wave's reads and waits overlap the other's MFMAs.
-template <typename Tr, int TW, int NW = 3, int WI = 4, int CW = 4>  // TW = 28 (maps of 224-pixel tiles: 28 / 56 / 112 wide) or 32 (256-pixel tiles: 32 / 64 / 128 wide); NW = weight ring depth
-__global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 3 : 2) void conv_igemm_halo_kernel(const IgemmArgs a) {
+template <typename Tr, int TW, int NW = 3, int WI = 4>  // TW = 28 (maps of 224-pixel tiles: 28 / 56 / 112 wide) or 32 (256-pixel tiles: 32 / 64 / 128 wide); NW = weight ring depth
+__global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs a) {
   typedef typename Tr::elem T;
   static_assert(TW == 28 || TW == 32, "tile width");
   static_assert(WI == 4 || WI == 2, "cout fragments per wave");
-  static_assert(CW == 4 || (CW == 8 && WI == 2), "consumer waves");
-  constexpr int NCG = CW / 2;                                    // cout groups (consumer waves along cout): 2 | 4
-  constexpr int WN = 16 * WI, BN = NCG * WN, MI = TW / 4, TR = 8;  // tile = 8 rows x TW columns = 224 | 256 pixels, BN = 128 | 64 couts
+  constexpr int BN = 32 * WI, MI = TW / 4, WN = 16 * WI, TR = 8;  // tile = 8 rows x TW columns = 224 | 256 pixels, BN = 128 | 64 couts
   constexpr int WPW = BN / 32;  // weight DMA instructions per loader wave and K-step (4 | 2)
   constexpr int WJ = (TW + 8 + 3) / 4, WIN_BYTES = WJ * 4 * 1024, B_BYTES = BN * 128;  // window of <= TW + 8 columns: 9 | 10 DMAs per loader wave
   static_assert(WJ == 9 || WJ == 10, "window DMAs per loader wave");
@@ -1333,10 +1328,10 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 3 : 2) void conv_igemm_hal
   const int dabs = a.dstep < 0 ? -a.dstep : a.dstep;
   const int WP = TW + 2 * dabs;              // window columns (<= 36)
 
-  if (wave >= CW) {
+  if (wave >= 4) {
     // ================= loader =================
     PS_LOADER_SETPRIO();
-    const int lw = wave - CW;
+    const int lw = wave - 4;
     const int srow = lane >> 3;              // window row this lane stages (of every window column)
     const int chunk_off = ((lane & 7) ^ srow) << 4;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, (int)a.src_bytes, 0x00020000);
@@ -1473,7 +1468,7 @@ __global__ __launch_bounds__(64 * (CW + 4), CW == 8 ? 3 : 2) void conv_igemm_hal
 
   // ================= consumer =================
   // waves 2x2: wm = column half of the tile (TW / 2 columns = MI fragments of 8 rows x 2 columns), wn = cout half
-  const int wm = wave / NCG, wn = wave % NCG;
+  const int wm = wave >> 1, wn = wave & 1;
   const int frow = lane & 15, g = lane >> 4;
   const int wfrag = W_OFF + (wn * WN + frow) * 128;
   const int sw = lane & 7;
@@ -1593,7 +1588,6 @@ PS_TUNABLE g_use_pp = 0;       // experimental ping-pong kernel (correct, slower
 PS_TUNABLE g_use_ws = 1;       // wave-specialised (loader/consumer) kernel for big problems
 PS_TUNABLE g_use_ws2 = 1;
 PS_TUNABLE g_use_halo = 1;     // window + halo staging for 3x3 stride-1 layers (width a multiple of 28): 0 off, 1 for big 16-bit problems, 2 forced      // large-tile wave-specialised kernel: 0 off, 1 by cost model, 256 / 224 force that pixel tile
-PS_TUNABLE g_halo_waves = 8;  // halo kernel block: 8 waves (4 consumers of 112 x 64 + 4 loaders) or 12 (8 consumers of 112 x 32 + 4 loaders)
 PS_TUNABLE g_halo_tail = 1;   // halo kernel: a partial last round (<= half the CUs) as a second launch of 64-cout half tiles: 0 off, 1 on
 PS_TUNABLE g_halo_ring = 3;   // weight ring depth of the halo kernel (3 | 4 | 5 stages of 16 KiB; 256-pixel tiles: <= 4)
 PS_TUNABLE g_use_3stage = 0;  // experimental 256x128 three-stage kernel: correct but slower than two 128x128 blocks per CU (r01 measurements)
@@ -1764,7 +1758,6 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
       if (tw == 28) {
         if (g_halo_ring == 5) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 5>), hgrid, dim3(512), 2 * 9 * 4096 + 5 * 16384, s, b);
         else if (g_halo_ring == 4) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 4>), hgrid, dim3(512), 2 * 9 * 4096 + 4 * 16384, s, b);
-        else if (g_halo_waves == 12 && sizeof(typename Tr::elem) == 2) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 3, 2, 8>), hgrid, dim3(768), 2 * 9 * 4096 + 3 * 16384, s, b);
         else hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 3>), hgrid, dim3(512), 2 * 9 * 4096 + 3 * 16384, s, b);
       } else {
         if (g_halo_ring >= 4) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32, 4>), hgrid, dim3(512), 2 * 10 * 4096 + 4 * 16384, s, b);
@@ -1832,7 +1825,6 @@ extern "C" int ps_debug_read_stamps(unsigned long long* host_out) {  // 256 x 4 
 #endif
 extern "C" void ps_debug_set_halo_ring(int v) { g_halo_ring = v; }
 extern "C" void ps_debug_set_halo_tail(int v) { g_halo_tail = v; }
-extern "C" void ps_debug_set_halo_waves(int v) { g_halo_waves = v; }
 extern "C" void ps_debug_set_supertile(int v) { g_supertile = v; }
 #endif
 

@@ -877,43 +877,3 @@ def test_conv_halo_tail_as_half_tiles(case, dtype):
     tol = TOL[dtype]
     for a_, r_ in zip(split[0], (nhwc((y + res).detach()), nhwc(act.detach()), nhwc(gx_ref))):
         assert rel_err(a_.float().cpu(), r_) < tol
-
-
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("case", [(3, 28, 28, 256, 128, 4), (7, 28, 28, 192, 384, 2), (2, 56, 56, 64, 128, 1), (1, 12, 56, 64, 256, 4), (24, 28, 28, 64, 512, 1)])
-def test_conv_halo_twelve_wave_block(case, dtype):
-    """The halo kernel with 8 consumer waves of 112 x 32 (two per SIMD) + 4 loaders: same MFMA chain per output element as the 8-wave block,
-    so forward (full epilogue) and data gradient are bit-identical to it."""
-    from pistoseg_amd import _lib, ops
-
-    lib = _lib.load()
-    n, h, w, cin, cout, d = case
-    g = torch.Generator().manual_seed(h + cin + cout + d)
-    D = dev()
-    x = torch.randn(n, h, w, cin, generator=g).to(D, dtype)
-    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
-    wf, wd = w_fwd_layout(wt).to(D, dtype), w_dgrad_layout(wt).to(D, dtype)
-    res = torch.randn(n, h, w, cout, generator=g).to(D, dtype)
-    gy = torch.randn(n, h, w, cout, generator=g).to(D, dtype)
-    scale, shift = (torch.rand(cout, generator=g) + 0.5).to(D), (torch.randn(cout, generator=g) * 0.1).to(D)
-    spec = ops.ConvSpec(cin, cout, 3, 1, d)
-
-    def run():
-        out_raw = torch.full((n, h, w, cout), float("nan"), device=D, dtype=dtype)
-        out_act = torch.full((n, h, w, cout), float("nan"), device=D, dtype=dtype)
-        ops.conv2d_fwd(spec, x, wf, add0=res, out_raw=out_raw, bn_scale=scale, bn_shift=shift, out_act=out_act)
-        gx = torch.full((n, h, w, cin), float("nan"), device=D, dtype=dtype)
-        ops.conv2d_dgrad(spec, gy, wd, (h, w), out_raw=gx)
-        return out_raw, out_act, gx
-
-    try:
-        lib.ps_debug_set_halo(2)
-        lib.ps_debug_set_halo_waves(12)
-        got = [run() for _ in range(2)]
-        lib.ps_debug_set_halo_waves(8)
-        ref = run()
-    finally:
-        lib.ps_debug_set_halo(1)
-        lib.ps_debug_set_halo_waves(8)
-    for a_, b_, c_ in zip(got[0], got[1], ref):
-        assert torch.equal(a_, b_) and torch.equal(a_, c_)
