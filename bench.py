@@ -37,6 +37,11 @@ sys.path.insert(0, ROOT)
 
 GFLOP_FWD_PER_TILE = 199.93   # SURVEY.md 8(d) / BASELINE.md 2: conv FLOPs, 2*MACs, per 224x224 tile (RFM net)
 GFLOP_TRAIN_PER_TILE = 556.28  # fwd + dgrad + wgrad, frozen conv1a/b2* skipped
+# TEST ONLY: RCCL refuses two ranks of one communicator on one device, and the test boxes have one GPU.  With PISTOSEG_BENCH_TEST_BACKEND=gloo
+# the ranks of `bench.py --gpus N` may share the visible GPU(s) and talk over gloo, so that the multi-rank control flow of this script (child
+# launch, barriers, MAX-over-ranks timing, lockstep instrumented step, teardown) is exercised by tests/test_bench_launch.py.  Such a run's
+# numbers mean nothing and its JSON line says so ("test_backend").
+TEST_BACKEND = os.environ.get("PISTOSEG_BENCH_TEST_BACKEND") or None
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # /opt/skills/guides/MI355X_MICROARCH.md, dense
 
 
@@ -70,7 +75,7 @@ def spawn_ranks(args) -> int:
     import subprocess
 
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not TEST_BACKEND:
         print(f"[bench] --gpus {args.gpus} asked for but {have} GPU(s) visible: refusing to report a smaller job", file=sys.stderr)
         return 2
     with socket.socket() as sk:
@@ -341,11 +346,16 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the HIP path has no CPU fallback)")
     if local_rank >= torch.cuda.device_count():
-        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible); RCCL needs one device per rank")
+        if not TEST_BACKEND:
+            raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible); RCCL needs one device per rank")
+        local_rank %= torch.cuda.device_count()  # test mode: ranks share the visible GPU(s)
     torch.cuda.set_device(local_rank)
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if TEST_BACKEND:
+            torch.distributed.init_process_group(TEST_BACKEND)
+        else:
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__
 
@@ -389,6 +399,8 @@ def main():
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "tile": args.tile, "parallelism": f"dp{world}"},
         "train_conv_tflops_per_gpu": round(value / world * GFLOP_TRAIN_PER_TILE * (args.tile / 224.0) ** 2 / 1e3, 1),
     }
+    if TEST_BACKEND:
+        out["test_backend"] = TEST_BACKEND + ": ranks share GPUs, numbers are not measurements"
 
     if not args.no_infer:
         model.eval()

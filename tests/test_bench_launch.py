@@ -37,3 +37,24 @@ def test_bench_gpus_2_launches_two_rccl_ranks_when_the_box_has_them():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 16
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["seg", "rfm", "infer2"])
+def test_bench_multi_rank_control_flow_on_a_shared_gpu(workload):
+    """The N > 1 control flow of bench.py -- child torch.distributed.run launch, init, barrier-bracketed timing with MAX over ranks, the
+    lockstep instrumented step (it contains collectives), teardown, ONE JSON line from rank 0 -- with two ranks sharing the test GPU over gloo
+    (PISTOSEG_BENCH_TEST_BACKEND: RCCL itself refuses two ranks on one device).  Checks the line's bookkeeping, not its numbers."""
+    argv = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--tile", "64", "--no-cpu-baseline", "--workload", workload]
+    r = run_bench(*argv, env={"PISTOSEG_BENCH_TEST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["steps"] == 2 and line["scaling"] == "weak"
+    if workload == "infer2":
+        assert line["config"]["tiles_per_gpu"] == 4 and line["value"] > 0
+    else:
+        assert line["config"]["global_batch"] == 4 and line["value"] > 0
+    if workload == "seg":
+        assert "roofline" in line and "cpu_baseline" not in line and "test_backend" in line
