@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pistoseg_amd import _lib, ops
-lib = _lib.use_debug_library()  # the ps_debug_* switches live in libpistoseg_hip_debug.so only; D = torch.device("cuda:0"); dt = torch.bfloat16
+lib = _lib.use_debug_library(); D = torch.device("cuda:0"); dt = torch.bfloat16  # the ps_debug_* switches live in the debug library only
 n, H = 64, 28
 import argparse
 ap = argparse.ArgumentParser(); ap.add_argument("--ablate", type=int, default=0); args = ap.parse_args()
