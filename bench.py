@@ -48,8 +48,8 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # /opt/skill
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50, help="timed steps (SURVEY 8d: >= 50, median of per-step HIP events reported beside the wall-clock mean)")
+    ap.add_argument("--warmup", type=int, default=10, help="untimed warm-up steps (SURVEY 8d: 10)")
     ap.add_argument("--batch", type=int, default=64, help="tiles per GPU per step")
     ap.add_argument("--tile", type=int, default=224)
     ap.add_argument("--classes", type=int, default=3)

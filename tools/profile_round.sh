@@ -16,7 +16,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_
 python tools/pmc_traffic.py gpurun_out/pmc_${tag}_fetch gpurun_out/pmc_${tag}_write gpurun_out/${tag}_pmc_hbm_traffic.json > /dev/null &&
 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_${tag}_mfma_1 -- python bench.py $PMC_ARGS > /dev/null 2>&1 &&
 python tools/pmc_mfma_report.py gpurun_out/pmc_${tag}_mfma_1 > gpurun_out/${tag}_pmc_mfma_busy_train_step.txt &&
-python bench.py --steps 10 --warmup 3 > gpurun_out/${tag}_bench_unprofiled.json 2> gpurun_out/${tag}_bench_unprofiled.err &&
+python bench.py > gpurun_out/${tag}_bench_unprofiled.json 2> gpurun_out/${tag}_bench_unprofiled.err &&
 python tools/step_profile.py > gpurun_out/${tag}_step_profile_per_launch.txt 2>&1 &&
 # --- the PARITY path: fp32 storage, exact-f32 MFMA (157 TFLOP/s matrix peak)
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_fp32 -- python bench.py --precision fp32 --steps 3 --warmup 1 --no-cpu-baseline --no-overlap > gpurun_out/${tag}_bench_fp32_parity_path.json 2>> gpurun_out/${tag}_bench_profiled.err &&
