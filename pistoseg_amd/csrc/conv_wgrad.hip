@@ -18,22 +18,6 @@
 namespace {
 
 
-struct FastDiv {
-  uint32_t magic, shift, d;
-};
-static FastDiv make_fastdiv(uint32_t d) {
-  FastDiv f;
-  f.d = d;
-  uint32_t l = 0;
-  while ((1u << l) < d) ++l;
-  f.shift = 31 + l;
-  f.magic = static_cast<uint32_t>(((1ull << f.shift) + d - 1) / d);  // exact for dividends < 2^31
-  return f;
-}
-__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
-  return static_cast<uint32_t>((static_cast<unsigned long long>(n) * f.magic) >> f.shift);
-}
-
 struct WgradArgs {
   const unsigned char* x;   // forward input  [n,h,w,cin]
   const unsigned char* dy;  // output gradient [n,ho,wo,cout]

@@ -131,6 +131,24 @@ __device__ __forceinline__ void ps_store8<__bf16>(__bf16* p, const float* v) {
   *reinterpret_cast<uint4*>(p) = a;
 }
 
+// Division by a launch-invariant divisor as multiply-high + shift (the device has no integer divide: a 32-bit `/` is ~40
+// instructions, a 64-bit one several hundred).  Exact for dividends < 2^31.
+struct FastDiv {
+  uint32_t magic, shift, d;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  uint32_t l = 0;
+  while ((1u << l) < d) ++l;
+  f.shift = 31 + l;
+  f.magic = static_cast<uint32_t>(((1ull << f.shift) + d - 1) / d);
+  return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+  return static_cast<uint32_t>((static_cast<unsigned long long>(n) * f.magic) >> f.shift);
+}
+
 // Eight consecutive elements held as loaded (no conversion): lets a kernel issue loads well ahead of their use.
 template <typename T>
 struct PsRaw8 {

@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const float* __restrict__ x
 template <typename T, bool F16>
 __global__ __launch_bounds__(256) void conv1a_lowp_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
-                                                          T* __restrict__ out_act, T* __restrict__ out_raw, int n, int h, int wd) {
+                                                          T* __restrict__ out_act, T* __restrict__ out_raw, int n, int h, int wd,
+                                                          const FastDiv div_hw, const FastDiv div_w) {
   const int lane = threadIdx.x & 63, g = lane >> 4, col = lane & 15;
   typedef T t8 __attribute__((ext_vector_type(8)));
   t8 wa[4];
@@ -113,18 +114,20 @@ __global__ __launch_bounds__(256) void conv1a_lowp_kernel(const float* __restric
     tdx[e] = kx - 1;
     toff[e] = c * h * wd;
   }
-  const long long total = (long long)n * h * wd;
-  const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+  // (pixel indices fit 31 bits: checked by the launcher; the decomposition pixel -> (image, y, x) is two magic-number divisions -- as
+  // plain `/` on a 64-bit index it was several hundred VALU instructions per 16 pixels, more than everything else in the loop)
+  const int total = n * h * wd;
+  const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
   // The NEXT 16 pixels' taps are loaded before this group's stores are issued (loads are unconditional on clamped coordinates; the
   // validity bits zero the padding afterwards): vmcnt is one in-order queue, a load issued behind the stores would wait for them.
   float raw[8];
   unsigned vmask = 0;
-  auto gather = [&](long long p0) {
-    const long long pix = p0 + col;
+  auto gather = [&](int p0) {
+    const int pix = p0 + col;
     const bool live = pix < total;
-    const int img = live ? (int)(pix / ((long long)h * wd)) : 0;
-    const int rem = live ? (int)(pix - (long long)img * h * wd) : 0;
-    const int y = rem / wd, xx = rem - y * wd;
+    const int img = live ? (int)fdiv((uint32_t)pix, div_hw) : 0;
+    const int rem = live ? pix - img * h * wd : 0;
+    const int y = (int)fdiv((uint32_t)rem, div_w), xx = rem - y * wd;
     const float* xb = x + (long long)img * 3 * h * wd;
     vmask = 0;
 #pragma unroll
@@ -136,13 +139,14 @@ __global__ __launch_bounds__(256) void conv1a_lowp_kernel(const float* __restric
     }
   };
   gather(wave_id * 16);
-  for (long long p0 = wave_id * 16; p0 < total; p0 += nwaves * 16) {
-    const long long pix = p0 + col;
+  for (long long p0l = (long long)wave_id * 16; p0l < total; p0l += (long long)nwaves * 16) {
+    const int p0 = (int)p0l;
+    const long long pix = p0l + col;
     const bool live = pix < total;
     t8 bv;
 #pragma unroll
     for (int e = 0; e < 8; ++e) bv[e] = static_cast<T>((vmask >> e) & 1u ? raw[e] : 0.f);
-    gather(p0 + nwaves * 16 < total ? p0 + nwaves * 16 : p0);  // (the last group re-reads itself)
+    gather(p0l + (long long)nwaves * 16 < total ? p0 + nwaves * 16 : p0);  // (the last group re-reads itself)
     f32x4 acc[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -616,12 +620,14 @@ extern "C" int ps_conv1a_fwd(int32_t out_dtype, const float* x, const float* w, 
   PS_REQUIRE((!out_act || ps_aligned16(out_act)) && (!out_raw || ps_aligned16(out_raw)), "conv1a: misaligned output");
   const long long pix = (long long)n * h * wd;
   PS_REQUIRE((long long)3 * h * wd < (1LL << 31), "conv1a: image too large");
+  PS_REQUIRE(pix < (1LL << 31) - 16, "conv1a: more than 2^31 pixels in one launch");
+  const FastDiv div_hw = make_fastdiv((uint32_t)(h * wd)), div_w = make_fastdiv((uint32_t)wd);
   const int grid = grid_for(pix, 64, 256 * 8);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (out_dtype == PS_BF16)
-    hipLaunchKernelGGL((conv1a_lowp_kernel<__bf16, false>), dim3(grid), dim3(256), 0, s, x, w, scale, shift, (__bf16*)out_act, (__bf16*)out_raw, n, h, wd);
+    hipLaunchKernelGGL((conv1a_lowp_kernel<__bf16, false>), dim3(grid), dim3(256), 0, s, x, w, scale, shift, (__bf16*)out_act, (__bf16*)out_raw, n, h, wd, div_hw, div_w);
   else if (out_dtype == PS_F16)
-    hipLaunchKernelGGL((conv1a_lowp_kernel<_Float16, true>), dim3(grid), dim3(256), 0, s, x, w, scale, shift, (_Float16*)out_act, (_Float16*)out_raw, n, h, wd);
+    hipLaunchKernelGGL((conv1a_lowp_kernel<_Float16, true>), dim3(grid), dim3(256), 0, s, x, w, scale, shift, (_Float16*)out_act, (_Float16*)out_raw, n, h, wd, div_hw, div_w);
   else if (out_dtype == PS_F32)
     hipLaunchKernelGGL(conv1a_kernel<float>, dim3(grid), dim3(256), 0, s, x, w, scale, shift, (float*)out_act, (float*)out_raw, n, h, wd);
   else
