@@ -123,12 +123,12 @@ __device__ __forceinline__ void ps_store8<float>(float* p, const float* v) {
 }
 template <>
 __device__ __forceinline__ void ps_store8<__bf16>(__bf16* p, const float* v) {
-  uint4 a;
-  a.x = ps_f32_to_bf16(v[0]) | (static_cast<uint32_t>(ps_f32_to_bf16(v[1])) << 16);
-  a.y = ps_f32_to_bf16(v[2]) | (static_cast<uint32_t>(ps_f32_to_bf16(v[3])) << 16);
-  a.z = ps_f32_to_bf16(v[4]) | (static_cast<uint32_t>(ps_f32_to_bf16(v[5])) << 16);
-  a.w = ps_f32_to_bf16(v[6]) | (static_cast<uint32_t>(ps_f32_to_bf16(v[7])) << 16);
-  *reinterpret_cast<uint4*>(p) = a;
+  // one vector conversion = four v_cvt_pk_bf16_f32 of adjacent pairs (written element by element with shifts and ORs, hipcc paired
+  // (v0, v2) / (v1, v3) and then re-interleaved the halves with 16 extra instructions)
+  typedef float f32x8 __attribute__((ext_vector_type(8)));
+  typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+  const f32x8 f = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+  *reinterpret_cast<uint4*>(p) = __builtin_bit_cast(uint4, __builtin_convertvector(f, b16x8));
 }
 
 // Division by a launch-invariant divisor as multiply-high + shift (the device has no integer divide: a 32-bit `/` is ~40

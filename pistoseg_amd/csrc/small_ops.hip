@@ -2,6 +2,9 @@
 // backward, weight layout transforms, and the flat-arena optimisers.  wave64 everywhere; 16-byte accesses.
 #include <math.h>
 
+#include <algorithm>
+#include <type_traits>
+
 #include "ps_internal.h"
 
 namespace {
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256) void conv1a_kernel(const float* __restrict__ x
 // storage type, instead of 7 exact-f32 16x16x4 MFMAs: the f32 form is matrix-pipe-bound (28 x 32 cycles per 16 pixels, 330 us at
 // bs = 64), this one leaves only the 64-channel store stream.  Lane (g, col) supplies k = 8g .. 8g+7 of weight row cout(f, col)
 // and of pixel col's im2col row.
-template <typename T, bool F16>
+template <typename T, bool F16, bool RAW, bool ACT>  // RAW / ACT: which outputs exist (compile time: see the loop)
 __global__ __launch_bounds__(256) void conv1a_lowp_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           T* __restrict__ out_act, T* __restrict__ out_raw, int n, int h, int wd,
@@ -100,53 +103,61 @@ __global__ __launch_bounds__(256) void conv1a_lowp_kernel(const float* __restric
       wa[f][e] = static_cast<T>(k < 27 ? w[co * 27 + k] : 0.f);
     }
   }
-  float sc[16], sh[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    sc[i] = scale ? scale[16 * g + i] : 1.f;
-    sh[i] = shift ? shift[16 * g + i] : 0.f;
+  // Registers decide how many waves hide this kernel's memory latency (it was 140 -> 3 waves per SIMD): the BN scale / shift rows
+  // (32 values per lane) live in LDS and are re-read in every group's epilogue, and a tap's validity is 6 flag bits, not two shifts.
+  __shared__ __attribute__((aligned(16))) float s_aff[2][64];
+  if (threadIdx.x < 64) {
+    s_aff[0][threadIdx.x] = scale ? scale[threadIdx.x] : 1.f;
+    s_aff[1][threadIdx.x] = shift ? shift[threadIdx.x] : 0.f;
   }
-  int toff[8], tdy[8], tdx[8];
+  __syncthreads();
+  // this lane's 8 taps k = 8g + e -> (c, ky, kx): byte offset relative to the centre pixel of channel 0, and flags naming the pixel
+  // conditions under which the tap is padding: bit 0 top row, 1 bottom row, 2 first column, 3 last column, 4 always (k >= 27),
+  // 5 pixel past the end of the batch
+  int tapoff[8];
+  unsigned long long tapflags = 0;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int k = 8 * g + e, c = k / 9, r = k - 9 * c, ky = r / 3, kx = r - 3 * ky;
-    tdy[e] = k < 27 ? ky - 1 : (1 << 20);
-    tdx[e] = kx - 1;
-    toff[e] = c * h * wd;
+    tapoff[e] = (c * h * wd + (ky - 1) * wd + (kx - 1)) * 4;
+    const unsigned f = (ky == 0 ? 1u : 0u) | (ky == 2 ? 2u : 0u) | (kx == 0 ? 4u : 0u) | (kx == 2 ? 8u : 0u) | (k >= 27 ? 16u : 0u) | 32u;
+    tapflags |= (unsigned long long)f << (8 * e);
   }
-  // (pixel indices fit 31 bits: checked by the launcher; the decomposition pixel -> (image, y, x) is two magic-number divisions -- as
-  // plain `/` on a 64-bit index it was several hundred VALU instructions per 16 pixels, more than everything else in the loop)
+  // (pixel indices and image byte offsets fit 31 bits: checked by the launcher.  The decomposition pixel -> (image, y, x) is two
+  // magic-number divisions, and the taps are fetched through a buffer descriptor with 32-bit offsets: an invalid tap -- zero padding,
+  // k >= 27, a pixel past the end -- gets an offset outside the descriptor and arrives as 0.0 without a select.  Written with `/` on a
+  // 64-bit index, 64-bit addresses and a validity mask the gather was ~35 VALU instructions per tap.)
   const int total = n * h * wd;
   const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
-  // The NEXT 16 pixels' taps are loaded before this group's stores are issued (loads are unconditional on clamped coordinates; the
-  // validity bits zero the padding afterwards): vmcnt is one in-order queue, a load issued behind the stores would wait for them.
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, total * 12, 0x00020000);
+  // The NEXT 16 pixels' taps are loaded before this group's stores are issued: vmcnt is one in-order queue, a load issued behind the
+  // stores would wait for them.
   float raw[8];
-  unsigned vmask = 0;
   auto gather = [&](int p0) {
     const int pix = p0 + col;
     const bool live = pix < total;
-    const int img = live ? (int)fdiv((uint32_t)pix, div_hw) : 0;
-    const int rem = live ? pix - img * h * wd : 0;
+    const int img = (int)fdiv((uint32_t)pix, div_hw);
+    const int rem = pix - img * h * wd;
     const int y = (int)fdiv((uint32_t)rem, div_w), xx = rem - y * wd;
-    const float* xb = x + (long long)img * 3 * h * wd;
-    vmask = 0;
+    const int centre = (img * 3 * h * wd + rem) * 4;
+    const unsigned pm = (y == 0 ? 1u : 0u) | (y == h - 1 ? 2u : 0u) | (xx == 0 ? 4u : 0u) | (xx == wd - 1 ? 8u : 0u) | 16u | (live ? 0u : 32u);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int yy = y + tdy[e], xs = xx + tdx[e];
-      const bool ok = live && yy >= 0 && yy < h && xs >= 0 && xs < wd;
-      raw[e] = xb[ok ? toff[e] + yy * wd + xs : 0];  // (k >= 27 and padding taps read the image's first element, masked off)
-      vmask |= (ok ? 1u : 0u) << e;
+      const unsigned bad = (unsigned)(tapflags >> (8 * e)) & pm;  // branch-free: a padding tap gets an offset outside the descriptor
+      raw[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsx, (centre + tapoff[e]) | (bad ? (int)0x80000000 : 0), 0, 0));
     }
   };
-  gather(wave_id * 16);
-  for (long long p0l = (long long)wave_id * 16; p0l < total; p0l += (long long)nwaves * 16) {
-    const int p0 = (int)p0l;
-    const long long pix = p0l + col;
-    const bool live = pix < total;
+  // One group of 16 pixels.  FULL groups store unconditionally and the outputs are template flags, so that the number of stores behind
+  // the next group's loads is a compile-time constant and the wait at the top of the next iteration is a counted `vmcnt(stores)`:
+  // with run-time `if (out_raw)` / `if (live)` around the stores hipcc could only write `vmcnt(0)` there, i.e. every iteration
+  // waited for its own stores to be acknowledged.  Only the last group of the launch can be partial; it takes the predicated copy.
+  // (Store shape: a lane writes the two 16-byte chunks it holds of its pixel's 128-byte row.  Swapping chunks between lanes so that an
+  // instruction writes eight WHOLE rows -- 1 KiB contiguous -- was measured twice and is 50 % slower: 237 vs 156 us.)
+  auto group = [&](auto full, int p0, int pnext) {
     t8 bv;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = static_cast<T>((vmask >> e) & 1u ? raw[e] : 0.f);
-    gather(p0l + (long long)nwaves * 16 < total ? p0 + nwaves * 16 : p0);  // (the last group re-reads itself)
+    for (int e = 0; e < 8; ++e) bv[e] = static_cast<T>(raw[e]);
+    gather(pnext);
     f32x4 acc[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -154,23 +165,48 @@ __global__ __launch_bounds__(256) void conv1a_lowp_kernel(const float* __restric
       if constexpr (F16) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wa[f]), __builtin_bit_cast(f16x8, bv), acc[f], 0, 0, 0);
       else acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[f]), __builtin_bit_cast(bf16x8, bv), acc[f], 0, 0, 0);
     }
-    if (!live) continue;
+    const long long pix = (long long)p0 + col;
+    const bool live = decltype(full)::value || pix < total;
     float v[16];
 #pragma unroll
     for (int f = 0; f < 4; ++f)
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[4 * f + r] = acc[f][r];
-    if (out_raw) {
-      ps_store8<T>(out_raw + pix * 64 + 16 * g, v);
-      ps_store8<T>(out_raw + pix * 64 + 16 * g + 8, v + 8);
+    if constexpr (RAW) {
+      if (live) {
+        ps_store8<T>(out_raw + pix * 64 + 16 * g, v);
+        ps_store8<T>(out_raw + pix * 64 + 16 * g + 8, v + 8);
+      }
     }
-    if (out_act) {
+    if constexpr (ACT) {
+      int z;
+      asm volatile("s_mov_b32 %0, 0" : "=s"(z));  // opaque zero: keeps the 32 affine values out of registers across the loop
+      const float4* af = reinterpret_cast<const float4*>(&s_aff[0][16 * g + z]);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i] * sc[i] + sh[i], 0.f);
-      ps_store8<T>(out_act + pix * 64 + 16 * g, v);
-      ps_store8<T>(out_act + pix * 64 + 16 * g + 8, v + 8);
+      for (int i = 0; i < 4; ++i) {
+        const float4 a = af[i], b = af[16 + i];
+        v[4 * i + 0] = fmaxf(v[4 * i + 0] * a.x + b.x, 0.f);
+        v[4 * i + 1] = fmaxf(v[4 * i + 1] * a.y + b.y, 0.f);
+        v[4 * i + 2] = fmaxf(v[4 * i + 2] * a.z + b.z, 0.f);
+        v[4 * i + 3] = fmaxf(v[4 * i + 3] * a.w + b.w, 0.f);
+      }
+      if (live) {
+        ps_store8<T>(out_act + pix * 64 + 16 * g, v);
+        ps_store8<T>(out_act + pix * 64 + 16 * g + 8, v + 8);
+      }
     }
+  };
+  const int stride = nwaves * 16;
+  int p0 = wave_id * 16;
+  gather(p0);
+  auto next_of = [&](int p) { return p + stride < total ? p + stride : p; };  // (the last group re-reads itself)
+  if (p0 + 16 <= total) {
+    // first group peeled: the loop header then sees the same queue (8 loads, then this group's stores) from the entry as from the
+    // back edge -- merged with an entry that has no stores behind the loads, the wait would again be vmcnt(0)
+    group(std::true_type{}, p0, next_of(p0));
+    for (p0 += stride; p0 + 16 <= total; p0 += stride) group(std::true_type{}, p0, next_of(p0));
   }
+  if (p0 < total) group(std::false_type{}, p0, p0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -620,15 +656,27 @@ extern "C" int ps_conv1a_fwd(int32_t out_dtype, const float* x, const float* w, 
   PS_REQUIRE((!out_act || ps_aligned16(out_act)) && (!out_raw || ps_aligned16(out_raw)), "conv1a: misaligned output");
   const long long pix = (long long)n * h * wd;
   PS_REQUIRE((long long)3 * h * wd < (1LL << 31), "conv1a: image too large");
-  PS_REQUIRE(pix < (1LL << 31) - 16, "conv1a: more than 2^31 pixels in one launch");
+  PS_REQUIRE(pix * 12 < (1LL << 31) - 64, "conv1a: image batch of 2 GiB or more in one launch");
   const FastDiv div_hw = make_fastdiv((uint32_t)(h * wd)), div_w = make_fastdiv((uint32_t)wd);
   const int grid = grid_for(pix, 64, 256 * 8);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (out_dtype == PS_BF16)
-    hipLaunchKernelGGL((conv1a_lowp_kernel<__bf16, false>), dim3(grid), dim3(256), 0, s, x, w, scale, shift, (__bf16*)out_act, (__bf16*)out_raw, n, h, wd, div_hw, div_w);
-  else if (out_dtype == PS_F16)
-    hipLaunchKernelGGL((conv1a_lowp_kernel<_Float16, true>), dim3(grid), dim3(256), 0, s, x, w, scale, shift, (_Float16*)out_act, (_Float16*)out_raw, n, h, wd, div_hw, div_w);
-  else if (out_dtype == PS_F32)
+  // the 16-bit kernels walk the pixels with a grid stride: exactly the resident blocks (one round, equal shares) -- the fixed cap of
+  // 2048 blocks was 2.67 rounds of the 3 blocks a CU held
+  auto lowp = [&](auto kernel, auto* oa, auto* orw) {
+    static const int bpc = ps_blocks_per_cu(kernel);
+    hipLaunchKernelGGL(kernel, dim3(std::min(grid, ps_num_cus() * bpc)), dim3(256), 0, s, x, w, scale, shift, oa, orw, n, h, wd, div_hw, div_w);
+  };
+  if (out_dtype == PS_BF16) {
+    __bf16 *oa = (__bf16*)out_act, *orw = (__bf16*)out_raw;
+    if (oa && orw) lowp(conv1a_lowp_kernel<__bf16, false, true, true>, oa, orw);
+    else if (oa) lowp(conv1a_lowp_kernel<__bf16, false, false, true>, oa, orw);
+    else lowp(conv1a_lowp_kernel<__bf16, false, true, false>, oa, orw);
+  } else if (out_dtype == PS_F16) {
+    _Float16 *oa = (_Float16*)out_act, *orw = (_Float16*)out_raw;
+    if (oa && orw) lowp(conv1a_lowp_kernel<_Float16, true, true, true>, oa, orw);
+    else if (oa) lowp(conv1a_lowp_kernel<_Float16, true, false, true>, oa, orw);
+    else lowp(conv1a_lowp_kernel<_Float16, true, true, false>, oa, orw);
+  } else if (out_dtype == PS_F32)
     hipLaunchKernelGGL(conv1a_kernel<float>, dim3(grid), dim3(256), 0, s, x, w, scale, shift, (float*)out_act, (float*)out_raw, n, h, wd);
   else
     PS_REQUIRE(false, "conv1a: dtype %d unsupported", out_dtype);
