@@ -80,7 +80,8 @@ def build_variant(tag: str, defines, verbose: bool = True) -> str:
     """An A/B build of the debug library with extra -D defines: pistoseg_amd/libpistoseg_hip_debug_<tag>.so (load it with
     PISTOSEG_HIP_DEBUG_LIB=<path>).  Optimisation harness only."""
     lib = os.path.join(HERE, f"libpistoseg_hip_debug_{tag}.so")
-    return _build_one(lib, os.path.join(HERE, "build", "ab_" + tag), ["-DPS_DEBUG_HOOKS", *[f"-D{d}" for d in defines]], False, verbose)
+    extra = [d if d.startswith("-") else f"-D{d}" for d in defines]  # NAME=VALUE -> -DNAME=VALUE; anything starting with '-' is a raw compiler flag
+    return _build_one(lib, os.path.join(HERE, "build", "ab_" + tag), ["-DPS_DEBUG_HOOKS", *extra], False, verbose)
 
 
 if __name__ == "__main__":
