@@ -3,6 +3,8 @@
 // wavefront (64-lane) shuffles for the reductions.
 #include <math.h>
 
+#include <algorithm>
+
 #include "ps_internal.h"
 
 namespace {
@@ -113,6 +115,71 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T4 dd, const T4
         if (lane == 0) t4_store(ds, (long long)n * ds.sn + (long long)(c0 + c) * ds.sc + (long long)iy * ds.sh + (long long)ix * ds.sw, s);
       }
     }
+  }
+}
+
+// Separable form of the same sum for destination rows of up to 1024 pixels: one block per SOURCE ROW (n, iy).  Pass 1 -- the threads own
+// destination columns and fold the destination rows whose footprint touches iy into per-column sums (row weights are block-uniform;
+// NCHW gradients are read along x, coalesced, each row by the two source rows it feeds); pass 2 -- one thread per (ix, c) folds its
+// window of column sums from LDS.  Deterministic; reads the gradient ~2x instead of the ~7x (three quarters of them weight-zero
+// candidates) of the wave-per-source-pixel form.
+// The row loop is branch-free and unrolled -- rows past the end are clamped and weigh 0 like the window's slack rows, the channel count
+// of a chunk and the gradient's dtype are template arguments -- so that the loads of several rows are in flight together: with a
+// `continue` per row and a run-time `if (c < channels)` around every load each load sat in its own basic block and the block paid
+// one memory latency per LOAD (63 of them: 47 us; measured by ablation, pass 2 is 9 us).
+constexpr int BWD_MAXC = 8, BWD_SLOTS = 4;
+template <int DDT, int CC>
+__global__ __launch_bounds__(256) void bilinear_bwd_rows_kernel(const T4 dd, const T4 ds, int align, float sy, float sx, int wy, int wx) {
+  extern __shared__ float cols[];  // [channel of the chunk][dd.w]
+  const int tid = threadIdx.x;
+  const int iy = (int)(blockIdx.x % (unsigned)ds.h), n = (int)(blockIdx.x / (unsigned)ds.h);
+  const float hb = align ? 0.f : 0.5f;
+  const float inv_y = sy > 0.f ? 1.f / sy : 0.f, inv_x = sx > 0.f ? 1.f / sx : 0.f;
+  const int oy_lo = sy > 0.f ? max(0, (int)floorf(((float)iy - 1.f + hb) * inv_y - hb) - 1) : 0;
+  for (int c0 = 0; c0 < ds.c; c0 += CC) {  // (a last partial chunk re-reads the last channel and does not store the copies)
+    for (int ox0 = 0; ox0 < dd.w; ox0 += 256) {
+      const int ox = ox0 + tid;
+      const long long ocol = (long long)n * dd.sn + (long long)min(ox, dd.w - 1) * dd.sw;
+      long long och[CC];
+#pragma unroll
+      for (int c = 0; c < CC; ++c) och[c] = ocol + (long long)min(c0 + c, ds.c - 1) * dd.sc;
+      float acc[CC];
+#pragma unroll
+      for (int c = 0; c < CC; ++c) acc[c] = 0.f;
+#pragma unroll 4
+      for (int r = 0; r < wy; ++r) {
+        const int oyr = oy_lo + r, oy = min(oyr, dd.h - 1);
+        int y0, y1;
+        float ly0, ly1;
+        interp_index(sy, oy, ds.h, align, y0, y1, ly0, ly1);
+        const float wyv = oyr < dd.h ? (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f) : 0.f;
+        const long long orow = (long long)oy * dd.sh;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) acc[c] = fmaf(wyv, ps_ld_dt(dd.ptr, DDT, och[c] + orow), acc[c]);
+      }
+      if (ox < dd.w) {
+#pragma unroll
+        for (int c = 0; c < CC; ++c) cols[c * dd.w + ox] = acc[c];
+      }
+    }
+    __syncthreads();
+    const int cc = min(CC, ds.c - c0);
+    for (int j = tid; j < ds.w * cc; j += 256) {
+      const int ix = j / cc, c = j - ix * cc;
+      const int ox_lo = sx > 0.f ? max(0, (int)floorf(((float)ix - 1.f + hb) * inv_x - hb) - 1) : 0;
+      float sum = 0.f;
+      for (int k = 0; k < wx; ++k) {
+        const int ox = ox_lo + k;
+        if (ox >= dd.w) break;
+        int x0, x1;
+        float lx0, lx1;
+        interp_index(sx, ox, ds.w, align, x0, x1, lx0, lx1);
+        const float wxv = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+        sum = fmaf(wxv, cols[c * dd.w + ox], sum);
+      }
+      t4_store(ds, (long long)n * ds.sn + (long long)(c0 + c) * ds.sc + (long long)iy * ds.sh + (long long)ix * ds.sw, sum);
+    }
+    __syncthreads();
   }
 }
 
@@ -360,6 +427,31 @@ extern "C" int ps_bilinear_bwd(const ps_tensor4* ddst, const ps_tensor4* dsrc, i
   // window of destination pixels per source pixel: ~2/scale (+ slack for the floor/ceil and rounding)
   const int wy = sy > 0.f ? (int)ceilf(2.f / sy) + 4 : ddst->h;
   const int wx = sx > 0.f ? (int)ceilf(2.f / sx) + 4 : ddst->w;
+  const long long rows = (long long)dsrc->n * dsrc->h;
+  if (ddst->w <= 256 * BWD_SLOTS && rows < (1LL << 31)) {
+    const size_t lds = (size_t)std::min<int>(BWD_MAXC, dsrc->c) * ddst->w * sizeof(float);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const T4 a = to_t4(ddst), b = to_t4(dsrc);
+#define PS_BIL_ROWS(DT, CC) hipLaunchKernelGGL((bilinear_bwd_rows_kernel<DT, CC>), dim3((unsigned)rows), dim3(256), lds, st, a, b, align, sy, sx, wy, wx)
+#define PS_BIL_ROWS_C(DT)                                                                                   \
+  switch (std::min<int>(BWD_MAXC, dsrc->c)) {                                                              \
+    case 1: PS_BIL_ROWS(DT, 1); break;                                                                     \
+    case 2: PS_BIL_ROWS(DT, 2); break;                                                                     \
+    case 3: PS_BIL_ROWS(DT, 3); break;                                                                     \
+    case 4: PS_BIL_ROWS(DT, 4); break;                                                                     \
+    case 5: PS_BIL_ROWS(DT, 5); break;                                                                     \
+    case 6: PS_BIL_ROWS(DT, 6); break;                                                                     \
+    case 7: PS_BIL_ROWS(DT, 7); break;                                                                     \
+    default: PS_BIL_ROWS(DT, 8); break;                                                                    \
+  }
+    if (ddst->dtype == PS_F32) { PS_BIL_ROWS_C(PS_F32) }
+    else if (ddst->dtype == PS_BF16) { PS_BIL_ROWS_C(PS_BF16) }
+    else { PS_BIL_ROWS_C(PS_F16) }
+#undef PS_BIL_ROWS_C
+#undef PS_BIL_ROWS
+    PS_CHECK_LAUNCH("bilinear_bwd_rows");
+    return PS_OK;
+  }
   const long long waves = (long long)dsrc->n * dsrc->h * dsrc->w;
   PS_REQUIRE((waves + 3) / 4 < (1LL << 31), "bilinear_bwd: too many source pixels");
   hipLaunchKernelGGL(bilinear_bwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), to_t4(ddst),

@@ -230,7 +230,8 @@ def test_conv1a_and_fc8(dtype):
 
 
 @pytest.mark.parametrize("align", [True, False])
-@pytest.mark.parametrize("sizes", [((28, 28), (224, 224)), ((32, 32), (28, 28)), ((7, 9), (40, 33)), ((224, 224), (32, 32)), ((256, 256), (32, 32)), ((5, 5), (5, 5))])
+@pytest.mark.parametrize("sizes", [((28, 28), (224, 224)), ((32, 32), (28, 28)), ((7, 9), (40, 33)), ((224, 224), (32, 32)), ((256, 256), (32, 32)), ((5, 5), (5, 5)),
+                                   ((3, 5), (4, 1100))])  # (destination rows above 1024 pixels: the wave-per-source-pixel backward)
 def test_bilinear_fwd_bwd(sizes, align):
     from pistoseg_amd import ops
 
