@@ -275,6 +275,27 @@ def test_softmax_ce(ignore):
         assert float(dl.cpu().permute(0, 2, 3, 1)[tgt == ignore].abs().max()) == 0.0
 
 
+def test_ce_and_argmax_run_time_channel_count():
+    """C = 2..5 are compile-time instantiations of the CE / argmax kernels (a pixel's values loaded once); any other count takes the
+    run-time loops: same results."""
+    from pistoseg_amd import _lib, ops
+
+    D = dev()
+    g = torch.Generator().manual_seed(77)
+    for c in (7, 1, 5):
+        logits = (torch.randn(2, c, 19, 23, generator=g) * 3).requires_grad_(True)
+        tgt = torch.randint(0, c + 1, (2, 19, 23), generator=g)
+        loss = F.cross_entropy(logits, tgt, ignore_index=c)  # mean over kept pixels ...
+        kept = (tgt != c).sum()
+        (loss * kept / tgt.numel()).backward()               # ... the kernel's mean is over ALL pixels (segmentation_module.py:97-98)
+        l, dl = ops.softmax_ce(logits.detach().to(D), tgt.to(D), c, want_grad=True)
+        assert abs(float(l) - float(loss * kept / tgt.numel())) <= 1e-5 * abs(float(loss)) + 1e-7
+        assert rel_err(dl.cpu(), logits.grad) < 1e-5 or float(logits.grad.abs().max()) == 0.0
+        x = logits.detach()
+        assert torch.equal(torch.argmax(x, dim=1).byte(), ops.argmax_mask(x.to(D), mode=_lib.PS_MASK_PLAIN).cpu())
+        assert torch.equal(torch.argmax(torch.softmax(x, 1), dim=1).byte(), ops.argmax_mask(x.to(D), mode=_lib.PS_MASK_PLAIN, softmax_first=True).cpu())
+
+
 def test_argmax_modes_match_oracle(golden_dir):
     """Mask indices are bit-exact against the oracle / reference goldens on identical inputs."""
     from oracle import ref_cpu
