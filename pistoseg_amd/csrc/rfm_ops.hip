@@ -80,6 +80,106 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmArgs a) {
       }
 }
 
+// The same GEMM, same tile, same order of the K sum (bit-identical results), for operands that can be staged in 4-element vectors
+// (one of (m, k) resp. (k, n) contiguous, extents / strides / pointers multiples of 4 elements; dtypes at compile time): 32-deep K steps,
+// the NEXT step's global vectors are in registers while this step's MFMAs run, two LDS buffers and one barrier per step.  The
+// element-wise version above stages through a generic accessor (a dtype switch per load: one load per basic block) with
+// two barriers per 16 MFMAs: 213 us per launch of the affinity products at bs = 32, this one see profiles/.
+template <int DT>
+__device__ __forceinline__ float4 bg_load4(const unsigned char* p, long long i) {  // 4 consecutive elements from element index i
+  if constexpr (DT == PS_F32) {
+    return *reinterpret_cast<const float4*>(p + i * 4);
+  } else {
+    const uint2 r = *reinterpret_cast<const uint2*>(p + i * 2);
+    if constexpr (DT == PS_BF16)
+      return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+    else
+      return make_float4(ps_f16_to_f32((uint16_t)(r.x & 0xffff)), ps_f16_to_f32((uint16_t)(r.x >> 16)), ps_f16_to_f32((uint16_t)(r.y & 0xffff)),
+                         ps_f16_to_f32((uint16_t)(r.y >> 16)));
+  }
+}
+template <int ADT, int BDT>
+__global__ __launch_bounds__(256) void bgemm_vec_kernel(const BgemmArgs a) {
+  constexpr int KS = 32, LD = 80;
+  __shared__ __attribute__((aligned(16))) float As[2][KS][LD], Bs[2][KS][LD];
+  const int b = blockIdx.z, m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, l16 = lane & 15, g = lane >> 4;
+  const unsigned char* Ab = static_cast<const unsigned char*>(a.A);
+  const unsigned char* Bb = static_cast<const unsigned char*>(a.B);
+  const bool a_kfast = a.sak == 1, b_kfast = a.sbk == 1;
+  // this thread's two vectors per operand: (row in the 64-wide tile side, k offset in the step); the 4 elements run along k or along m / n
+  int am[2], ak[2], bn[2], bk[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + 256 * u;
+    if (a_kfast) { ak[u] = (e & 7) * 4; am[u] = e >> 3; } else { am[u] = (e & 15) * 4; ak[u] = e >> 4; }
+    if (b_kfast) { bk[u] = (e & 7) * 4; bn[u] = e >> 3; } else { bn[u] = (e & 15) * 4; bk[u] = e >> 4; }
+  }
+  float4 ra[2], rb[2];
+  auto load_regs = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int m = m0 + am[u], k = k0 + ak[u];
+      ra[u] = (m < a.M && k < a.K) ? bg_load4<ADT>(Ab, b * a.sab + m * a.sam + k * a.sak) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int n = n0 + bn[u], k2 = k0 + bk[u];
+      rb[u] = (n < a.N && k2 < a.K) ? bg_load4<BDT>(Bb, b * a.sbb + k2 * a.sbk + n * a.sbn) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (a_kfast) {
+        As[buf][ak[u] + 0][am[u]] = ra[u].x; As[buf][ak[u] + 1][am[u]] = ra[u].y; As[buf][ak[u] + 2][am[u]] = ra[u].z; As[buf][ak[u] + 3][am[u]] = ra[u].w;
+      } else {
+        *reinterpret_cast<float4*>(&As[buf][ak[u]][am[u]]) = ra[u];
+      }
+      if (b_kfast) {
+        Bs[buf][bk[u] + 0][bn[u]] = rb[u].x; Bs[buf][bk[u] + 1][bn[u]] = rb[u].y; Bs[buf][bk[u] + 2][bn[u]] = rb[u].z; Bs[buf][bk[u] + 3][bn[u]] = rb[u].w;
+      } else {
+        *reinterpret_cast<float4*>(&Bs[buf][bk[u]][bn[u]]) = rb[u];
+      }
+    }
+  };
+  bg_f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = bg_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nk = (a.K + KS - 1) / KS;
+  load_regs(0);
+  store_lds(0);
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int buf = ks & 1;
+    if (ks + 1 < nk) load_regs((ks + 1) * KS);
+#pragma unroll
+    for (int k4 = 0; k4 < KS / 4; ++k4) {
+      float av[2], bv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        av[i] = As[buf][4 * k4 + g][wm * 32 + i * 16 + l16];
+        bv[i] = Bs[buf][4 * k4 + g][wn * 32 + i * 16 + l16];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (ks + 1 < nk) store_lds(buf ^ 1);  // (every wave left that buffer before the previous barrier)
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 32 + i * 16 + 4 * g + r, n = n0 + wn * 32 + j * 16 + l16;
+        if (m < a.M && n < a.N) st(a.C, a.cdt, b * a.scb + m * a.scm + n * a.scn, a.alpha * acc[i][j][r]);
+      }
+}
+
 // in-place softmax of rows of length len (one wave per row)
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, long long rows, int len) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -96,55 +196,66 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x
   for (int i = lane; i < len; i += 64) r[i] = expf(r[i] - mx) * inv;
 }
 
-// R[n,j,cc] = sum_i P[n][j][i] * V[n,i,cc]     (one wave per (n,j); cc <= 24)
+// Channel loops of the two affinity kernels: the maps' channel count cc = 3 x classes is a template argument for 9 / 12 / 15 (CT > 0: a
+// pixel's V row is loaded back to back), any other count up to RFM_MAXCC takes the predicated form (CT == 0: `if (c < cc)` puts every
+// load into its own basic block, where it is consumed before the next is issued -- one L1 latency per load).
 constexpr int RFM_MAXCC = 24;
+template <int CT, class F>
+__device__ __forceinline__ void for_cc(int cc, F&& f) {
+  if constexpr (CT > 0) {
+#pragma unroll
+    for (int c = 0; c < CT; ++c) f(c);
+  } else {
+#pragma unroll
+    for (int c = 0; c < RFM_MAXCC; ++c)
+      if (c < cc) f(c);
+  }
+}
+
+// R[n,j,cc] = sum_i P[n][j][i] * V[n,i,cc]     (one wave per (n,j); cc <= 24)
+template <int CT>
 __global__ __launch_bounds__(256) void rfm_apply_kernel(const float* __restrict__ P, const float* __restrict__ V, float* __restrict__ R,
-                                                        long long rows, int np, int cc) {
+                                                        long long rows, int np, int cc_rt) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  const int cc = CT ? CT : cc_rt;
   const int lane = threadIdx.x & 63;
   const long long n = row / np;
   const float* p = P + row * np;
   const float* v = V + n * np * cc;
-  float acc[RFM_MAXCC];
-#pragma unroll
-  for (int c = 0; c < RFM_MAXCC; ++c) acc[c] = 0.f;
+  float acc[CT ? CT : RFM_MAXCC];
+  for_cc<CT>(cc, [&](int c) { acc[c] = 0.f; });
   for (int i = lane; i < np; i += 64) {
     const float pv = p[i];
-#pragma unroll
-    for (int c = 0; c < RFM_MAXCC; ++c)
-      if (c < cc) acc[c] = fmaf(pv, v[(long long)i * cc + c], acc[c]);
+    const float* vi = v + (long long)i * cc;
+    for_cc<CT>(cc, [&](int c) { acc[c] = fmaf(pv, vi[c], acc[c]); });
   }
-#pragma unroll
-  for (int c = 0; c < RFM_MAXCC; ++c)
-    if (c < cc) {
-      const float s = ps_wave_sum(acc[c]);
-      if (lane == 0) R[row * cc + c] = s;
-    }
+  for_cc<CT>(cc, [&](int c) {
+    const float s = ps_wave_sum(acc[c]);
+    if (lane == 0) R[row * cc + c] = s;
+  });
 }
 
 // dS[n][j][i] = P[n][j][i] * (sum_c dR[n,j,c]*V[n,i,c] - sum_c dR[n,j,c]*R[n,j,c])   (in place over P)
+template <int CT>
 __global__ __launch_bounds__(256) void affinity_softmax_bwd_kernel(float* __restrict__ P, const float* __restrict__ dR,
                                                                    const float* __restrict__ V, const float* __restrict__ R,
-                                                                   long long rows, int np, int cc) {
+                                                                   long long rows, int np, int cc_rt) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  const int cc = CT ? CT : cc_rt;
   const int lane = threadIdx.x & 63;
   const long long n = row / np;
-  float g[RFM_MAXCC];
+  float g[CT ? CT : RFM_MAXCC];
   float dot = 0.f;
-#pragma unroll
-  for (int c = 0; c < RFM_MAXCC; ++c) {
-    g[c] = c < cc ? dR[row * cc + c] : 0.f;
-    if (c < cc) dot = fmaf(g[c], R[row * cc + c], dot);
-  }
+  for_cc<CT>(cc, [&](int c) { g[c] = dR[row * cc + c]; });
+  for_cc<CT>(cc, [&](int c) { dot = fmaf(g[c], R[row * cc + c], dot); });
   float* p = P + row * np;
   const float* v = V + n * np * cc;
   for (int i = lane; i < np; i += 64) {
+    const float* vi = v + (long long)i * cc;
     float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < RFM_MAXCC; ++c)
-      if (c < cc) s = fmaf(g[c], v[(long long)i * cc + c], s);
+    for_cc<CT>(cc, [&](int c) { s = fmaf(g[c], vi[c], s); });
     p[i] = p[i] * (s - dot);
   }
 }
@@ -389,23 +500,38 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restri
 // histograms of the earlier passes (a 256-entry scan), a fifth launch sums the selected values per block and a last one adds the
 // partial sums in block order (deterministic) and writes thr / take / sums.
 struct TopkState { uint32_t prefix, remaining; };
-// Block-cooperative: the finished histograms of the passes above `upto_pass` are copied into LDS by 256 threads each, thread 0 walks
-// them there (a single thread walking them in global memory cost ~50 us of dependent loads per launch).  All threads must call it;
-// returns the state to every thread.  lds: 256 uints + 2.
+// Block-cooperative (blocks of >= 256 threads; all threads must call it; returns the state to every thread): for each pass already
+// histogrammed, threads 0..255 scan the 256 bins in parallel (wave-level inclusive scan + the four wave totals through LDS) and the one
+// thread whose bin holds the k-th remaining key publishes bin and remainder.  A single thread walking the bins -- one dependent LDS
+// load per bin, up to 256 per pass, up to four passes per launch -- was most of every launch of this family (19-34 us each for
+// 5 us of data).  lds: TOPK_LDS uints.
+constexpr int TOPK_LDS = 264;
 __device__ __forceinline__ TopkState topk_state(const unsigned* __restrict__ ghist /* [4][256] of this row */, int k, int upto_pass, unsigned* lds) {
-  if (threadIdx.x == 0) { lds[256] = 0u; lds[257] = (unsigned)k; }
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) { lds[256] = 0u; lds[257] = (unsigned)k; }
   for (int pass = 3; pass > upto_pass; --pass) {  // passes already histogrammed
     __syncthreads();
-    if (threadIdx.x < 256) lds[threadIdx.x] = ghist[pass * 256 + threadIdx.x];
+    const unsigned c = tid < 256 ? ghist[pass * 256 + tid] : 0u;
+    unsigned incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned t = __shfl_up(incl, d);
+      if (lane >= d) incl += t;
+    }
+    if (tid < 256 && lane == 63) lds[260 + (tid >> 6)] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned rem = lds[257], b = 0;
-      for (; b < 256; ++b) {
-        if (lds[b] >= rem) break;
-        rem -= lds[b];
+    if (tid < 256) {
+      for (int w = 0; w < (tid >> 6); ++w) incl += lds[260 + w];
+      const unsigned rem = lds[257];
+      if (incl >= rem && incl - c < rem) {  // exactly one bin (k <= row length): the first whose running count reaches rem
+        lds[258] = (unsigned)tid;
+        lds[259] = rem - (incl - c);
       }
-      lds[256] |= b << (8 * pass);
-      lds[257] = rem;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      lds[256] |= lds[258] << (8 * pass);
+      lds[257] = lds[259];
     }
   }
   __syncthreads();
@@ -416,7 +542,7 @@ __device__ __forceinline__ TopkState topk_state(const unsigned* __restrict__ ghi
 __global__ __launch_bounds__(1024) void topk_hist_kernel(const float* __restrict__ x, long long row_len, long long chunk, int k, int largest, int pass,
                                                          unsigned* __restrict__ ghist) {
   __shared__ unsigned int hist[256];
-  __shared__ unsigned int st_lds[258];
+  __shared__ unsigned int st_lds[TOPK_LDS];
   const int row = blockIdx.y;
   const float* r = x + (long long)row * row_len;
   unsigned* gh = ghist + (long long)row * 1024;
@@ -443,7 +569,7 @@ __global__ __launch_bounds__(1024) void topk_hist_kernel(const float* __restrict
 }
 __global__ __launch_bounds__(1024) void topk_sum_kernel(const float* __restrict__ x, long long row_len, long long chunk, int k, int largest, int relu,
                                                         const unsigned* __restrict__ ghist, float* __restrict__ partial) {
-  __shared__ unsigned int st_lds[258];
+  __shared__ unsigned int st_lds[TOPK_LDS];
   __shared__ float red[16];
   const int row = blockIdx.y;
   const float* r = x + (long long)row * row_len;
@@ -465,7 +591,7 @@ __global__ __launch_bounds__(1024) void topk_sum_kernel(const float* __restrict_
 }
 __global__ __launch_bounds__(256) void topk_finish_kernel(const unsigned* __restrict__ ghist, const float* __restrict__ partial, int nblk, int k,
                                                           int largest, int relu, float* __restrict__ thr, int* __restrict__ take, float* __restrict__ sums) {
-  __shared__ unsigned int st_lds[258];
+  __shared__ unsigned int st_lds[TOPK_LDS];
   const int row = blockIdx.x;  // one block per row
   const TopkState st = topk_state(ghist + (long long)row * 1024, k, -1, st_lds);
   if (threadIdx.x != 0) return;
@@ -572,7 +698,21 @@ extern "C" int ps_bgemm(int32_t adt, int32_t bdt, int32_t cdt, const void* A, co
   PS_REQUIRE(A && B && C && batch > 0 && M > 0 && N > 0 && K > 0, "bgemm: bad argument");
   PS_REQUIRE(batch <= 65535, "bgemm: batch %d too large", batch);
   BgemmArgs a{A, B, C, adt, bdt, cdt, batch, M, N, K, sab, sam, sak, sbb, sbk, sbn, scb, scm, scn, alpha};
-  hipLaunchKernelGGL(bgemm_kernel, dim3((N + 63) / 64, (M + 63) / 64, batch), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  const dim3 grid((N + 63) / 64, (M + 63) / 64, batch);
+  hipStream_t st_ = static_cast<hipStream_t>(stream);
+  // vector staging: K a multiple of 4, and per operand either k contiguous, or the other index contiguous with an extent that is a
+  // multiple of 4; every other stride and the base pointer a multiple of 4 elements (a vector is then entirely inside or outside)
+  auto vec_ok = [](const void* p, int dt, long long s_slow, long long s_batch) {
+    return reinterpret_cast<uintptr_t>(p) % (4 * ps_esize(dt)) == 0 && s_slow % 4 == 0 && s_batch % 4 == 0;
+  };
+  bool fast = K % 4 == 0 && (sak == 1 || (sam == 1 && M % 4 == 0)) && (sbk == 1 || (sbn == 1 && N % 4 == 0));
+  fast = fast && vec_ok(A, adt, sak == 1 ? sam : sak, sab) && vec_ok(B, bdt, sbk == 1 ? sbn : sbk, sbb);
+  if (fast && adt == PS_F32 && bdt == PS_F32) hipLaunchKernelGGL((bgemm_vec_kernel<PS_F32, PS_F32>), grid, dim3(256), 0, st_, a);
+  else if (fast && adt == PS_BF16 && bdt == PS_BF16) hipLaunchKernelGGL((bgemm_vec_kernel<PS_BF16, PS_BF16>), grid, dim3(256), 0, st_, a);
+  else if (fast && adt == PS_F32 && bdt == PS_BF16) hipLaunchKernelGGL((bgemm_vec_kernel<PS_F32, PS_BF16>), grid, dim3(256), 0, st_, a);
+  else if (fast && adt == PS_F16 && bdt == PS_F16) hipLaunchKernelGGL((bgemm_vec_kernel<PS_F16, PS_F16>), grid, dim3(256), 0, st_, a);
+  else if (fast && adt == PS_F32 && bdt == PS_F16) hipLaunchKernelGGL((bgemm_vec_kernel<PS_F32, PS_F16>), grid, dim3(256), 0, st_, a);
+  else hipLaunchKernelGGL(bgemm_kernel, grid, dim3(256), 0, st_, a);
   PS_CHECK_LAUNCH("bgemm");
   return PS_OK;
 }
@@ -587,7 +727,13 @@ extern "C" int ps_softmax_rows(float* x, int64_t rows, int32_t len, void* stream
 extern "C" int ps_rfm_apply(const float* P, const float* V, float* R, int32_t n, int32_t np, int32_t cc, void* stream) {
   PS_REQUIRE(P && V && R && n > 0 && np > 0 && cc > 0 && cc <= RFM_MAXCC, "rfm_apply: bad argument (cc <= %d)", RFM_MAXCC);
   const long long rows = (long long)n * np;
-  hipLaunchKernelGGL(rfm_apply_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), P, V, R, rows, np, cc);
+  auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), P, V, R, rows, np, cc); };
+  switch (cc) {
+    case 9: launch(rfm_apply_kernel<9>); break;
+    case 12: launch(rfm_apply_kernel<12>); break;
+    case 15: launch(rfm_apply_kernel<15>); break;
+    default: launch(rfm_apply_kernel<0>); break;
+  }
   PS_CHECK_LAUNCH("rfm_apply");
   return PS_OK;
 }
@@ -596,8 +742,15 @@ extern "C" int ps_affinity_softmax_bwd(float* P_inout, const float* dR, const fl
                                        void* stream) {
   PS_REQUIRE(P_inout && dR && V && R && n > 0 && np > 0 && cc > 0 && cc <= RFM_MAXCC, "affinity_softmax_bwd: bad argument");
   const long long rows = (long long)n * np;
-  hipLaunchKernelGGL(affinity_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), P_inout, dR,
-                     V, R, rows, np, cc);
+  auto launch = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), P_inout, dR, V, R, rows, np, cc);
+  };
+  switch (cc) {
+    case 9: launch(affinity_softmax_bwd_kernel<9>); break;
+    case 12: launch(affinity_softmax_bwd_kernel<12>); break;
+    case 15: launch(affinity_softmax_bwd_kernel<15>); break;
+    default: launch(affinity_softmax_bwd_kernel<0>); break;
+  }
   PS_CHECK_LAUNCH("affinity_softmax_bwd");
   return PS_OK;
 }

@@ -92,6 +92,53 @@ def test_rfm_helpers_match_reference_goldens(golden_dir):
     assert Net.get_norm_cam_d  # API parity with revise_net.py:29
 
 
+@pytest.mark.parametrize("cc", [12, 7, 15, 9, 24])  # 9 / 12 / 15 (3 x classes) are compile-time instantiations, the rest the predicated form
+def test_affinity_apply_and_softmax_backward_against_torch(cc):
+    """R = P V and, through the column softmax P = softmax(S), dS = P * (dR V^T - rowsum(dR * R))  (revise_net.py:72-76, 90-96)."""
+    from pistoseg_amd import ops
+
+    g = torch.Generator().manual_seed(cc)
+    n, npix = 2, 131
+    S = (torch.randn(n, npix, npix, generator=g) * 2).double().requires_grad_(True)
+    V = torch.randn(n, npix, cc, generator=g).double()
+    P = torch.softmax(S, dim=2)
+    R = P @ V
+    dR = torch.randn(n, npix, cc, generator=g).double()
+    R.backward(dR)
+    Pd, Vd = P.detach().float().to(D), V.float().to(D)
+    Rd = torch.empty((n, npix, cc), device=D)
+    ops.rfm_apply(Pd, Vd, Rd)
+    np.testing.assert_allclose(Rd.cpu().numpy(), R.detach().numpy(), rtol=2e-5, atol=2e-6)
+    ops.affinity_softmax_bwd_(Pd, dR.float().to(D), Vd, Rd)  # in place: Pd now holds dS
+    np.testing.assert_allclose(Pd.cpu().numpy(), S.grad.numpy(), rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("dts", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.bfloat16), (torch.float16, torch.float16)])
+@pytest.mark.parametrize("dims", [(100, 76, 52), (131, 64, 30), (64, 192, 784)])  # (M, N, K); the second: K % 4 != 0 -> element-wise kernel
+def test_bgemm_stride_patterns(dts, dims):
+    """ps_bgemm over the three operand layouts the affinity products use (revise_net.py:130,179-180: k q^T, dS^T k, dS q) and an
+    unaligned case: the vector-staged and the element-wise kernel sum K in the same order, exact-f32 MFMA."""
+    from pistoseg_amd import ops
+
+    M, N, K = dims
+    batch = 3
+    g = torch.Generator().manual_seed(M * 7 + K)
+    adt, bdt = dts
+    for a_kfast in (True, False):
+        for b_kfast in (True, False):
+            A = torch.randn(batch, M, K, generator=g).to(adt)
+            B = torch.randn(batch, K, N, generator=g).to(bdt)
+            ref = torch.bmm(A.double(), B.double())
+            Ad = (A if a_kfast else A.transpose(1, 2).contiguous()).to(D)   # memory [b][m][k] or [b][k][m]
+            Bd = (B.transpose(1, 2).contiguous() if b_kfast else B).to(D)   # memory [b][n][k] or [b][k][n]
+            sa = (M * K, K, 1) if a_kfast else (M * K, 1, M)
+            sb = (K * N, 1, K) if b_kfast else (K * N, N, 1)
+            Cd = torch.full((batch, M, N), float("nan"), device=D)
+            ops.bgemm(Ad, Bd, Cd, batch, M, N, K, sa, sb, (M * N, N, 1), alpha=0.5)
+            err = float((Cd.cpu().double() - 0.5 * ref).abs().max()) / float(ref.abs().max())
+            assert err < 2e-6, (a_kfast, b_kfast, err)
+
+
 def test_topk_select_against_torch():
     from pistoseg_amd import ops
 
