@@ -195,6 +195,33 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x
   const float inv = 1.f / s;
   for (int i = lane; i < len; i += 64) r[i] = expf(r[i] - mx) * inv;
 }
+// The same for rows of up to 64 x NV elements: the row is read ONCE, NV loads per lane issued back to back, and lives in registers for
+// the three passes (same operations in the same order: bit-identical).  The three-pass form re-reads the row and pays a memory latency
+// per element and pass.
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(float* __restrict__ x, long long rows, int len) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float* r = x + row * len;
+  float v[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) v[j] = r[min(lane + 64 * j, len - 1)];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+    if (lane + 64 * j < len) mx = fmaxf(mx, v[j]);
+  mx = ps_wave_max(mx);
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+    if (lane + 64 * j < len) s += expf(v[j] - mx);
+  s = ps_wave_sum(s);
+  const float inv = 1.f / s;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+    if (lane + 64 * j < len) r[lane + 64 * j] = expf(v[j] - mx) * inv;
+}
 
 // Channel loops of the two affinity kernels: the maps' channel count cc = 3 x classes is a template argument for 9 / 12 / 15 (CT > 0: a
 // pixel's V row is loaded back to back), any other count up to RFM_MAXCC takes the predicated form (CT == 0: `if (c < cc)` puts every
@@ -304,6 +331,62 @@ __global__ __launch_bounds__(256) void norm_cam_kernel(const NormArgs a) {
       for (int c = 1; c < a.c; ++c)
         if (v[c] < fgmax) v[c] = 0.f;
     for (int c = 0; c < a.c; ++c) a.dst[n * a.dn + c * a.dc + p * a.dp] = v[c];
+  }
+}
+
+// The same for maps of up to 1024 positions (every call site: 28 x 28 CAMs, 32 x 32 pseudo-masks): a thread's pixels (<= 4) and their
+// C <= 8 values are loaded ONCE, unconditionally (channel index clamped, dtype at compile time: 32 loads back to back), kept in
+// registers for the normalisation pass, and a pixel's offset is computed once.  The general kernel above pays a memory latency and two
+// integer divisions per element and pass through its generic accessor: 17.5 us per launch for a few hundred KB, five launches per step.
+template <int SDT>
+__global__ __launch_bounds__(256) void norm_cam_small_kernel(const NormArgs a) {
+  __shared__ float smin[8][4], smax[8][4], fmn[8], fmx[8];
+  const int n = blockIdx.x, hw = a.h * a.w, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float x[4][8];
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) {
+    const int p = min((int)threadIdx.x + 256 * sl, hw - 1);
+    const long long off = n * a.sn + (long long)(p / a.w) * a.sh + (long long)(p % a.w) * a.sw;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) x[sl][c] = ps_ld_dt(a.src, SDT, off + (long long)min(c, a.c - 1) * a.sc);
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl)
+      if ((int)threadIdx.x + 256 * sl < hw) { mn = fminf(mn, x[sl][c]); mx = fmaxf(mx, x[sl][c]); }
+    mn = ps_wave_min(mn); mx = ps_wave_max(mx);
+    if (lane == 0) { smin[c][wave] = mn; smax[c][wave] = mx; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int c = threadIdx.x;
+    fmn[c] = fminf(fminf(smin[c][0], smin[c][1]), fminf(smin[c][2], smin[c][3]));
+    fmx[c] = fmaxf(fmaxf(smax[c][0], smax[c][1]), fmaxf(smax[c][2], smax[c][3]));
+  }
+  __syncthreads();
+#pragma unroll
+  for (int sl = 0; sl < 4; ++sl) {
+    const int p = (int)threadIdx.x + 256 * sl;
+    if (p >= hw) continue;
+    float v[8];
+    float fgmax = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      if (c >= a.c) continue;
+      const float xv = x[sl][c];
+      if (a.mode == 0) v[c] = (xv - fmn[c]) / ((fmx[c] + 1e-5f) - fmn[c]);
+      else v[c] = (xv - fmn[c]) / (fmx[c] - fmn[c] + 1e-5f) * (a.label ? a.label[n * a.c + c] : 1.f);
+      if (c >= 1) fgmax = fmaxf(fgmax, v[c]);
+    }
+    v[0] = 1.f - fgmax;
+#pragma unroll
+    for (int c = 1; c < 8; ++c)
+      if (a.mode == 0 && c < a.c && v[c] < fgmax) v[c] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < a.c) a.dst[n * a.dn + c * a.dc + p * a.dp] = v[c];
   }
 }
 
@@ -611,7 +694,16 @@ __global__ __launch_bounds__(256) void gap_kernel(const float* __restrict__ x, f
   __shared__ float red[4];
   const float* p = x + (long long)blockIdx.x * hw;
   float s = 0.f;
-  for (long long i = threadIdx.x; i < hw; i += 256) s += p[i];
+  // (eight loads in flight per thread, added in index order: same sum as the plain loop, which paid a memory latency per element)
+  long long i = threadIdx.x;
+  for (; i + 7 * 256 < hw; i += 8 * 256) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = p[i + j * 256];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  for (; i < hw; i += 256) s += p[i];
   s = ps_wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -719,7 +811,11 @@ extern "C" int ps_bgemm(int32_t adt, int32_t bdt, int32_t cdt, const void* A, co
 
 extern "C" int ps_softmax_rows(float* x, int64_t rows, int32_t len, void* stream) {
   PS_REQUIRE(x && rows > 0 && len > 0, "softmax_rows: bad argument");
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), x, (long long)rows, len);
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  hipStream_t st_ = static_cast<hipStream_t>(stream);
+  if (len <= 64 * 13) hipLaunchKernelGGL(softmax_rows_reg_kernel<13>, grid, dim3(256), 0, st_, x, (long long)rows, len);  // 28 x 28 = 784 positions
+  else if (len <= 64 * 16) hipLaunchKernelGGL(softmax_rows_reg_kernel<16>, grid, dim3(256), 0, st_, x, (long long)rows, len);  // 32 x 32
+  else hipLaunchKernelGGL(softmax_rows_kernel, grid, dim3(256), 0, st_, x, (long long)rows, len);
   PS_CHECK_LAUNCH("softmax_rows");
   return PS_OK;
 }
@@ -759,7 +855,11 @@ extern "C" int ps_norm_cam(const ps_tensor4* src, float* dst, int64_t dn, int64_
   PS_REQUIRE(src && src->ptr && dst, "norm_cam: null argument");
   PS_REQUIRE(src->c >= 2 && src->c <= 8 && (mode == 0 || mode == 1), "norm_cam: C=%d unsupported (2..8) or bad mode", src->c);
   NormArgs a{src->ptr, src->dtype, src->sn, src->sc, src->sh, src->sw, dst, dn, dc, dp, label, src->c, src->h, src->w, mode};
-  hipLaunchKernelGGL(norm_cam_kernel, dim3(src->n), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  hipStream_t st_ = static_cast<hipStream_t>(stream);
+  if (src->h * src->w <= 1024 && src->dtype == PS_F32) hipLaunchKernelGGL(norm_cam_small_kernel<PS_F32>, dim3(src->n), dim3(256), 0, st_, a);
+  else if (src->h * src->w <= 1024 && src->dtype == PS_BF16) hipLaunchKernelGGL(norm_cam_small_kernel<PS_BF16>, dim3(src->n), dim3(256), 0, st_, a);
+  else if (src->h * src->w <= 1024 && src->dtype == PS_F16) hipLaunchKernelGGL(norm_cam_small_kernel<PS_F16>, dim3(src->n), dim3(256), 0, st_, a);
+  else hipLaunchKernelGGL(norm_cam_kernel, dim3(src->n), dim3(256), 0, st_, a);
   PS_CHECK_LAUNCH("norm_cam");
   return PS_OK;
 }

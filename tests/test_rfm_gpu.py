@@ -139,6 +139,47 @@ def test_bgemm_stride_patterns(dts, dims):
             assert err < 2e-6, (a_kfast, b_kfast, err)
 
 
+@pytest.mark.parametrize("length", [37, 784, 1000, 1024, 1500])  # <= 832 / <= 1024: register-resident rows; above: three passes
+def test_softmax_rows_in_place(length):
+    from pistoseg_amd import ops
+
+    g = torch.Generator().manual_seed(length)
+    x = torch.randn(7, length, generator=g) * 4
+    xd = x.to(D)
+    ops.softmax_rows_(xd, 7, length)
+    np.testing.assert_allclose(xd.cpu().numpy(), torch.softmax(x.double(), 1).numpy(), rtol=2e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("hw", [(28, 28), (32, 32), (40, 41), (5, 3)])  # <= 1024 positions: the register-resident kernel; (40, 41): the general one
+@pytest.mark.parametrize("c", [4, 8, 2])
+def test_norm_cam_map_sizes_and_layouts(hw, c):
+    """get_norm_cam_d (mode 0) and max_norm * label with the rebuilt background (mode 1) against the oracle, NCHW f32 and NHWC bf16 sources."""
+    from pistoseg_amd import ops
+
+    h, w = hw
+    n = 3
+    g = torch.Generator().manual_seed(h * 100 + c)
+    cam = torch.randn(n, c, h, w, generator=g)
+    cam[0, 1] = cam[0, 2] if c > 2 else cam[0, 1]  # a tie between two foreground channels
+    ref0 = ref_cpu.get_norm_cam_d(cam.clone())
+    out = torch.empty((n, c, h, w), device=D)
+    ops.norm_cam(cam.to(D), "nchw", out, (c * h * w, h * w, 1), 0)
+    np.testing.assert_allclose(out.cpu().numpy(), ref0.numpy(), rtol=1e-6, atol=1e-7)
+    assert np.array_equal(out.cpu().numpy() == 0, ref0.numpy() == 0)
+    camb = cam.to(torch.bfloat16)
+    refb = ref_cpu.get_norm_cam_d(camb.float())
+    outb = torch.empty((n, h * w, c), device=D)  # pixel-major destination, channels-last bf16 source (the CAM of the low-precision path)
+    ops.norm_cam(camb.permute(0, 2, 3, 1).contiguous().to(D), "nhwc", outb, (h * w * c, 1, c), 0)
+    np.testing.assert_allclose(outb.cpu().permute(0, 2, 1).reshape(n, c, h, w).numpy(), refb.numpy(), rtol=1e-6, atol=1e-7)
+    label = (torch.rand(n, c, generator=g) > 0.4).float()
+    label[:, 0] = 1
+    ref1 = ref_cpu.max_norm(cam.clone()) * label.view(n, c, 1, 1)
+    out1 = torch.empty((n, c, h, w), device=D)
+    ops.norm_cam(cam.to(D), "nchw", out1, (c * h * w, h * w, 1), 1, label.to(D))
+    np.testing.assert_allclose(out1.cpu().numpy()[:, 1:], ref1.numpy()[:, 1:], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(out1.cpu().numpy()[:, 0], 1.0 - out1.cpu().numpy()[:, 1:].max(1), rtol=0, atol=1e-7)
+
+
 def test_topk_select_against_torch():
     from pistoseg_amd import ops
 
