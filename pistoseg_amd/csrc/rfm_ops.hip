@@ -180,6 +180,64 @@ __global__ __launch_bounds__(256) void bgemm_vec_kernel(const BgemmArgs a) {
       }
 }
 
+// Both operands 16-bit and K-contiguous (the affinity logits k q^T of the low-precision path, revise_net.py:69-72): the MFMA fragments
+// ARE 16 consecutive bytes of a row, so they go from memory straight into registers -- no LDS, no barrier -- and the products run on
+// the 16-bit MFMA (16x16x32: products of two bf16 / f16 numbers are exact in f32 and the accumulation is f32, i.e. the arithmetic of
+// the f32 kernels above with another summation order) at 16x the rate of the exact-f32 instruction.  64 x 64 tile, four waves of
+// 32 x 32, K a multiple of 32; the next K step's fragments are loaded before this step's MFMAs.
+template <bool F16>
+__global__ __launch_bounds__(256) void bgemm_kk16_kernel(const BgemmArgs a) {
+  const int b = blockIdx.z, m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, l16 = lane & 15, g = lane >> 4;
+  const uint16_t* Ab = static_cast<const uint16_t*>(a.A) + (long long)b * a.sab;
+  const uint16_t* Bb = static_cast<const uint16_t*>(a.B) + (long long)b * a.sbb;
+  const uint16_t* pa[2];
+  const uint16_t* pb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {  // rows past the end are clamped (their results are not stored)
+    pa[i] = Ab + (long long)min(m0 + wm * 32 + i * 16 + l16, a.M - 1) * a.sam + 8 * g;
+    pb[i] = Bb + (long long)min(n0 + wn * 32 + i * 16 + l16, a.N - 1) * a.sbn + 8 * g;
+  }
+  bg_f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = bg_f32x4{0.f, 0.f, 0.f, 0.f};
+  uint4 fa[2], fb[2], na[2], nb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    fa[i] = *reinterpret_cast<const uint4*>(pa[i]);
+    fb[i] = *reinterpret_cast<const uint4*>(pb[i]);
+  }
+  for (int k0 = 0; k0 < a.K; k0 += 32) {
+    const int kn = k0 + 32 < a.K ? k0 + 32 : k0;  // (the last step re-reads itself)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      na[i] = *reinterpret_cast<const uint4*>(pa[i] + kn);
+      nb[i] = *reinterpret_cast<const uint4*>(pb[i] + kn);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if constexpr (F16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa[i]), __builtin_bit_cast(f16x8, fb[j]), acc[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { fa[i] = na[i]; fb[i] = nb[i]; }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 32 + i * 16 + 4 * g + r, n = n0 + wn * 32 + j * 16 + l16;
+        if (m < a.M && n < a.N) st(a.C, a.cdt, b * a.scb + m * a.scm + n * a.scn, a.alpha * acc[i][j][r]);
+      }
+}
+
 // in-place softmax of rows of length len (one wave per row)
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, long long rows, int len) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -799,7 +857,12 @@ extern "C" int ps_bgemm(int32_t adt, int32_t bdt, int32_t cdt, const void* A, co
   };
   bool fast = K % 4 == 0 && (sak == 1 || (sam == 1 && M % 4 == 0)) && (sbk == 1 || (sbn == 1 && N % 4 == 0));
   fast = fast && vec_ok(A, adt, sak == 1 ? sam : sak, sab) && vec_ok(B, bdt, sbk == 1 ? sbn : sbk, sbb);
-  if (fast && adt == PS_F32 && bdt == PS_F32) hipLaunchKernelGGL((bgemm_vec_kernel<PS_F32, PS_F32>), grid, dim3(256), 0, st_, a);
+  // 16-bit x 16-bit with k contiguous in both: fragments straight from memory (16-byte aligned rows, K a multiple of 32)
+  const bool kk16 = adt == bdt && (adt == PS_BF16 || adt == PS_F16) && sak == 1 && sbk == 1 && K % 32 == 0 && sam % 8 == 0 && sbn % 8 == 0 &&
+                    sab % 8 == 0 && sbb % 8 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(B) % 16 == 0;
+  if (kk16 && adt == PS_BF16) hipLaunchKernelGGL(bgemm_kk16_kernel<false>, grid, dim3(256), 0, st_, a);
+  else if (kk16) hipLaunchKernelGGL(bgemm_kk16_kernel<true>, grid, dim3(256), 0, st_, a);
+  else if (fast && adt == PS_F32 && bdt == PS_F32) hipLaunchKernelGGL((bgemm_vec_kernel<PS_F32, PS_F32>), grid, dim3(256), 0, st_, a);
   else if (fast && adt == PS_BF16 && bdt == PS_BF16) hipLaunchKernelGGL((bgemm_vec_kernel<PS_BF16, PS_BF16>), grid, dim3(256), 0, st_, a);
   else if (fast && adt == PS_F32 && bdt == PS_BF16) hipLaunchKernelGGL((bgemm_vec_kernel<PS_F32, PS_BF16>), grid, dim3(256), 0, st_, a);
   else if (fast && adt == PS_F16 && bdt == PS_F16) hipLaunchKernelGGL((bgemm_vec_kernel<PS_F16, PS_F16>), grid, dim3(256), 0, st_, a);

@@ -114,7 +114,8 @@ def test_affinity_apply_and_softmax_backward_against_torch(cc):
 
 
 @pytest.mark.parametrize("dts", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.bfloat16), (torch.float16, torch.float16)])
-@pytest.mark.parametrize("dims", [(100, 76, 52), (131, 64, 30), (64, 192, 784)])  # (M, N, K); the second: K % 4 != 0 -> element-wise kernel
+@pytest.mark.parametrize("dims", [(100, 76, 52), (131, 64, 30), (64, 192, 784), (200, 136, 192)])
+# (M, N, K); the second: K % 4 != 0 -> element-wise kernel; the last: K % 32 == 0 -> 16-bit operands with k contiguous go straight to the 16-bit MFMA
 def test_bgemm_stride_patterns(dts, dims):
     """ps_bgemm over the three operand layouts the affinity products use (revise_net.py:130,179-180: k q^T, dS^T k, dS q) and an
     unaligned case: the vector-staged and the element-wise kernel sum K in the same order, exact-f32 MFMA."""
