@@ -1,4 +1,4 @@
-"""Per-launch table of one training step / one inference pass at bs=64 (HIP events around every conv launch)."""
+"""Per-launch table of one training step (HIP events around every conv launch):  python tools/step_profile.py [batch] [bf16|fp16] [classes]"""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,9 +25,12 @@ def wrap(name):
     setattr(ops, name, f)
 for nm in ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad"): wrap(nm)
 import pistoseg_amd.resnet38d, pistoseg_amd.seg_model
-model = ResNet38dSeg(3, "bf16"); init_weights_he(model); model = model.to(D)
+BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+PREC = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+CLASSES = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+model = ResNet38dSeg(CLASSES, PREC); init_weights_he(model); model = model.to(D)
 tr = SegTrainer(model, overlap_wgrad=False)  # one stream: every launch alone on the GPU
-x = torch.randn(64, 3, 224, 224, device=D); y = torch.randint(0, 4, (64, 224, 224), device=D)
+x = torch.randn(BATCH, 3, 224, 224, device=D); y = torch.randint(0, CLASSES + 1, (BATCH, 224, 224), device=D)
 for _ in range(3): tr.train_step(x, y)
 torch.cuda.synchronize(); rec.clear()
 tr.train_step(x, y); torch.cuda.synchronize()

@@ -1,0 +1,34 @@
+"""Same-box A/B of debug-library switches on the whole training step:  python tools/train_ab.py name=value[,name=value] ...
+Each argument is one variant (comma-separated ps_debug_set_<name>(value) calls; the word `base` = no switch); the variants are run
+interleaved, 3 rounds x 10 steps each, and the best round per variant is printed.  bs = 64, 224 x 224, bf16, two-stream backward."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pistoseg_amd import _lib
+from pistoseg_amd.seg_model import ResNet38dSeg
+from pistoseg_amd.trainer import SegTrainer, init_weights_he
+
+lib = _lib.use_debug_library()
+D = torch.device("cuda:0")
+model = ResNet38dSeg(3, "bf16"); init_weights_he(model, seed=42); model = model.to(D)
+tr = SegTrainer(model)
+x = torch.randn(64, 3, 224, 224, device=D); y = torch.randint(0, 4, (64, 224, 224), device=D)
+variants = sys.argv[1:] or ["base"]
+RESET = {"wgrad_raster": -1, "halo_tail": 1}
+def apply(v):
+    for k, d in RESET.items(): getattr(lib, "ps_debug_set_" + k)(d)
+    if v != "base":
+        for kv in v.split(","):
+            k, val = kv.split("="); getattr(lib, "ps_debug_set_" + k)(int(val))
+for _ in range(5): tr.train_step(x, y)
+best = {v: 1e9 for v in variants}
+for r in range(3):
+    for v in variants:
+        apply(v)
+        tr.train_step(x, y); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10): tr.train_step(x, y)
+        torch.cuda.synchronize()
+        best[v] = min(best[v], (time.perf_counter() - t0) / 10)
+apply("base")
+for v in variants: print(f"{v:32s} {1e3 * best[v]:7.3f} ms/step  {64 / best[v]:7.1f} tiles/s")
