@@ -30,13 +30,12 @@ class SegmentationTTAWrapper(torch.nn.Module):
     def forward(self, image: torch.Tensor) -> torch.Tensor:
         x = image.contiguous().float()
         n = x.shape[0]
-        views = []
-        for hflip, k in D4_VIEWS:
-            v = torch.empty_like(x)
+        stacked = torch.empty((len(D4_VIEWS) * n,) + tuple(x.shape[1:]), device=x.device, dtype=x.dtype)  # the views land in ONE batch: no torch.cat
+        views = [stacked[i * n:(i + 1) * n] for i in range(len(D4_VIEWS))]
+        for (hflip, k), v in zip(D4_VIEWS, views):
             ops.d4_view(x, v, hflip, k, inverse=False, accumulate=False)
-            views.append(v)
         if self.batched:
-            outs = self.model(torch.cat(views, 0)).float().contiguous()
+            outs = self.model(stacked).float().contiguous()
             outs = [outs[i * n:(i + 1) * n] for i in range(len(D4_VIEWS))]
         else:
             outs = [self.model(v).float().contiguous() for v in views]

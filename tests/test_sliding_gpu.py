@@ -115,7 +115,7 @@ def test_multi_scale_cam_matches_oracle():
     assert np.allclose(got, ref, rtol=1e-12, atol=1e-13)
 
 
-@pytest.mark.parametrize("s", [8, 33])
+@pytest.mark.parametrize("s", [8, 33, 224, 70])  # (odd rotations go through 32 x 32 LDS tiles: whole and ragged tile grids)
 def test_d4_views_match_torch_rot90_flip(s):
     from pistoseg_amd import ops
     from pistoseg_amd.tta import D4_VIEWS

@@ -25,3 +25,6 @@ small = torch.empty(n, c, 32, 32, device=D)
 t("bilinear_fwd 224->32", lambda: ops.bilinear_fwd(logits, "nchw", small, "nchw", False), n * c * s * s * 4 / 1e6)
 dc = torch.empty(n, 28, 28, c, device=D)
 t("bilinear_bwd 224->28 (ac)", lambda: ops.bilinear_bwd(logits, "nchw", dc, "nhwc", True), n * c * s * s * 4 / 1e6)
+img = torch.randn(64, 3, 224, 224, device=D); view = torch.empty_like(img)
+for hflip, k in ((False, 0), (True, 2), (False, 1), (True, 3)):
+    t(f"d4_view hflip={int(hflip)} k={k}", lambda: ops.d4_view(img, view, hflip, k, inverse=False, accumulate=False), 2 * img.numel() * 4 / 1e6)
