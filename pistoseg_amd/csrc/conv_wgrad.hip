@@ -302,27 +302,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
   int first, G, nitems;  // this block's items: first, first + G, ... < nitems
   ps_block_items(blockIdx.x, gridDim.x, a.tiles_co * a.tiles_ci * a.taps * live, a.nb, a.tpb, first, G, nitems);
   // item -> (ci tile, co tile, tap, pixel range), pixel range slowest (co-running blocks share their dY / X chunks in L2)
-  // Order inside a pixel range (a.raster): which 32 consecutive items -- the blocks of one XCD, streaming the range together through one
-  // L2 -- share most.  An item stages 32 KiB of dY (its 256 couts) and 16 KiB of X (its 128 cins, rows shifted by its tap) per K-step:
-  //   0: cin tile, cout tile, tap   (32 items = 8 cin x 4 cout tiles of one tap: 128 + 128 KiB unique per step at 1024 -> 2048)
-  //   1: cin tile, tap, cout tile   (8 cin tiles x 4 taps of ONE cout tile: 32 KiB + 128 KiB, the taps' X rows coincide up to a skew)
-  //   2: cin tile mod 4, tap, cin tile / 4, cout tile   (4 cin tiles x 8 taps of one cout tile: 32 + 64 KiB)
   auto decode = [&](int item, int& tci, int& tco, int& tap, int& ks0, int& ks1) {
-    if (a.raster == 2) {
-      const int t4 = item & 3; item >>= 2;
-      tap = item % a.taps; item /= a.taps;
-      const int q = a.tiles_ci >> 2;
-      tci = (item % q) * 4 + t4; item /= q;
-      tco = item % a.tiles_co; item /= a.tiles_co;
-    } else if (a.raster == 1) {
-      tci = item % a.tiles_ci; item /= a.tiles_ci;
-      tap = item % a.taps; item /= a.taps;
-      tco = item % a.tiles_co; item /= a.tiles_co;
-    } else {
-      tci = item % a.tiles_ci; item /= a.tiles_ci;
-      tco = item % a.tiles_co; item /= a.tiles_co;
-      tap = item % a.taps; item /= a.taps;
-    }
+    tci = item % a.tiles_ci; item /= a.tiles_ci;
+    tco = item % a.tiles_co; item /= a.tiles_co;
+    tap = item % a.taps; item /= a.taps;
     ks0 = item * per;
     ks1 = min(a.ksteps, ks0 + per);
   };
@@ -595,10 +578,7 @@ int launch_wgrad_ws2(WgradArgs a, hipStream_t s) {
   a.dq = 64 % a.Wo;
   a.dp = (64 / a.Wo) % a.Ho;
   a.dn = 64 / (a.Wo * a.Ho);
-  // (measured r02, profiles/r02_wgrad_item_order_ab.txt: orders 1 / 2 are +1..3 % on two layers in isolation and change nothing in the
-  // training step -- tools/train_ab.py, 31.78 ms for all three on one box: the L2 hit rate is not what limits this kernel)
-  a.raster = g_wgrad_raster >= 0 ? g_wgrad_raster : 0;
-  if (a.raster == 2 && a.tiles_ci % 4 != 0) a.raster = 1;
+  a.raster = 0;
   a.ablate = g_wgrad_ablate;
   const long long tiles = (long long)a.tiles_co * a.tiles_ci * a.taps;
   const int ncu = ps_num_cus();
