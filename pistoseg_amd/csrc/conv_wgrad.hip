@@ -281,7 +281,14 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 1) void conv_wgrad_kernel(
 //     next item's main loop.
 // 16-bit operands only (transposed LDS reads); cout % 256 == 0 and cin % 128 == 0 (every trainable backbone conv).
 // ------------------------------------------------------------------------------------------------
-template <bool F16>
+// XM: how the loaders address the X rows (compile time: the loader waves are issue-bound -- with the general form's per-row pixel
+// tracking, 25 VALU instructions per X row and K-step, ablating it was worth +5..13 % on the kernel, profiles/r02_wgrad_loader_ablation.txt;
+// and a run-time switch here is worse than no switch: hipcc triplicated the issue code and the kernel lost 12 %)
+//   0: any stride: (n, p, q) of the lane's pixel tracked incrementally, address rebuilt per K-step
+//   1: stride 1 (output map = input map): the tap's row is the pixel's row shifted by a constant, i.e. a per-lane constant offset plus a
+//      SCALAR offset per K-step; only the padding test keeps per-lane state (the shifted coordinates, 11 instructions per row)
+//   2: 1x1, stride 1: no padding either -- constant lane offset + scalar offset, as for dY (no VALU work per K-step at all)
+template <bool F16, int XM>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs a) {
   constexpr int ES = 2, KP = 64, BCO = 256, BCI = 128;
   constexpr int RBG = BCO * ES, RBX = BCI * ES;             // 512 / 256 bytes per LDS row
@@ -321,7 +328,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
     PS_LOADER_SETPRIO();
     const int wave = wave_all - 4;
     const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)a.dy_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+    // XM >= 1: the descriptor starts `xpad` bytes BEFORE the tensor (the largest negative tap shift), so that scalar + lane offsets of
+    // every row are non-negative; nothing in front of the tensor is ever read (those rows fail the padding test)
+    const int xpad = XM == 1 ? (a.dil * a.W + a.dil) * (int)a.x_pix_bytes : 0;
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x - xpad), 0, (int)a.x_bytes + xpad, 0x00020000);
     const int g_rowin = lane / (RBG / 16), g_pos = lane % (RBG / 16);
     const int x_rowin = lane / (RBX / 16), x_pos = lane % (RBX / 16);
     const int n_img = a.M / (a.Ho * a.Wo);
@@ -342,12 +352,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
 #pragma unroll
       for (int j = 0; j < NIX; ++j) {
         const int R = (wave * NIX + j) * RPX + x_rowin;
-        const uint32_t m = (uint32_t)(ks * KP + R);
-        const uint32_t n = fdiv(m, a.div_hw);
-        const uint32_t rem = m - n * a.div_hw.d;
-        const uint32_t p = fdiv(rem, a.div_w);
-        xn[j] = (int)n; xp[j] = (int)p; xq[j] = (int)(rem - p * a.div_w.d);
+        if constexpr (XM != 2) {
+          const uint32_t m = (uint32_t)(ks * KP + R);
+          const uint32_t n = fdiv(m, a.div_hw);
+          const uint32_t rem = m - n * a.div_hw.d;
+          const uint32_t p = fdiv(rem, a.div_w);
+          xn[j] = (int)n; xp[j] = (int)p; xq[j] = (int)(rem - p * a.div_w.d);
+          if constexpr (XM == 1) { xp[j] += dy_off; xq[j] += dx_off; }  // the SHIFTED coordinates are what is tracked and tested
+        }
         xchunk[j] = (unsigned)(tci * BCI * ES + ((x_pos ^ row_swz<ES, RBX>(R)) << 4));
+        if constexpr (XM >= 1) xchunk[j] += (unsigned)(R * (int)a.x_pix_bytes);  // the lane's constant row offset
       }
     };
     item_setup(item);
@@ -361,19 +375,35 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
 #pragma unroll
       for (int j = 0; j < NIG; ++j)
         if (stage) BLDS16(rsG, sg + (wave * NIG + j) * 1024, goff[j], gso);
+      // scalar part of an X row's offset (XM >= 1): (first pixel of the K-step + the tap's shift) rows, from the padded descriptor base
+      const int xso = XM >= 1 ? (ks * KP + dy_off * a.W + dx_off) * (int)a.x_pix_bytes + xpad : 0;
 #pragma unroll
       for (int j = 0; j < NIX; ++j) {
-        const int y = xp[j] * a.stride + dy_off, xx = xq[j] * a.stride + dx_off;
-        const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)xx < (unsigned)a.W && xn[j] < n_img;
-        const unsigned off = ok ? (unsigned)(((xn[j] * a.H + y) * a.W + xx) * (int)a.x_pix_bytes) + xchunk[j] : PAD_ROW;
-        if (stage) BLDS16(rsX, sx + (wave * NIX + j) * 1024, off, 0);
-        int q = xq[j] + a.dq;  // advance this lane's pixel by KP
-        const int c1 = q >= a.Wo;
-        q -= c1 ? a.Wo : 0;
-        int p = xp[j] + a.dp + c1;
-        const int c2 = p >= a.Ho;
-        p -= c2 ? a.Ho : 0;
-        xq[j] = q; xp[j] = p; xn[j] += a.dn + c2;
+        if constexpr (XM == 2) {
+          if (stage) BLDS16(rsX, sx + (wave * NIX + j) * 1024, xchunk[j], xso);  // (rows past the last pixel: outside the descriptor -> zeros)
+        } else if constexpr (XM == 1) {
+          const bool ok = (unsigned)xp[j] < (unsigned)a.H && (unsigned)xq[j] < (unsigned)a.W;  // (past the last image: outside the descriptor)
+          if (stage) BLDS16(rsX, sx + (wave * NIX + j) * 1024, ok ? xchunk[j] : PAD_ROW, xso);
+          int q = xq[j] + a.dq;  // advance the lane's (shifted) pixel by KP: wrap where the UNSHIFTED coordinate leaves the map
+          const int c1 = q >= a.W + dx_off;
+          q -= c1 ? a.W : 0;
+          int p = xp[j] + a.dp + c1;
+          const int c2 = p >= a.H + dy_off;
+          p -= c2 ? a.H : 0;
+          xq[j] = q; xp[j] = p;
+        } else {
+          const int y = xp[j] * a.stride + dy_off, xx = xq[j] * a.stride + dx_off;
+          const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)xx < (unsigned)a.W && xn[j] < n_img;
+          const unsigned off = ok ? (unsigned)(((xn[j] * a.H + y) * a.W + xx) * (int)a.x_pix_bytes) + xchunk[j] : PAD_ROW;
+          if (stage) BLDS16(rsX, sx + (wave * NIX + j) * 1024, off, 0);
+          int q = xq[j] + a.dq;  // advance this lane's pixel by KP
+          const int c1 = q >= a.Wo;
+          q -= c1 ? a.Wo : 0;
+          int p = xp[j] + a.dp + c1;
+          const int c2 = p >= a.Ho;
+          p -= c2 ? a.Ho : 0;
+          xq[j] = q; xp[j] = p; xn[j] += a.dn + c2;
+        }
       }
       ++issued;
       slot = (slot == 2) ? 0 : slot + 1;
@@ -597,7 +627,10 @@ int launch_wgrad_ws2(WgradArgs a, hipStream_t s) {
   const long long items = tiles * live;
   a.nb = ncu;
   const unsigned grid = ps_persistent_grid(items, a.nb, a.tpb);
-  hipLaunchKernelGGL((conv_wgrad_ws2_kernel<Tr::F16>), dim3(grid), dim3(512), 3 * 64 * (256 + 128) * 2, s, a);
+  const size_t lds = 3 * 64 * (256 + 128) * 2;
+  if (a.stride == 1 && a.taps == 1) hipLaunchKernelGGL((conv_wgrad_ws2_kernel<Tr::F16, 2>), dim3(grid), dim3(512), lds, s, a);
+  else if (a.stride == 1) hipLaunchKernelGGL((conv_wgrad_ws2_kernel<Tr::F16, 1>), dim3(grid), dim3(512), lds, s, a);
+  else hipLaunchKernelGGL((conv_wgrad_ws2_kernel<Tr::F16, 0>), dim3(grid), dim3(512), lds, s, a);
   PS_CHECK_LAUNCH("conv_wgrad_ws2");
   return PS_OK;
 }
