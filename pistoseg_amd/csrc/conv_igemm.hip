@@ -1445,7 +1445,31 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
     wait_allow(WPW * (w_issued > 0 ? w_issued - 1 : 0));  // window 0 (oldest) and the weights of step 0 have landed
     __builtin_amdgcn_s_barrier();
     int r = 0;
-    for (int gs = 0; gs < total_steps; ++gs) {
+    // STEADY STATE, three K-steps (one window) at a time while every issue below is known to succeed: the waits are then compile-time
+    // literals -- queue behind the weights of step gs + 1: r = 0, 1: the younger weight steps and the whole next window; r = 2: the
+    // window is older than them, only the weight steps issued after IT may stay in flight.  The loader waves' issue stream is part of
+    // the K-step's critical path: the general step below re-derives `allow` from four counters and reaches its
+    // `s_waitcnt` through a 5-level compare tree (a switch over 18 literals) -- ~40 scalar instructions and half a dozen branches more
+    // per K-step than this form.
+    constexpr int ALLOW01 = WPW * (NW - 2) + WJ, ALLOW2 = WPW * ((NW - 2) < 2 ? (NW - 2) : 2);
+    for (int gs = 0; gs < total_steps;) {
+      if (r == 0 && b_left >= 3 && a_left >= 1) {
+        issue_weights();
+        issue_window();
+        wait_allow(ALLOW01);
+        __builtin_amdgcn_s_barrier();
+        issue_weights();
+        wait_allow(ALLOW01);
+        __builtin_amdgcn_s_barrier();
+        issue_weights();
+        wait_allow(ALLOW2);
+        __builtin_amdgcn_s_barrier();
+        w_issued += 3;
+        after_win = 2;
+        win_pending = false;
+        gs += 3;
+        continue;
+      }
       if (issue_weights()) { ++w_issued; ++after_win; }   // weights of step gs + NW - 1
       if (r == 0) {
         win_pending = issue_window();                     // the NEXT window, behind this step's weights
@@ -1462,6 +1486,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
       wait_allow(allow);
       __builtin_amdgcn_s_barrier();
       r = (r == 2) ? 0 : r + 1;
+      ++gs;
     }
     return;
   }
