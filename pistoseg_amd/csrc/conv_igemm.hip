@@ -479,7 +479,7 @@ __global__ __launch_bounds__(64 * WMW * WNW) void conv_igemm_kernel(const IgemmA
   __syncthreads();
   for (int s = 0; s < nsteps; ++s) {
     const int cur = s & 1;
-    if (s + 1 < nsteps && !(a.ablate == 1 && s >= 1)) stage_issue(cur ^ 1);
+    if (s + 1 < nsteps && !(PS_ABLATE(a.ablate) == 1 && s >= 1)) stage_issue(cur ^ 1);
     const unsigned char* st = smem + cur * STAGE;
     u32x4 wf[2][WI], xf[2][MI];  // all fragments of the K-line first: the reads overlap the MFMAs of the first half
 #pragma unroll
@@ -993,10 +993,10 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_ws_kernel(const IgemmArgs a
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     for (int s = 0; s < nsteps; ++s) {
-      if (s + 1 < nsteps && !(a.ablate >= 1 && s >= 1)) stage_issue((s + 1) & 1);  // the buffer the consumers finished before the last barrier
+      if (s + 1 < nsteps && !(PS_ABLATE(a.ablate) >= 1 && s >= 1)) stage_issue((s + 1) & 1);  // the buffer the consumers finished before the last barrier
       if (LDS_EPI && s + 1 == nsteps && tile1_src) tile_issue(tile1_src, tile1_ldc, smem + ((s + 1) & 1) * STAGE);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (a.ablate != 2) __builtin_amdgcn_s_barrier();
+      if (PS_ABLATE(a.ablate) != 2) __builtin_amdgcn_s_barrier();
     }
     if (LDS_EPI && tile2_src) {  // second operand: into the buffer the consumers have just finished
       tile_issue(tile2_src, tile2_ldc, smem + ((nsteps - 1) & 1) * STAGE);
@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_ws_kernel(const IgemmArgs a
         for (int i = 0; i < WI; ++i) Tr::mma(wf[i], xf[mi], acc[mi][i]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (a.ablate != 2) __builtin_amdgcn_s_barrier();
+    if (PS_ABLATE(a.ablate) != 2) __builtin_amdgcn_s_barrier();
   }
   if constexpr (LDS_EPI) {
     if (tile2_src) __builtin_amdgcn_s_barrier();
@@ -1143,9 +1143,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
     };
     int tile = first, slot = 0, issued = 0;
     tile_setup(tile);
-    auto issue_next = [&]() -> bool {  // stages the next K-step of the flat sequence (exactly NLD loads per wave)
-      if (issued >= total_steps) return false;
-      if (a.ablate == 1 && issued >= 3) { ++issued; return false; }  // timing experiment: consumers run on stale LDS contents
+    // stages the next K-step of the flat sequence (exactly NLD loads per wave); the caller guarantees issued < total_steps (no end test and,
+    // in the product build, no selector test in the issue path: it is on the K-step's critical path)
+    auto issue_next = [&]() {
+      if (PS_ABLATE(a.ablate) == 1 && issued >= 3) { ++issued; return; }  // timing experiment: consumers run on stale LDS contents
       unsigned char* sa = smem + slot * STAGE;
       unsigned char* sb = sa + A_BYTES;
       const int ko = kl * 128;
@@ -1166,22 +1167,29 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
           tile_setup(tile);
         }
       }
-      return true;
     };
-    auto wait_older = [&](bool newest_in_flight) {  // everything but the newest step's loads has landed
-      if (newest_in_flight) {
-        if constexpr (NLD == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+    auto wait_newest_in_flight = [&]() {  // everything but the newest step's loads has landed
+      if constexpr (NLD == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
     };
-    issue_next();
-    wait_older(issue_next());
+    // Steps 0 and 1, then one step per barrier while there are steps left to stage, then the drain (nothing to stage: everything landed).
+    if (total_steps > 0) issue_next();  // (a block without work stages nothing; it still meets the consumers' first barrier)
+    if (total_steps > 1) {
+      issue_next();
+      wait_newest_in_flight();
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();  // step 0 visible
-    for (int gs = 0; gs < total_steps; ++gs) {
+    int gs = 0;
+    for (; gs + 2 < total_steps; ++gs) {
       // ring slot (gs+2)%3 held step gs-1: the consumers' reads of it completed before the previous barrier
-      wait_older(issue_next());  // step gs+1 landed
+      issue_next();             // step gs + 2
+      wait_newest_in_flight();  // step gs + 1 landed
+      __builtin_amdgcn_s_barrier();
+    }
+    for (; gs < total_steps; ++gs) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
     return;
