@@ -310,3 +310,32 @@ def test_bench_batch_fp32_parity_path_vs_oracle():
     mask = ops.argmax_mask(got, mode=_lib.PS_MASK_PLAIN, softmax_first=True).cpu()
     ok, ndiff = masks_agree_up_to_ties(ref, ref_cpu.logits_to_mask(ref), mask, err)
     assert_tie_excused("bench tiles fp32", ndiff, mask.numel(), ok)
+
+
+def test_forward_and_data_gradient_launches_are_bit_reproducible():
+    """The forward / data-gradient kernels contain no atomics: repeated launches on the same input agree bit for bit.  A loader that let too many
+    DMA pieces stay in flight (its `vmcnt` waits are compile-time literals in steady state), or refilled a ring slot early, would show here as
+    an intermittent difference (tools/determinism_check.py runs the same at the bench shapes)."""
+    from pistoseg_amd import ops
+    from pistoseg_amd.seg_model import ResNet38dSeg
+    from pistoseg_amd.trainer import init_weights_he
+
+    model = ResNet38dSeg(3, "bf16")
+    init_weights_he(model, 42)
+    model = model.to(D)
+    model.eval()
+    x = torch.randn(19, 3, 224, 224, generator=torch.Generator().manual_seed(19)).to(D)  # 19 tiles: ragged tile counts in every layer
+    with torch.no_grad():
+        ref = model(x).clone()
+        for _ in range(6):
+            assert torch.equal(model(x), ref)
+    spec = ops.ConvSpec(512, 512, 3, 1, 1)
+    g = torch.Generator().manual_seed(3)
+    gy = torch.randn(19, 28, 28, 512, generator=g).to(D, torch.bfloat16)
+    wd = (torch.randn(512, 3, 3, 512, generator=g) * 0.02).to(D, torch.bfloat16)
+    outs = []
+    for _ in range(6):
+        gx = torch.empty(19, 28, 28, 512, device=D, dtype=torch.bfloat16)
+        ops.conv2d_dgrad(spec, gy, wd, (28, 28), out_raw=gx)
+        outs.append(gx)
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
