@@ -10,12 +10,35 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# Collection order of the GPU suite (`-x` stops at the first failure, so what runs first is what is always seen):
+#   0  oracle / reference-golden parity, per op and per model  -- the tests that carry the parity claim
+#   1  self-comparisons and properties (`@pytest.mark.selfcheck`: two HIP paths against each other, determinism, launch variants)
+#   2  control flow around the path: bench.py contract, rank launchers, DDP plumbing
+PARITY_FILES = ["test_ops_gpu", "test_model_gpu", "test_rfm_gpu", "test_modules_gpu", "test_sliding_gpu", "test_oeem_gpu",
+                "test_infer2_gpu", "test_infer4_gpu", "test_contract_gpu"]
+CONTROL_FILES = ["test_bench_gpu", "test_bench_launch", "test_ddp_gpu"]
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "selfcheck: HIP path compared with itself (property / determinism / variant equivalence); "
+                                       "ordered after every oracle-parity test")
+
+
+def _order_key(item):
+    mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+    if mod in CONTROL_FILES:
+        return (2, CONTROL_FILES.index(mod))
+    if "selfcheck" in item.keywords:
+        return (1, PARITY_FILES.index(mod) if mod in PARITY_FILES else len(PARITY_FILES))
+    if mod in PARITY_FILES:
+        return (0, PARITY_FILES.index(mod))
+    return (0, len(PARITY_FILES))  # CPU tests and anything new: with the parity group, after the listed files
 
 
 def pytest_collection_modifyitems(config, items):
-    """GPU tests are skipped (not failed) when no device is visible and -m gpu was not asked for."""
+    """Order the suite (see above; stable within a group), then skip -- not fail -- GPU tests when no device is visible."""
+    items.sort(key=_order_key)
     try:
         import torch
 

@@ -11,16 +11,38 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", autouse=True)
-def debug_library():
-    """This module sweeps the kernels' staging / tiling variants through the `ps_debug_*` switches: those exist only in
-    libpistoseg_hip_debug.so (same sources, -DPS_DEBUG_HOOKS).  With every switch at its default the debug build launches exactly what
-    the product library launches; the model-level test files run on the product library."""
+@pytest.fixture(scope="module", autouse=True, params=["product", "debug"])
+def library(request):
+    """Every test of this module runs against BOTH binaries unless it says otherwise:
+
+    * "product" = libpistoseg_hip.so, what `bench.py` and the model-level tests launch (tunables `constexpr`, no `ps_debug_*` symbols);
+      kernel selection there is a pure function of the geometry, so the cases below include shapes that SELECT the persistent
+      kernels (halo / ws2 / wgrad_ws2) by themselves -- asserted through `ps_conv_variant` / `ps_conv_wgrad_variant`;
+    * "debug" = libpistoseg_hip_debug.so (same sources, -DPS_DEBUG_HOOKS): the staging / tiling variant sweeps that force a kernel
+      through `ps_debug_set_*` exist only there (`@debug_only`).  Same sources is not same code (the hand-scheduled loops are
+      sensitive to any codegen change), hence both."""
     from pistoseg_amd import _lib
 
-    _lib.use_debug_library(True)
-    yield
+    _lib.use_debug_library(request.param == "debug")
+    yield request.param
     _lib.use_debug_library(False)
+
+
+debug_only = pytest.mark.parametrize("library", ["debug"], indirect=True)  # tests that drive `ps_debug_set_*`
+# conv_igemm.hip's variant codes (include/pistoseg_hip.h)
+V_4WAVE, V_WS_128, V_WS_112, V_WS2_256, V_WS2_224, V_OTHER, V_HALO = 1, 2, 3, 4, 5, 6, 7
+
+
+def conv_variant(spec, dtype, n, h, w, kind):
+    """Which kernel family the loaded library selects for this launch (`ps_conv_variant` / `ps_conv_wgrad_variant`)."""
+    import ctypes as C
+
+    from pistoseg_amd import _lib, ops
+
+    g = ops._geom(spec, ops._dt(dtype), n, h, w, spec.cin, spec.cout)
+    if kind == "wgrad":
+        return int(_lib.load().ps_conv_wgrad_variant(C.byref(g)))
+    return int(_lib.load().ps_conv_variant(C.byref(g), 1 if kind == "dgrad" else 0))
 
 
 HALO_RING_DEFAULT = 3  # library default of ps_debug_set_halo_ring
@@ -65,14 +87,16 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("glds", [2, 1, 0])  # operand staging: buffer LDS-DMA (default), flat LDS-DMA, registers
+# operand staging: buffer LDS-DMA (the default: both libraries), flat LDS-DMA and registers (debug switches)
+@pytest.mark.parametrize("library,glds", [("product", 2), ("debug", 2), ("debug", 1), ("debug", 0)], indirect=["library"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_fwd_dgrad_wgrad(case, dtype, glds):
+def test_conv_fwd_dgrad_wgrad(case, dtype, glds, library):
     from pistoseg_amd import _lib, ops
 
     lib = _lib.load()
-    lib.ps_debug_set_glds(glds)
+    if library == "debug":
+        lib.ps_debug_set_glds(glds)
     try:
         cin, cout, k, s, d = case
         if glds != 2 and cin > 256:
@@ -115,7 +139,8 @@ def test_conv_fwd_dgrad_wgrad(case, dtype, glds):
         ops.conv2d_wgrad(spec, xd, gyd, dw)
         assert rel_err(dw.cpu(), w_fwd_layout(wt.grad)) < tol
     finally:
-        lib.ps_debug_set_glds(2)
+        if library == "debug":
+            lib.ps_debug_set_glds(2)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
@@ -406,6 +431,8 @@ def test_scaled_optimizers_fp16_shadow_and_nonfinite():
     assert int(ops.nonfinite_count(t.to(D))) == 3
 
 
+@pytest.mark.selfcheck
+@debug_only
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", [
     # (n, h, w, cin, cout, k, s, d): large enough for the 256x128 three-stage kernel (>= 256 tiles)
@@ -472,6 +499,7 @@ def test_conv_pipelined_kernels_are_bit_identical_to_two_stage(case, dtype):
     assert rel_err(ref[0][:1].float().cpu(), nhwc(cpu)) < tol
 
 
+@debug_only
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", [
     # (n, h, w, cin, cout, d): 3x3 stride 1, width a multiple of 28.  Tiles are 8 rows x 28 columns: on 28x28 maps they straddle
@@ -489,6 +517,7 @@ def test_conv_halo_window_kernel(case, dtype):
     _halo_case(case, dtype, 3)
 
 
+@debug_only
 @pytest.mark.parametrize("ring", [4, 5])
 @pytest.mark.parametrize("case", [(3, 28, 28, 256, 128, 4), (7, 28, 28, 192, 384, 2), (2, 56, 56, 64, 128, 1), (1, 12, 56, 64, 256, 4),
                                   (5, 32, 32, 192, 384, 4), (3, 20, 64, 64, 256, 4)])
@@ -551,14 +580,17 @@ def _halo_case(case, dtype, ring):
     (2, 13, 10, 128, 256, 3, 2, 1), (2, 13, 10, 256, 256, 3, 1, 1), (3, 9, 11, 256, 512, 1, 2, 1), (2, 13, 10, 512, 1024, 3, 1, 2),
     (4, 14, 14, 1024, 2048, 3, 1, 4), (16, 28, 28, 512, 512, 3, 1, 1), (8, 28, 28, 2048, 4096, 1, 1, 1),
 ])
-def test_wgrad_large_tile_persistent_kernel(case, dtype):
-    """conv_wgrad_ws2_kernel (256x128 tile, persistent, 3-stage ring) forced on small and medium problems: against the CPU
-    autograd weight gradient on identically rounded operands, and against the 128x128 kernel (same products, f32 atomics in a
-    different order)."""
+def test_wgrad_large_tile_persistent_kernel(case, dtype, library):
+    """conv_wgrad_ws2_kernel (256x128 tile, persistent, 3-stage ring) against the CPU autograd weight gradient on identically rounded
+    operands.  Product library: only the cases whose geometry SELECTS the kernel (asserted); debug library: forced on every case, and
+    also compared with the 128x128 kernel (same products, f32 atomics in a different order)."""
     from pistoseg_amd import _lib, ops
 
     lib = _lib.load()
     n, h, w, cin, cout, k, s, d = case
+    spec = ops.ConvSpec(cin, cout, k, s, d)
+    if library == "product" and conv_variant(spec, dtype, n, h, w, "wgrad") != 1:
+        pytest.skip("the product library serves this small problem with the 128x128 kernel (covered by test_conv_fwd_dgrad_wgrad)")
     g = torch.Generator().manual_seed(cin + cout + k)
     q = quant(dtype)
     x = q(torch.randn(n, cin, h, w, generator=g))
@@ -566,31 +598,92 @@ def test_wgrad_large_tile_persistent_kernel(case, dtype):
     y = F.conv2d(x, wt, stride=s, padding=d if k == 3 else 0, dilation=d)
     gy = q(torch.randn(y.shape, generator=g))
     y.backward(gy)
-    spec = ops.ConvSpec(cin, cout, k, s, d)
     D = dev()
     xd, gyd = nhwc(x).to(D, dtype), nhwc(gy).to(D, dtype)
+    old = None
     try:
-        lib.ps_debug_set_wgrad_ws2(2)
+        if library == "debug":
+            lib.ps_debug_set_wgrad_ws2(2)
         got = []
         for _ in range(3):  # race screen: repeated launches agree up to f32 atomic ordering
             dw = torch.zeros((cout, k, k, cin), device=D, dtype=torch.float32)
             ops.conv2d_wgrad(spec, xd, gyd, dw)
             got.append(dw)
-        lib.ps_debug_set_wgrad_ws2(0)
-        old = torch.zeros((cout, k, k, cin), device=D, dtype=torch.float32)
-        ops.conv2d_wgrad(spec, xd, gyd, old)
+        if library == "debug":
+            lib.ps_debug_set_wgrad_ws2(0)
+            old = torch.zeros((cout, k, k, cin), device=D, dtype=torch.float32)
+            ops.conv2d_wgrad(spec, xd, gyd, old)
     finally:
-        lib.ps_debug_set_wgrad_ws2(1)
+        if library == "debug":
+            lib.ps_debug_set_wgrad_ws2(1)
     ref = w_fwd_layout(wt.grad)
     for dw in got:
         assert rel_err(dw.cpu(), ref) < 1e-4   # exact products, f32 accumulation
-        assert rel_err(dw.cpu(), old.cpu()) < 1e-5
+        assert old is None or rel_err(dw.cpu(), old.cpu()) < 1e-5
+        assert rel_err(dw.cpu(), got[0].cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case,family", [
+    # (n, h, w, cin, cout, k, s, d): the smallest batches at which the GEOMETRY selects each persistent kernel (>= 256 tiles), ragged:
+    ((19, 28, 28, 128, 512, 3, 1, 1), "halo"),    # 66.5 pixel tiles of 8 x 28: straddles images, ragged last tile; tail half tiles
+    ((10, 56, 56, 64, 256, 3, 1, 2), "halo"),     # two column blocks per row, dilation 2
+    ((17, 32, 32, 64, 512, 3, 1, 4), "halo"),     # 256-pixel tiles (the maps of 256 x 256 inputs), dilation 4
+    ((8, 28, 28, 2048, 4096, 1, 1, 1), "ws2"),    # b7's 1x1 shape
+    ((37, 28, 28, 512, 1024, 1, 1, 1), "ws2"),    # odd image count: ragged last pixel tile
+    ((21, 56, 56, 256, 512, 3, 2, 1), "ws2"),     # stride-2 3x3 (b4's first conv)
+])
+def test_persistent_kernels_selected_by_geometry_match_cpu(case, family, dtype, library):
+    """The kernels the benchmark runs (conv_igemm_halo_kernel, conv_igemm_ws2_kernel, conv_wgrad_ws2_kernel), reached WITHOUT any debug
+    switch -- in the product library that is the only way to reach them -- against CPU autograd on identically rounded operands:
+    forward with the full epilogue (residual add, raw output, BN + ReLU + dropout output), data gradient with the ReLU-mask epilogue,
+    weight gradient (resnet38d.py:16-21,38-41,64,86)."""
+    from pistoseg_amd import ops
+
+    n, h, w, cin, cout, k, s_, d = case
+    spec = ops.ConvSpec(cin, cout, k, s_, d)
+    want = (V_HALO,) if family == "halo" else (V_WS2_256, V_WS2_224)
+    assert conv_variant(spec, dtype, n, h, w, "fwd") in want
+    wg_ws2 = conv_variant(spec, dtype, n, h, w, "wgrad") == 1
+    assert wg_ws2 or cout % 256 or cin % 128  # every eligible shape here is big enough for the persistent weight-gradient kernel
+    g = torch.Generator().manual_seed(sum(case))
+    q = quant(dtype)
+    x = q(torch.randn(n, cin, h, w, generator=g)).requires_grad_(True)
+    wt = q(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5).requires_grad_(True)
+    pad = d if k == 3 else 0
+    y = F.conv2d(x, wt, stride=s_, padding=pad, dilation=d)
+    res = q(torch.randn(y.shape, generator=g))
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    drop = (torch.rand(n, cout, generator=g) > 0.3).float() / 0.7
+    act = F.relu((y + res) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)) * drop.view(n, cout, 1, 1)
+    gy = q(torch.randn(y.shape, generator=g))
+    y.backward(gy)
+    mask_src = q(F.relu(torch.randn(n, cin, h, w, generator=g)))
+    sc2 = torch.rand(cin, generator=g) + 0.5
+    gx_ref = torch.where(mask_src > 0, x.grad * sc2.view(1, -1, 1, 1), torch.zeros(()))
+    tol = TOL[dtype]
+    D = dev()
+    ho, wo = spec.out_hw(h, w)
+    xd, wf, wd = nhwc(x.detach()).to(D, dtype), w_fwd_layout(wt.detach()).to(D, dtype), w_dgrad_layout(wt.detach()).to(D, dtype)
+    gyd = nhwc(gy).to(D, dtype)
+    out_raw = torch.full((n, ho, wo, cout), float("nan"), device=D, dtype=dtype)
+    out_act = torch.full((n, ho, wo, cout), float("nan"), device=D, dtype=dtype)
+    ops.conv2d_fwd(spec, xd, wf, add0=nhwc(res).to(D, dtype), out_raw=out_raw, bn_scale=scale.to(D), bn_shift=shift.to(D), drop=drop.to(D), out_act=out_act)
+    assert rel_err(out_raw.float().cpu(), nhwc((y + res).detach())) < tol
+    assert rel_err(out_act.float().cpu(), nhwc(act.detach())) < tol
+    gx = torch.full((n, h, w, cin), float("nan"), device=D, dtype=dtype)
+    ops.conv2d_dgrad(spec, gyd, wd, (h, w), mask_src=nhwc(mask_src).to(D, dtype), bn_scale=sc2.to(D), out=gx)
+    assert rel_err(gx.float().cpu(), nhwc(gx_ref)) < tol
+    dw = torch.zeros((cout, k, k, cin), device=D, dtype=torch.float32)
+    ops.conv2d_wgrad(spec, xd, gyd, dw)
+    assert rel_err(dw.cpu(), w_fwd_layout(wt.grad)) < 1e-4  # exact products of 16-bit operands, f32 accumulation
 
 
 @pytest.mark.parametrize("case", [(512, 512, 3, 1, 28), (1024, 2048, 3, 4, 28), (256, 256, 3, 1, 56), (2048, 4096, 1, 1, 28)])
-def test_full_size_layers_kernel_families_agree(case):
-    """BASELINE-size layers (bs = 64, bf16), too big for a CPU reference inside the suite: size-independent checks instead.
-    (1) the production kernel for the layer (halo / large-tile) against the small-tile two-blocks-per-CU family on the same data --
+def test_full_size_layers_kernel_families_agree(case, library):
+    """BASELINE-size layers (bs = 64, bf16), too big for a full CPU reference inside the suite: size-independent checks instead, plus
+    image 0's forward on the CPU.
+    (1, debug library) the production kernel for the layer (halo / large-tile) against the small-tile two-blocks-per-CU family on the same data --
     different tilings, staging and (halo) K order, so agreement within bf16 output rounding is strong evidence for both;
     (2) linearity of the forward in its input; (3) <dy, conv(x)> == <dgrad(dy), x> == <wgrad(x, dy), w> (adjoint identities, f32 sums)."""
     from pistoseg_amd import _lib, ops
@@ -617,19 +710,32 @@ def test_full_size_layers_kernel_families_agree(case):
         ops.conv2d_wgrad(spec, x, gy, dw)
         return gx, dw
 
+    # the persistent kernels are what the geometry selects, in either library
+    want = (V_HALO,) if k == 3 else (V_WS2_256, V_WS2_224)
+    for kind in ("fwd", "dgrad"):
+        assert conv_variant(spec, dtype, n, hw, hw, kind) in want, kind
+    assert conv_variant(spec, dtype, n, hw, hw, "wgrad") == 1
     y, (gx, dw) = run(x), run_bwd()
-    try:
-        lib.ps_debug_set_halo(0)
-        lib.ps_debug_set_ws2(0)
-        lib.ps_debug_set_wgrad_ws2(0)
-        y_small, (gx_small, dw_small) = run(x), run_bwd()
-    finally:
-        lib.ps_debug_set_halo(1)
-        lib.ps_debug_set_ws2(WS2_DEFAULT)
-        lib.ps_debug_set_wgrad_ws2(1)
-    assert rel_err(y.float(), y_small.float()) < 8e-3 and rel_err(gx.float(), gx_small.float()) < 8e-3  # one bf16 ulp of the largest output
-    assert float((y.float() - y_small.float()).abs().mean() / y_small.float().abs().mean()) < 1e-3
-    assert rel_err(dw, dw_small) < 1e-4
+    if library == "debug":
+        try:
+            lib.ps_debug_set_halo(0)
+            lib.ps_debug_set_ws2(0)
+            lib.ps_debug_set_wgrad_ws2(0)
+            y_small, (gx_small, dw_small) = run(x), run_bwd()
+        finally:
+            lib.ps_debug_set_halo(1)
+            lib.ps_debug_set_ws2(WS2_DEFAULT)
+            lib.ps_debug_set_wgrad_ws2(1)
+        assert rel_err(y.float(), y_small.float()) < 8e-3 and rel_err(gx.float(), gx_small.float()) < 8e-3  # one bf16 ulp of the largest output
+        assert float((y.float() - y_small.float()).abs().mean() / y_small.float().abs().mean()) < 1e-3
+        assert rel_err(dw, dw_small) < 1e-4
+    # images 0 and 63 of the forward and of the data gradient on the CPU (same bf16-rounded operands)
+    wq = wt.to(dtype).float()
+    for i in (0, n - 1):
+        ref = F.conv2d(x[i:i + 1].float().cpu().permute(0, 3, 1, 2), wq, padding=d if k == 3 else 0, dilation=d)
+        assert rel_err(y[i:i + 1].float().cpu(), nhwc(ref)) < BF16_TOL, i
+        ref = torch.nn.grad.conv2d_input((1, cin, hw, hw), wq, gy[i:i + 1].float().cpu().permute(0, 3, 1, 2), padding=d if k == 3 else 0, dilation=d)
+        assert rel_err(gx[i:i + 1].float().cpu(), nhwc(ref)) < BF16_TOL, i
     # linearity: conv(x + 2 x2) == conv(x) + 2 conv(x2) up to output rounding
     x2 = torch.randn(n, hw, hw, cin, generator=g).to(D, dtype)
     lhs = run((x.float() + 2 * x2.float()).to(dtype)).float()
@@ -647,7 +753,8 @@ def test_full_size_layers_kernel_families_agree(case):
 
 
 @pytest.mark.parametrize("tpb", [1, 2, 5])
-def test_persistent_kernels_batched_work_split_is_exact(tpb):
+@pytest.mark.selfcheck
+def test_persistent_kernels_batched_work_split_is_exact(tpb, library):
     """ps_conv_geom.tiles_per_block = n: the persistent kernels' blocks are dispatched in batches and take n work items each (used while
     an all-reduce shares the GPU).  Only the item -> block assignment changes: forward / data gradient are bit-identical to the
     one-batch schedule, the weight gradient up to f32 atomic ordering."""
@@ -675,19 +782,21 @@ def test_persistent_kernels_batched_work_split_is_exact(tpb):
             ops.conv2d_wgrad(spec, x, gy, dw)
             return y, gx, dw
 
+        # every launch here is served by a persistent kernel by the geometry alone (no switch needed in either library)
+        assert conv_variant(spec, dtype, n, h, w, "fwd") in (V_HALO, V_WS2_224, V_WS2_256)
+        assert conv_variant(spec, dtype, n, h, w, "wgrad") == 1
         try:
             ops.TILES_PER_BLOCK = 0
-            lib.ps_debug_set_wgrad_ws2(2)
             ref = run()
             ops.TILES_PER_BLOCK = tpb
             got = run()
         finally:
             ops.TILES_PER_BLOCK = 0
-            lib.ps_debug_set_wgrad_ws2(1)
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
         assert rel_err(got[2].cpu(), ref[2].cpu()) < 1e-5
 
 
+@debug_only
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("bm", [112, 128, 224, 256])
 @pytest.mark.parametrize("case", [(128, 256, 3, 2, 1), (256, 256, 3, 1, 2), (512, 128, 1, 1, 1)])
@@ -773,11 +882,13 @@ def test_weight_transpose_batched_matches_permute(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("case", [(128, 256, 56, 56, 2), (256, 512, 28, 28, 3), (128, 128, 23, 31, 2)])  # cin, cout, H, W, N (odd sizes: ragged classes)
-def test_stride2_dgrad_parity_class_launches_are_bit_identical(case, dtype):
+# cin, cout, H, W, N (odd sizes: ragged classes); the last case is b4's first conv at a batch where the geometry itself selects the split
+@pytest.mark.parametrize("case", [(128, 256, 56, 56, 2), (256, 512, 28, 28, 3), (128, 128, 23, 31, 2), (256, 512, 56, 56, 37)])
+def test_stride2_dgrad_parity_class_launches_are_bit_identical(case, dtype, library):
     """Stride-2 3x3 data gradient as four parity-class launches (only the live taps of each class) vs the one-launch path that gathers
     all nine taps per pixel: skipping zero contributions does not change any f32 sum, so the outputs must be bit-identical -- with the
-    ReLU-mask + add1 epilogue and with a plain store."""
+    ReLU-mask + add1 epilogue and with a plain store (debug library: both schedules forced); and against the CPU primitive (both
+    libraries; the product library splits exactly when the geometry says so)."""
     from pistoseg_amd import _lib, ops
 
     cin, cout, h, w, n = case
@@ -793,8 +904,9 @@ def test_stride2_dgrad_parity_class_launches_are_bit_identical(case, dtype):
     sc = (torch.rand(cin, generator=g) + 0.5).to(d)
     outs = []
     try:
-        for mode in (0, 2):
-            lib.ps_debug_set_s2split(mode)
+        for mode in ((0, 2) if library == "debug" else (1, 1)):
+            if library == "debug":
+                lib.ps_debug_set_s2split(mode)
             a = torch.full((n, h, w, cin), 7.0, device=d, dtype=dtype)
             b = torch.full((n, h, w, cin), 7.0, device=d, dtype=dtype)
             ops.conv2d_dgrad(spec, gy, wd, (h, w), mask_src=act, bn_scale=sc, add1=add, out=a)
@@ -802,13 +914,16 @@ def test_stride2_dgrad_parity_class_launches_are_bit_identical(case, dtype):
             torch.cuda.synchronize()
             outs.append((a, b))
     finally:
-        lib.ps_debug_set_s2split(1)
+        if library == "debug":
+            lib.ps_debug_set_s2split(1)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     # and against the CPU primitive (same check as test_conv_fwd_dgrad_wgrad)
     q = quant(dtype)
     wt = wd.float().cpu().permute(3, 0, 1, 2).contiguous()  # [cin][kh][kw][cout] -> OIHW of the forward conv
     ref = torch.nn.grad.conv2d_input((n, cin, h, w), wt, q(gy.float().cpu()).permute(0, 3, 1, 2), stride=2, padding=1)
     assert rel_err(outs[1][1].float().cpu().permute(0, 3, 1, 2), ref) < TOL[dtype]
+    full = torch.where(act.float().cpu().permute(0, 3, 1, 2) > 0, ref * sc.cpu().view(1, -1, 1, 1), torch.zeros(())) + add.float().cpu().permute(0, 3, 1, 2)
+    assert rel_err(outs[1][0].float().cpu().permute(0, 3, 1, 2), full) < TOL[dtype]
 
 
 def test_dropout2d_masks_kernel():
@@ -852,9 +967,10 @@ def test_dropout2d_masks_kernel():
     # 9 x 56 x 56 / 224 = 126 x 3 = 378 = 256 + 122 with 122 % 3 != 0 -> NOT split (the tail must be whole pixel tiles)
     (24, 28, 28, 64, 512, 1), (24, 28, 28, 128, 512, 4), (20, 32, 32, 64, 512, 2), (9, 56, 56, 64, 384, 1),
 ])
-def test_conv_halo_tail_as_half_tiles(case, dtype):
+def test_conv_halo_tail_as_half_tiles(case, dtype, library):
     """The partial last round of a halo launch goes to a second launch of 64-cout half tiles: same MFMA chain per output element, so
-    forward (full epilogue) and data gradient are BIT-IDENTICAL to the single-launch schedule, and match the CPU."""
+    forward (full epilogue) and data gradient are BIT-IDENTICAL to the single-launch schedule (debug library: both forced), and match
+    the CPU (both libraries: these geometries select the halo kernel and its tail split by themselves)."""
     from pistoseg_amd import _lib, ops
 
     lib = _lib.load()
@@ -886,15 +1002,19 @@ def test_conv_halo_tail_as_half_tiles(case, dtype):
         ops.conv2d_dgrad(spec_t, gyd, wdt, (h, w), out_raw=gx)
         return out_raw, out_act, gx
 
-    try:
-        lib.ps_debug_set_halo_tail(1)
+    assert conv_variant(spec, dtype, n, h, w, "fwd") == V_HALO and conv_variant(spec_t, dtype, n, h, w, "dgrad") == V_HALO
+    if library == "debug":
+        try:
+            lib.ps_debug_set_halo_tail(1)
+            split = [run() for _ in range(2)]
+            lib.ps_debug_set_halo_tail(0)
+            single = run()
+        finally:
+            lib.ps_debug_set_halo_tail(1)
+        for a_, b_ in zip(split[0], single):
+            assert torch.equal(a_, b_)
+    else:
         split = [run() for _ in range(2)]
-        lib.ps_debug_set_halo_tail(0)
-        single = run()
-    finally:
-        lib.ps_debug_set_halo_tail(1)
-    for a_, b_ in zip(split[0], single):
-        assert torch.equal(a_, b_)
     assert all(torch.equal(a_, b_) for a_, b_ in zip(split[0], split[1]))
     tol = TOL[dtype]
     for a_, r_ in zip(split[0], (nhwc((y + res).detach()), nhwc(act.detach()), nhwc(gx_ref))):
