@@ -58,10 +58,11 @@ def parse():
     ap.add_argument("--no-infer", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="weight gradients on the launch stream instead of a second stream")
     ap.add_argument("--cpu-tiles", type=int, default=8, help="tiles per CPU-baseline step (SURVEY 8d: bs=8, 1 warm-up + 3 timed)")
-    ap.add_argument("--workload", default="seg", choices=["seg", "rfm", "infer2"],
+    ap.add_argument("--workload", default="seg", choices=["seg", "rfm", "infer2", "infer4"],
                     help="seg: BASELINE configs[1]/[4] (segmentation_train.py step, the headline metric); rfm: configs[3], the stage-3 step "
                          "(revise_pseudo_labels.py train_epoch body: RFM net, cls + rfm + ecr losses, PolyOptimizer); infer2: configs[2], the "
-                         "stage-2 loop (infer_pseudo_masks.py:116-154) over this rank's shard of --steps x --batch tiles")
+                         "stage-2 loop (infer_pseudo_masks.py:116-154) over this rank's shard of --steps x --batch tiles; infer4: the stage-4 loop "
+                         "(infer_revise_masks.py:115-143: RFM net forward + three label-masked argmax maps; use --tile 256, the size that script resizes to)")
     ap.add_argument("--tta", action="store_true", help="infer2: d4 test-time augmentation (8 views per tile) as infer_pseudo_masks.py:96")
     ap.add_argument("--pack", default=None, help="infer2: write logits_32x32 of every rank into this ONE packed file")
     ap.add_argument("--streams", type=int, default=1, help="infer2: HIP streams that consecutive (independent) batches alternate between")
@@ -211,6 +212,38 @@ def cpu_baseline(tiles, tile, classes):
     return out
 
 
+def cpu_baseline_rfm(tiles, tile, c):
+    """The CPU oracle's stage-3 step (revise_forward + rfm_losses + autograd + SGD with the PolyOptimizer's effective settings) on a
+    bounded sample: bs = `tiles`, one warm-up + three timed steps on all host threads, median."""
+    from oracle import ref_cpu
+
+    sd = ref_cpu.make_state_dict(c, True, seed=42)
+    tk = ref_cpu.trainable_keys(sd)
+    params = [sd[k].requires_grad_(True) for k in tk]
+    opt = torch.optim.SGD(params, lr=0.01, momentum=5e-4, weight_decay=5e-4)
+    g = torch.Generator().manual_seed(4321)
+    x = torch.randn(tiles, 3, tile, tile, generator=g)
+    pm = torch.cat([torch.zeros(tiles, 1, 32, 32), torch.randn(tiles, c - 1, 32, 32, generator=g)], 1)
+    pc = torch.cat([torch.zeros(tiles, 1, 32, 32), torch.randn(tiles, c - 1, 32, 32, generator=g)], 1)
+    lab = (torch.rand(tiles, c - 1, generator=g) < 0.5).float()
+    lab[torch.arange(tiles), torch.randint(0, c - 1, (tiles,), generator=g)] = 1.0
+    label = torch.cat([torch.ones(tiles, 1), lab], 1).view(tiles, c, 1, 1)
+
+    def step():
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        outs = ref_cpu.revise_forward(sd, x, pm, pc)
+        ref_cpu.rfm_losses(outs, pm, pc, label, (tile, tile))[0].backward()
+        opt.step()
+        return time.perf_counter() - t0
+
+    step()
+    dt = sorted(step() for _ in range(3))[1]
+    return {"value": round(tiles / dt, 4), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"stage-3 step (RFM forward + cls/rfm/ecr losses + backward + SGD) on {tiles} synthetic {tile}x{tile} tiles, torch CPU fp32: "
+                      "1 warm-up + 3 timed steps, median"}
+
+
 def rfm_bench(args, world, rank, dev, dist_on):
     """BASELINE configs[3]: stage-3 training step (RFM net + feature-consistency losses + PolyOptimizer), DDP buckets as for seg."""
     from pistoseg_amd.revise_net import Net
@@ -234,16 +267,39 @@ def rfm_bench(args, world, rank, dev, dist_on):
     for _ in range(args.warmup):
         step()
     dt = timed(step, args.steps, dist_on)
+
+    def serial_step():  # the instrumented step runs the weight gradients on the launch stream: per-kernel times are exclusive
+        ws, tr.wgrad_stream = tr.wgrad_stream, None
+        try:
+            step()
+        finally:
+            tr.wgrad_stream = ws
+
+    roof = None
+    if rank == 0:
+        roof = roofline_leg(serial_step, args.precision)
+    else:
+        serial_step()  # lockstep: the instrumented step contains collectives
+    cpu = cpu_baseline_rfm(args.cpu_tiles, args.tile, c) if rank == 0 and world == 1 and not args.no_cpu_baseline else None
     if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank == 0:
-        print(json.dumps({
-            "metric": "224x224 tiles/sec (RFM stage-3 train fwd+bwd+opt)", "value": round(world * n * args.steps / dt, 2), "unit": "tiles/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+        value = world * n * args.steps / dt
+        out = {
+            "metric": "224x224 tiles/sec (RFM stage-3 train fwd+bwd+opt)", "value": round(value, 2), "unit": "tiles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "ms_per_step_median_hip_events": round(timed.median_ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"BASELINE configs[3]: revise_pseudo_labels.py train_epoch step, RFM net C={c}, cls+rfm+ecr losses, PolyOptimizer",
-                       "per_gpu_batch": n, "global_batch": n * world, "tile": args.tile, "parallelism": f"dp{world}"}}))
+                       "per_gpu_batch": n, "global_batch": n * world, "tile": args.tile, "parallelism": f"dp{world}"},
+            "train_conv_tflops_per_gpu": round(value / world * GFLOP_TRAIN_PER_TILE * (args.tile / 224.0) ** 2 / 1e3, 1),
+            "roofline": roof}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        if TEST_BACKEND:
+            out["test_backend"] = TEST_BACKEND + ": ranks share GPUs, numbers are not measurements"
+        print(json.dumps(out))
 
 
 def infer2_bench(args, world, rank, dev, dist_on):
@@ -331,6 +387,84 @@ def infer2_bench(args, world, rank, dev, dist_on):
                               "us_per_batch": round(1e3 * tail, 1)}}))
 
 
+def infer4_bench(args, world, rank, dev, dist_on):
+    """Stage 4 (infer_revise_masks.py:93-143): the RFM net behind the reference's `nn.DataParallel` wrapper, `infer`'s loop -- zero
+    background channels, forward, `(X_rv * label)[:, 1:]` -> argmax x 3 -- over a tile set sharded by contiguous ranges, no collective on
+    the data path.  Every rank owns --steps x --batch tiles (weak scaling) resident in HBM; the script itself resizes to 256 x 256 (:46):
+    run with --tile 256.  One timed pass = `infer.infer_revise_masks_sharded` over the rank's whole shard, a step = one batch of it."""
+    from pistoseg_amd import infer
+    from pistoseg_amd.revise_net import Net
+    from pistoseg_amd.trainer import init_weights_he
+
+    c, n, s = args.classes + 1, args.batch, args.tile  # n_class + background (infer_revise_masks.py:108)
+    net = Net(num_classes=c, precision=args.precision)
+    init_weights_he(net, seed=42)
+    model = torch.nn.DataParallel(net.to(dev), device_ids=[dev.index]).to(dev)  # :110 (one device per process: the wrapper only adds `module.`)
+    per_rank = args.steps * n
+    total = per_rank * world
+    lo, hi = rank * per_rank, (rank + 1) * per_rank
+    g = torch.Generator(device="cpu").manual_seed(555 + rank)
+    base = torch.randn(n, 3, s, s, generator=g).to(dev)
+    images = base.repeat(args.steps, 1, 1, 1)
+    pmask = torch.randn(per_rank, c - 1, 32, 32, generator=g).to(dev)
+    cam = torch.randn(per_rank, c - 1, 32, 32, generator=g).to(dev)
+    lab = (torch.rand(per_rank, c - 1, generator=g) < 0.5).float()
+    lab[torch.arange(per_rank), torch.randint(0, c - 1, (per_rank,), generator=g)] = 1.0
+    lab = lab.to(dev)
+
+    class _Shard:  # [T,...] view whose rows [lo, hi) live on this rank
+        def __init__(self, t):
+            self.t, self.shape = t, (total,) + tuple(t.shape[1:])
+
+        def __getitem__(self, sl):
+            return self.t[sl.start - lo:sl.stop - lo]
+
+    def one_pass():
+        return infer.infer_revise_masks_sharded(model, _Shard(images), _Shard(pmask), _Shard(cam), _Shard(lab), batch_size=n, rank=rank, world=world)
+
+    for _ in range(max(1, min(args.warmup, 2))):
+        one_pass()
+    dt = timed(one_pass, 1, dist_on)
+    out_lo, out_hi, m0, m1, m2 = one_pass()
+    assert (out_lo, out_hi) == (lo, hi) and all(tuple(m.shape) == (per_rank, s, s) and m.dtype == torch.uint8 for m in (m0, m1, m2))
+
+    # per-pixel tail of a batch: the three label-masked argmax maps (HBM-bound): read 3 x C x S^2 f32, write 3 x S^2 u8 per tile
+    pm, pc = infer._with_background(pmask[:n], dev), infer._with_background(cam[:n], dev)
+    labf = torch.cat([torch.ones(n, 1, device=dev), lab[:n]], 1)
+    with torch.no_grad():
+        _, cam_rv, pmask_rv, pcam_rv = model(base, pm, pc)
+    from pistoseg_amd import _lib, ops
+    tail_ms = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for t in (pmask_rv, pcam_rv, cam_rv):
+            ops.argmax_mask(t, mode=_lib.PS_MASK_MUL, first_ch=1, label=labf)
+        e1.record()
+        torch.cuda.synchronize()
+        tail_ms.append(e0.elapsed_time(e1))
+    tail = sorted(tail_ms)[2]
+    tail_bytes = n * 3 * (c * s * s * 4 + s * s)
+    if dist_on:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        value = total / dt
+        out = {
+            "metric": f"{s}x{s} tiles/sec (stage-4 revise-mask inference)", "value": round(value, 2),
+            "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"infer_revise_masks.py stage-4 loop over {total} synthetic tiles sharded by contiguous ranges: RFM net C={c} behind "
+                                   "nn.DataParallel, forward + 3 label-masked argmax maps", "per_gpu_batch": n, "tiles_per_gpu": per_rank, "tile": s,
+                       "parallelism": f"dp{world}"},
+            "infer_conv_tflops_per_gpu": round(value / world * GFLOP_FWD_PER_TILE * (s / 224.0) ** 2 / 1e3, 1),
+            "roofline_tail": {"bound": "hbm", "kernel": "argmax_mask(mul) x 3", "achieved": round(tail_bytes / (tail * 1e-3) / 1e9, 1), "peak": 8000.0,
+                              "unit": "GB/s", "frac": round(tail_bytes / (tail * 1e-3) / 8e12, 4), "bytes_per_batch": tail_bytes, "us_per_batch": round(1e3 * tail, 1)}}
+        if TEST_BACKEND:
+            out["test_backend"] = TEST_BACKEND + ": ranks share GPUs, numbers are not measurements"
+        print(json.dumps(out))
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -371,6 +505,8 @@ def main():
         return rfm_bench(args, world, rank, dev, dist_on)
     if args.workload == "infer2":
         return infer2_bench(args, world, rank, dev, dist_on)
+    if args.workload == "infer4":
+        return infer4_bench(args, world, rank, dev, dist_on)
     model = ResNet38dSeg(classes=args.classes, precision=args.precision)
     init_weights_he(model, seed=42)
     model = model.to(dev)

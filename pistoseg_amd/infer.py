@@ -88,3 +88,42 @@ def infer_revise_masks(model, x: Tensor, pmask: Tensor, pcam: Tensor, label: Ten
     _, cam_rv, pmask_rv, pcam_rv = model(x, pmask, pcam)
     lab = label.reshape(x.shape[0], -1).to(cam_rv.device)
     return tuple(ops.argmax_mask(t, mode=_lib.PS_MASK_MUL, first_ch=1, label=lab) for t in (pmask_rv, pcam_rv, cam_rv))
+
+
+def _with_background(t: Tensor, dev) -> Tensor:
+    """infer_revise_masks.py:125-128: `torch.concat([zeros(n,1,h,w), t], dim=1).cuda()` -- a zero background channel in front."""
+    n, c, h, w = t.shape
+    out = torch.zeros((n, c + 1, h, w), device=dev, dtype=torch.float32)
+    out[:, 1:].copy_(t, non_blocking=True)
+    return out
+
+
+@torch.no_grad()
+def infer_revise_masks_sharded(model, images, pmask, cam, label, batch_size: int = 64, rank: int = 0, world: int = 1):
+    """Stage 4 as the reference runs it (infer_revise_masks.py:115-143, `infer(dataloader, model, args)`) over this rank's contiguous
+    shard of the dataset tensors -- what `RefineDataset` (:28-69) yields, stacked: images [T,3,S,S] (S = 256, :46), pmask [T,C-1,32,32]
+    (`logits_32x32/*.pt`), cam [T,C-1,32,32] (`*.npy`), label [T,C-1] -- host or device resident.  Per batch: zero background channel
+    in front of pmask / cam (:125-128), background score 1 in front of the label (:130-133), `model(x, pmask, pcam)` (:135),
+    `(X_rv * label)[:, 1:]` -> `argmax(dim=1)` for pmask_rv, pcam_rv, cam_rv (:137-143).  `model` is the RFM net or an
+    `nn.DataParallel` wrapper around it (:108-111: the checkpoint keys carry `module.`).
+    Returns (lo, hi, pmask_rv_mask, pcam_rv_mask, cam_rv_mask): uint8 [hi-lo, S, S] on the device, values 0..C-2.  No collective on
+    the data path (tiles are independent); `dist.gather_masks` collects them on rank 0 when one host writes the PNGs (:145-210,
+    host-side I/O, out of scope)."""
+    net = model.module if isinstance(model, torch.nn.DataParallel) else model
+    dev = next(net.parameters()).device
+    model.eval()
+    lo, hi = shard_range(images.shape[0], rank, world)
+    outs = ([], [], [])
+    for s in range(lo, hi, batch_size):
+        e = min(hi, s + batch_size)
+        x = images[s:e].to(dev, non_blocking=True)
+        pm = _with_background(pmask[s:e], dev)
+        pc = _with_background(cam[s:e], dev)
+        lab = torch.ones((e - s, label.shape[1] + 1), device=dev, dtype=torch.float32)
+        lab[:, 1:].copy_(label[s:e], non_blocking=True)
+        _, cam_rv, pmask_rv, pcam_rv = model(x, pm, pc)
+        for acc, t in zip(outs, (pmask_rv, pcam_rv, cam_rv)):
+            acc.append(ops.argmax_mask(t, mode=_lib.PS_MASK_MUL, first_ch=1, label=lab))
+    size = tuple(images.shape[-2:])
+    cat = lambda xs: torch.cat(xs, 0) if xs else torch.empty((0,) + size, device=dev, dtype=torch.uint8)
+    return (lo, hi) + tuple(cat(a) for a in outs)

@@ -34,6 +34,15 @@ def test_bench_json_contract_small_config():
     assert c["kind"] in ("port", "reference") and c["unit"] == "tiles/s" and c["value"] > 0 and c["cores"] >= 1 and isinstance(c["sample"], str)
 
 
-def test_bench_rfm_workload_runs():
-    d = run_bench("--workload", "rfm", "--batch", "2", "--tile", "64", "--steps", "2", "--warmup", "1")
+def test_bench_rfm_workload_carries_roofline_and_cpu_baseline():
+    d = run_bench("--workload", "rfm", "--batch", "2", "--tile", "64", "--steps", "2", "--warmup", "1", "--cpu-tiles", "1")
     assert d["value"] > 0 and "configs[3]" in d["config"]["workload"] and d["n_gpus"] == 1
+    r, c = d["roofline"], d["cpu_baseline"]
+    assert r["bound"] == "mfma" and r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "stage-3" in c["sample"]
+
+
+def test_bench_infer4_workload_runs():
+    d = run_bench("--workload", "infer4", "--batch", "2", "--tile", "64", "--steps", "2", "--warmup", "1")
+    assert d["value"] > 0 and "infer_revise_masks.py" in d["config"]["workload"] and d["config"]["tiles_per_gpu"] == 4
+    assert d["roofline_tail"]["bound"] == "hbm" and d["roofline_tail"]["achieved"] > 0

@@ -40,7 +40,7 @@ def test_bench_gpus_2_launches_two_rccl_ranks_when_the_box_has_them():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload", ["seg", "rfm", "infer2"])
+@pytest.mark.parametrize("workload", ["seg", "rfm", "infer2", "infer4"])
 def test_bench_multi_rank_control_flow_on_a_shared_gpu(workload):
     """The N > 1 control flow of bench.py -- child torch.distributed.run launch, init, barrier-bracketed timing with MAX over ranks, the
     lockstep instrumented step (it contains collectives), teardown, ONE JSON line from rank 0 -- with two ranks sharing the test GPU over gloo
@@ -52,9 +52,9 @@ def test_bench_multi_rank_control_flow_on_a_shared_gpu(workload):
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["steps"] == 2 and line["scaling"] == "weak"
-    if workload == "infer2":
+    if workload in ("infer2", "infer4"):
         assert line["config"]["tiles_per_gpu"] == 4 and line["value"] > 0
     else:
         assert line["config"]["global_batch"] == 4 and line["value"] > 0
-    if workload == "seg":
+    if workload in ("seg", "rfm"):
         assert "roofline" in line and "cpu_baseline" not in line and "test_backend" in line

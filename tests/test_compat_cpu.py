@@ -101,3 +101,36 @@ def test_convert_mxnet_to_torch_matches_reference_key_map():
     assert not res.unexpected_keys and all(k.endswith("num_batches_tracked") for k in res.missing_keys)
     k = "b5_1.conv_branch2a.weight"
     assert torch.equal(net.state_dict()[k], torch.from_numpy(src["arg:res5b1_branch2a_weight"].a))
+
+
+def test_rfm_net_checkpoint_contract_under_dataparallel_wrapper(tmp_path):
+    """Stage 3 saves the state of a `nn.DataParallel` wrapper (`revise_pseudo_labels.py:186,214`): a FLAT dict of 233 `module.*` keys;
+    stage 4 wraps a fresh net and only then loads it (`infer_revise_masks.py:108-111`).  Host-side contract of the mirror (no GPU needed):
+    same key set as the oracle's state dict behind the prefix, strict reload after wrapping, values round-trip, `.eval()` of the wrapper
+    reaches the module's quirky `train()` (returns None for the module, the wrapper itself for the wrapper)."""
+    import torch
+
+    from oracle import ref_cpu
+    from pistoseg_amd.revise_net import Net
+
+    sd = ref_cpu.make_state_dict(4, True, seed=42)
+    net = Net(num_classes=4, precision="fp32")
+    net.load_state_dict(sd, strict=False)
+    wrapped = torch.nn.DataParallel(net)
+    state = wrapped.state_dict()
+    assert len(state) == 233 and sorted(state) == sorted("module." + k for k in sd)
+    path = str(tmp_path / "ResNet38-RFM.pth")
+    torch.save(state, path)
+    fresh = torch.nn.DataParallel(Net(num_classes=4, precision="fp32"))
+    res = fresh.load_state_dict(torch.load(path))
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in sd.items():
+        assert torch.equal(fresh.module.state_dict()[k], v), k
+    assert fresh.eval() is fresh and not fresh.module.training and fresh.module.eval() is None
+    # a checkpoint saved WITHOUT the wrapper is refused by the wrapped net (and vice versa): the prefix is part of the layout
+    import pytest
+
+    with pytest.raises(RuntimeError):
+        fresh.load_state_dict(sd)
+    with pytest.raises(RuntimeError):
+        Net(num_classes=4, precision="fp32").load_state_dict(state)

@@ -765,7 +765,7 @@ def test_persistent_kernels_batched_work_split_is_exact(tpb, library):
     dtype = torch.bfloat16
     g = torch.Generator().manual_seed(31 + tpb)
     # > 256 tiles / items each: halo (3x3 on 28x28), ws2 (1x1), wgrad ws2
-    cases = [(40, 28, 28, 256, 256, 3, 2), (36, 28, 28, 512, 256, 1, 1)]
+    cases = [(40, 28, 28, 256, 256, 3, 2), (36, 28, 28, 512, 512, 1, 1)]
     for n, h, w, cin, cout, k, d in cases:
         x = torch.randn(n, h, w, cin, generator=g).to(D, dtype)
         wt = (torch.randn(cout, cin, k, k, generator=g) * 0.03)

@@ -316,6 +316,67 @@ def test_rfm_trainer_step_matches_autograd_path_and_poly_optimizer():
             assert float((s1[k] - s2[k]).abs().max()) <= 1e-5 + 1e-3 * float((s2[k] - sd[k]).abs().max()), k
 
 
+def test_rfm_trainer_step_at_baseline_config3_shape_vs_oracle():
+    """BASELINE configs[3] at ITS shape: `RFMTrainer.train_step` on bs = 32 tiles of 224 x 224, C = 4 (n_class + background), dropout masks
+    injected on both sides, against the CPU oracle's `revise_forward` + `rfm_losses` + autograd on the SAME 32 tiles and weights
+    (revise_pseudo_labels.py:250-282).  Every loss of the block is a mean over samples of per-sample terms, so the oracle runs the batch
+    in chunks of 4 tiles (bounded host memory) and the chunk losses / gradients average exactly.
+    fp32 path: the four losses to 1e-4, every trainable tensor's gradient per-tensor L2 (the arena after a step with lr = 0);
+    bf16 path (what `bench.py --workload rfm` times; not the parity path): same comparison at bf16 tolerances, reported."""
+    from pistoseg_amd.revise_net import Net
+    from pistoseg_amd.trainer import RFMTrainer
+
+    n, s, c, chunk = 32, 224, 4, 4
+    sd = ref_cpu.make_state_dict(c, True, seed=42)
+    x, pmask, pcam, lab = make_inputs(n, s, c, seed=180)
+    pm, pc, label = with_bg(pmask, pcam, lab)
+    g = torch.Generator().manual_seed(181)
+    drop = {name: (torch.rand(n, ch, generator=g) >= p).float() / (1 - p)
+            for name, ch, p in (("b6.dropout_2b1", 512, 0.3), ("b6.dropout_2b2", 1024, 0.3), ("b7.dropout_2b1", 1024, 0.5),
+                                ("b7.dropout_2b2", 2048, 0.5), ("dropout7", 4096, 0.5))}
+
+    # ---- oracle: chunked forward + losses + autograd, averaged
+    sd_ref = {k: v.clone() for k, v in sd.items()}
+    tk = ref_cpu.trainable_keys(sd_ref)
+    for k in tk:
+        sd_ref[k].requires_grad_(True)
+    ref_losses = [0.0] * 4
+    for lo in range(0, n, chunk):
+        sl = slice(lo, lo + chunk)
+        outs = ref_cpu.revise_forward(sd_ref, x[sl], pm[sl], pc[sl], {k: v[sl] for k, v in drop.items()})
+        losses = ref_cpu.rfm_losses(outs, pm[sl], pc[sl], label[sl], (s, s))
+        (losses[0] * (chunk / n)).backward()
+        for i, v in enumerate(losses):
+            ref_losses[i] += float(v) * chunk / n
+
+    names = ("loss", "loss_cls", "loss_rfm", "loss_ecr")
+    for precision, loss_tol, grad_tol in (("fp32", 1e-4, 5e-3), ("bf16", 5e-2, 2.5e-1)):
+        model = build(c, precision, sd)
+        model.train()
+        assert sorted(model.sample_dropout(2, D)) == sorted(drop)
+        model.sample_dropout = lambda n_, dev_: {k: v.to(dev_) for k, v in drop.items()}
+        tr = RFMTrainer(model, lr=0.0, wt_dec=0.0, max_step=10)  # lr = 0: the step leaves weights alone and the arena holds the gradient
+        got = [float(v) for v in tr.train_step(x.to(D), pm.to(D), pc.to(D), label.reshape(n, c).to(D))]
+        torch.cuda.synchronize()
+        for nm, a, b in zip(names, got, ref_losses):
+            assert abs(a - b) <= loss_tol * abs(b), (precision, nm, a, b)
+        assert sorted(tr.offsets) == sorted(tk)
+        worst = ("", 0.0)
+        for k in tk:
+            o, cnt = tr.offsets[k]
+            co, ci, kh, kw = sd[k].shape
+            a = tr.g_flat[o:o + cnt].view(co, kh, kw, ci).permute(0, 3, 1, 2).cpu().double()
+            b = sd_ref[k].grad.double()
+            e = float((a - b).norm() / b.norm())
+            worst = max(worst, (k, e), key=lambda t: t[1])
+            assert e < grad_tol, (precision, k, e)
+        print(f"[parity] configs[3] RFM step bs=32 224x224 {precision} vs CPU oracle: losses "
+              + ", ".join(f"{nm} {a:.6f}/{b:.6f}" for nm, a, b in zip(names, got, ref_losses))
+              + f"; worst per-tensor gradient L2 rel err {worst[1]:.3e} ({worst[0]})")
+        del tr, model
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("largest", [True, False])
 @pytest.mark.parametrize("shape", [(5, 50176), (3, 200704), (2, 777), (1, 64)])
 def test_topk_select_multi_block_matches_torch_topk(shape, largest):
