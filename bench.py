@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="weight gradients without atomics (ps_conv2d_wgrad_det): the reference's Trainer(deterministic=True) / use_deterministic_algorithms(True)")
     ap.add_argument("--no-overlap", action="store_true", help="weight gradients on the launch stream instead of a second stream")
     ap.add_argument("--cpu-tiles", type=int, default=8, help="tiles per CPU-baseline step (SURVEY 8d: bs=8, 1 warm-up + 3 timed)")
     ap.add_argument("--workload", default="seg", choices=["seg", "rfm", "infer2", "infer4"],
@@ -254,7 +256,7 @@ def rfm_bench(args, world, rank, dev, dist_on):
     init_weights_he(model, seed=42)
     model = model.to(dev)
     tr = RFMTrainer(model, lr=0.01, wt_dec=5e-4, max_step=10 ** 6, process_group=torch.distributed.group.WORLD if dist_on else None,
-                    overlap_wgrad=not args.no_overlap)
+                    overlap_wgrad=not args.no_overlap, deterministic=args.deterministic)
     g = torch.Generator(device="cpu").manual_seed(4321 + rank)
     n = args.batch
     x = torch.randn(n, 3, args.tile, args.tile, generator=g).to(dev)
@@ -511,7 +513,8 @@ def main():
     init_weights_he(model, seed=42)
     model = model.to(dev)
     trainer = SegTrainer(model, lr=1e-3, weight_decay=0.05, ignore_index=args.classes,
-                         process_group=torch.distributed.group.WORLD if dist_on else None, overlap_wgrad=not args.no_overlap)
+                         process_group=torch.distributed.group.WORLD if dist_on else None, overlap_wgrad=not args.no_overlap,
+                         deterministic=args.deterministic)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     x = torch.randn(args.batch, 3, args.tile, args.tile, generator=g).to(dev)
     y = torch.randint(0, args.classes + 1, (args.batch, args.tile, args.tile), generator=g).to(dev)
@@ -532,7 +535,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{1 if (args.classes, args.precision, args.batch) == (3, 'bf16', 64) else 4}]: segmentation_train.py step, "
                                f"ResNet38-d seg model, {args.classes}-class CE(ignore={args.classes}), AdamW, random-init",
-                   "per_gpu_batch": args.batch, "global_batch": args.batch * world, "tile": args.tile, "parallelism": f"dp{world}"},
+                   "per_gpu_batch": args.batch, "global_batch": args.batch * world, "tile": args.tile, "parallelism": f"dp{world}",
+                   "deterministic": bool(args.deterministic)},
         "train_conv_tflops_per_gpu": round(value / world * GFLOP_TRAIN_PER_TILE * (args.tile / 224.0) ** 2 / 1e3, 1),
     }
     if TEST_BACKEND:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PS_VERSION 200 /* major*10000 + minor*100 + patch */
+#define PS_VERSION 210 /* major*10000 + minor*100 + patch */
 
 typedef enum ps_status {
   PS_OK = 0,
@@ -116,6 +116,17 @@ int ps_conv2d_dgrad(const ps_conv_geom* g, const void* dy, const void* w_dgrad, 
 /* dW_fwd[cout][kh][kw][cin] (f32) += sum over pixels dy[m,cout] * x[m@tap,cin].  ACCUMULATES with f32
  * atomics (split over pixel ranges): zero dw first.  replaces: autograd of F.conv2d w.r.t. its weight. */
 int ps_conv2d_wgrad(const ps_conv_geom* g, const void* x, const void* dy, float* dw, void* stream);
+/* The same result WITHOUT atomics -- bit-identical from run to run: every pixel range (split-K part) of a weight tile stores its f32
+ * partial sums into its own slice of a caller workspace, and a second kernel adds the slices to dw in range order (one thread per
+ * element: a fixed summation order).  dw is accumulated into, as above.  workspace: >= ps_conv2d_wgrad_det_workspace_bytes(g) bytes,
+ * 16-byte aligned, contents need not be initialised and are clobbered; 0 bytes (NULL allowed) when the problem is not split -- every
+ * element of dw then receives exactly one addition and the atomic kernel is already deterministic.
+ * replaces: autograd of F.conv2d w.r.t. its weight under the reference's determinism switches --
+ * torch.use_deterministic_algorithms(True) (revise_pseudo_labels.py:140-146), pl.Trainer(deterministic=True)
+ * (segmentation_train.py:153-160). */
+int64_t ps_conv2d_wgrad_det_workspace_bytes(const ps_conv_geom* g);
+int ps_conv2d_wgrad_det(const ps_conv_geom* g, const void* x, const void* dy, float* dw, void* workspace, int64_t workspace_bytes,
+                        void* stream);
 
 /* dst[cin][taps][cout] = src[cout][taps][cin]; same 16-bit dtype on both sides, f32 -> f32, or f32 -> bf16/f16 (cast). */
 int ps_weight_transpose(int32_t src_dtype, int32_t dst_dtype, const void* src, void* dst, int32_t cout, int32_t taps,

@@ -84,6 +84,8 @@ PROTOTYPES = {
     "ps_conv2d_fwd": (C.c_int, [C.POINTER(ConvGeom), _P, _P, C.POINTER(Epilogue), _P]),
     "ps_conv2d_dgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _P, C.POINTER(Epilogue), _P]),
     "ps_conv2d_wgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _P, _P, _P]),
+    "ps_conv2d_wgrad_det_workspace_bytes": (C.c_int64, [C.POINTER(ConvGeom)]),
+    "ps_conv2d_wgrad_det": (C.c_int, [C.POINTER(ConvGeom), _P, _P, _P, _P, _L, _P]),
     "ps_weight_transpose": (C.c_int, [_I, _I, _P, _P, _I, _I, _I, _P]),
     "ps_weight_transpose_batched": (C.c_int, [_I, _I, _I, C.POINTER(WtItem), _P]),
     "ps_copy_rows": (C.c_int, [_P, _L, _P, _L, _L, _L, _P]),

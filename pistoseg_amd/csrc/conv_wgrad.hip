@@ -33,6 +33,8 @@ struct WgradArgs {
   int raster;                  // block order (see kernel)
   int ablate;                  // timing experiments only (results WRONG): 1 = no atomics, 2 = plain stores instead of atomics
   int nb, tpb;                 // persistent kernel: blocks per batch (#CUs), items per block (0 = one batch), see ps_block_items
+  float* part;                 // deterministic mode (DET kernels): workspace [pixel range][cout][taps][cin] f32 for the partial sums
+  long long part_stride;       // elements per pixel range = cout * taps * cin
 };
 
 struct WTraitsBF16 {
@@ -65,7 +67,10 @@ constexpr unsigned PAD_ROW = 0x80000000u;
 // WS (wave-specialised): 8 waves; waves 4-7 only issue the LDS-DMA (and track the tap-shifted pixel addresses), waves
 // 0-3 only do transposed LDS reads + MFMA, <= 128 VGPRs so two blocks stay resident per CU (same idea and measurement
 // as conv_igemm_ws_kernel: issuing the DMAs costs a wave more issue time than its MFMAs).
-template <typename Tr, int BCO, int BCI, bool WS>
+// DET (deterministic mode, ps_conv2d_wgrad_det): the block STORES its partial sums into its pixel range's slice of the workspace
+// (every element of a slice is written by exactly one block) instead of adding them to dw with atomics; wgrad_reduce_kernel adds the
+// slices up in range order afterwards.
+template <typename Tr, int BCO, int BCI, bool WS, bool DET = false>
 __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 1) void conv_wgrad_kernel(const WgradArgs a) {
   constexpr int ES = Tr::ES, KP = Tr::KP;
   constexpr int RBG = BCO * ES, RBX = BCI * ES;           // LDS row bytes of the dY / X tiles
@@ -264,8 +269,26 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 1) void conv_wgrad_kernel(
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + wr * (BCO / 2) + i * 16 + 4 * g + r;
         const int ci = ci0 + wc * (BCI / 2) + j * 16 + l16;
-        atomicAdd(a.dw + co * wrow + (long long)tap * a.cin + ci, acc[i][j][r]);
+        if constexpr (DET) a.part[(long long)split * a.part_stride + co * wrow + (long long)tap * a.cin + ci] = acc[i][j][r];
+        else atomicAdd(a.dw + co * wrow + (long long)tap * a.cin + ci, acc[i][j][r]);
       }
+}
+
+// Second pass of the deterministic mode: dw[i] += part[0][i] + part[1][i] + ... in pixel-range order (one thread owns an element:
+// the summation order is fixed, so the result does not depend on scheduling).  HBM-bound: reads `live` slices, updates dw once.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long long n4, int live, long long stride4) {
+  const float4* p4 = reinterpret_cast<const float4*>(part);
+  float4* d4 = reinterpret_cast<float4*>(dw);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 s = p4[i];
+    for (int k = 1; k < live; ++k) {
+      const float4 v = p4[k * stride4 + i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float4 d = d4[i];
+    d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w;
+    d4[i] = d;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -288,7 +311,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 1) void conv_wgrad_kernel(
 //   1: stride 1 (output map = input map): the tap's row is the pixel's row shifted by a constant, i.e. a per-lane constant offset plus a
 //      SCALAR offset per K-step; only the padding test keeps per-lane state (the shifted coordinates, 11 instructions per row)
 //   2: 1x1, stride 1: no padding either -- constant lane offset + scalar offset, as for dY (no VALU work per K-step at all)
-template <bool F16, int XM>
+template <bool F16, int XM, bool DET = false>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs a) {
   constexpr int ES = 2, KP = 64, BCO = 256, BCI = 128;
   constexpr int RBG = BCO * ES, RBX = BCI * ES;             // 512 / 256 bytes per LDS row
@@ -541,7 +564,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
     // Buffer atomics: descriptor + scalar item offset + a 32-bit lane offset.  (No 64-bit VGPR address is live across the K loop: a
     // spilled one used to be reloaded at the top of every item, and the vmcnt(0) of that reload made the wave wait for all of the
     // previous item's atomics before it could start the next item's MFMAs.)
-    const __amdgpu_buffer_rsrc_t rs_dw = __builtin_amdgcn_make_buffer_rsrc((void*)a.dw, 0, (int)((long long)a.cout * wrow * 4), 0x00020000);
+    // deterministic mode: the item's pixel range owns one slice of the workspace; plain stores (each element written by one block)
+    float* const dst_base = DET ? a.part + (long long)(ks0 / per) * a.part_stride : a.dw;
+    const __amdgpu_buffer_rsrc_t rs_dw = __builtin_amdgcn_make_buffer_rsrc((void*)dst_base, 0, (int)((long long)a.cout * wrow * 4), 0x00020000);
     const unsigned row_bytes = (unsigned)wrow * 4u;
     const unsigned item_off = (unsigned)(((long long)(tco * BCO + wr * 128) * wrow + (long long)tap * a.cin + tci * BCI + wc * 64) * 4);
 #pragma unroll
@@ -561,7 +586,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
           // (the item offset is part of the lane offset on purpose: an item-invariant offset would be hoisted out of the item
           // loop, 128 live registers)
           const unsigned voff = item_off + (unsigned)(i * 16 + 4 * jp + r) * row_bytes + (unsigned)lane * 4u;
-          if (PS_ABLATE(a.ablate) == 0) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(o[jp], rs_dw, voff, 0, 0);
+          if constexpr (DET) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[jp]), rs_dw, voff, 0, 0);
+          else if (PS_ABLATE(a.ablate) == 0) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(o[jp], rs_dw, voff, 0, 0);
           else if (PS_ABLATE(a.ablate) == 2) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[jp]), rs_dw, voff, 0, 0);
           else asm volatile("" ::"v"(o[jp]));
         }
@@ -576,8 +602,9 @@ PS_TUNABLE g_wgrad_ws2 = 1;  // large-tile persistent kernel for 16-bit operands
 
 PS_TUNABLE g_wgrad_raster = -1;  // -1: by shape (measured r01: pixel-range-slowest wins for 3x3 layers with >= 64 tiles)
 
+// Geometry-derived fields + split-K choice of conv_wgrad_kernel; returns the number of pixel ranges that get work.
 template <typename Tr, int BCO, int BCI>
-int launch_wgrad(WgradArgs a, hipStream_t s) {
+long long plan_wgrad(WgradArgs& a) {
   a.tiles_co = a.cout / BCO;
   a.tiles_ci = a.cin / BCI;
   a.ksteps = (a.M + Tr::KP - 1) / Tr::KP;
@@ -600,18 +627,26 @@ int launch_wgrad(WgradArgs a, hipStream_t s) {
     if (best < 0 || cost < best) { best = cost; splits = sp; }
   }
   a.splits = (int)splits;
+  const long long per = (a.ksteps + splits - 1) / splits;
+  return (a.ksteps + per - 1) / per;
+}
+
+template <typename Tr, int BCO, int BCI, bool DET = false>
+int launch_wgrad(WgradArgs a, hipStream_t s) {
+  plan_wgrad<Tr, BCO, BCI>(a);
+  const long long tiles = (long long)a.tiles_co * a.tiles_ci * a.taps;
   const size_t lds = 2 * (size_t)Tr::KP * (BCO + BCI) * Tr::ES;
   if (g_wgrad_ws && BCO == 128 && BCI == 128) {
-    hipLaunchKernelGGL((conv_wgrad_kernel<Tr, BCO, BCI, true>), dim3((unsigned)(tiles * splits)), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((conv_wgrad_kernel<Tr, BCO, BCI, true, DET>), dim3((unsigned)(tiles * a.splits)), dim3(512), lds, s, a);
   } else {
-    hipLaunchKernelGGL((conv_wgrad_kernel<Tr, BCO, BCI, false>), dim3((unsigned)(tiles * splits)), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_wgrad_kernel<Tr, BCO, BCI, false, DET>), dim3((unsigned)(tiles * a.splits)), dim3(256), lds, s, a);
   }
   PS_CHECK_LAUNCH("conv_wgrad");
   return PS_OK;
 }
 
-template <typename Tr>
-int launch_wgrad_ws2(WgradArgs a, hipStream_t s) {
+// Geometry-derived fields + pixel-range count of conv_wgrad_ws2_kernel; returns the number of ranges that get work.
+static long long plan_wgrad_ws2(WgradArgs& a) {
   a.tiles_co = a.cout / 256;
   a.tiles_ci = a.cin / 128;
   a.ksteps = (a.M + 63) / 64;
@@ -633,14 +668,20 @@ int launch_wgrad_ws2(WgradArgs a, hipStream_t s) {
     if (best < 0 || cost < best) { best = cost; splits = sp; }
   }
   a.splits = (int)splits;
-  const long long per = (a.ksteps + splits - 1) / splits, live = (a.ksteps + per - 1) / per;
-  const long long items = tiles * live;
   a.nb = ncu;
+  const long long per = (a.ksteps + splits - 1) / splits;
+  return (a.ksteps + per - 1) / per;
+}
+
+template <typename Tr, bool DET = false>
+int launch_wgrad_ws2(WgradArgs a, hipStream_t s) {
+  const long long live = plan_wgrad_ws2(a);
+  const long long items = (long long)a.tiles_co * a.tiles_ci * a.taps * live;
   const unsigned grid = ps_persistent_grid(items, a.nb, a.tpb);
   const size_t lds = 3 * 64 * (256 + 128) * 2;
-  if (a.stride == 1 && a.taps == 1) hipLaunchKernelGGL((conv_wgrad_ws2_kernel<Tr::F16, 2>), dim3(grid), dim3(512), lds, s, a);
-  else if (a.stride == 1) hipLaunchKernelGGL((conv_wgrad_ws2_kernel<Tr::F16, 1>), dim3(grid), dim3(512), lds, s, a);
-  else hipLaunchKernelGGL((conv_wgrad_ws2_kernel<Tr::F16, 0>), dim3(grid), dim3(512), lds, s, a);
+  if (a.stride == 1 && a.taps == 1) hipLaunchKernelGGL((conv_wgrad_ws2_kernel<Tr::F16, 2, DET>), dim3(grid), dim3(512), lds, s, a);
+  else if (a.stride == 1) hipLaunchKernelGGL((conv_wgrad_ws2_kernel<Tr::F16, 1, DET>), dim3(grid), dim3(512), lds, s, a);
+  else hipLaunchKernelGGL((conv_wgrad_ws2_kernel<Tr::F16, 0, DET>), dim3(grid), dim3(512), lds, s, a);
   PS_CHECK_LAUNCH("conv_wgrad_ws2");
   return PS_OK;
 }
@@ -649,14 +690,60 @@ static bool use_wgrad_ws2(int esize, long long M, int cout, int cin, int taps) {
   return g_wgrad_ws2 && esize == 2 && cout % 256 == 0 && cin % 128 == 0 && (g_wgrad_ws2 > 1 || M * cout * cin * taps >= (1LL << 31));
 }
 
-template <typename Tr>
+template <typename Tr, bool DET = false>
 int dispatch_wgrad(const WgradArgs& a, hipStream_t s) {
-  if (use_wgrad_ws2(Tr::ES, a.M, a.cout, a.cin, a.taps)) return launch_wgrad_ws2<Tr>(a, s);
+  if constexpr (Tr::ES == 2) {
+    if (use_wgrad_ws2(Tr::ES, a.M, a.cout, a.cin, a.taps)) return launch_wgrad_ws2<Tr, DET>(a, s);
+  }
   const bool co128 = a.cout % 128 == 0, ci128 = a.cin % 128 == 0;
-  if (co128 && ci128) return launch_wgrad<Tr, 128, 128>(a, s);
-  if (co128) return launch_wgrad<Tr, 128, 64>(a, s);
-  if (ci128) return launch_wgrad<Tr, 64, 128>(a, s);
-  return launch_wgrad<Tr, 64, 64>(a, s);
+  if (co128 && ci128) return launch_wgrad<Tr, 128, 128, DET>(a, s);
+  if (co128) return launch_wgrad<Tr, 128, 64, DET>(a, s);
+  if (ci128) return launch_wgrad<Tr, 64, 128, DET>(a, s);
+  return launch_wgrad<Tr, 64, 64, DET>(a, s);
+}
+
+// Pixel ranges (split-K parts) the dispatcher will cut this problem into: the same plan functions the launchers use.
+template <typename Tr>
+long long wgrad_live_ranges(WgradArgs a) {
+  if (use_wgrad_ws2(Tr::ES, a.M, a.cout, a.cin, a.taps)) return plan_wgrad_ws2(a);
+  const bool co128 = a.cout % 128 == 0, ci128 = a.cin % 128 == 0;
+  if (co128 && ci128) return plan_wgrad<Tr, 128, 128>(a);
+  if (co128) return plan_wgrad<Tr, 128, 64>(a);
+  if (ci128) return plan_wgrad<Tr, 64, 128>(a);
+  return plan_wgrad<Tr, 64, 64>(a);
+}
+
+int fill_wgrad_args(const ps_conv_geom* g, const void* x, const void* dy, float* dw, WgradArgs& a, const char* who) {
+  PS_REQUIRE(g != nullptr, "%s: null geometry", who);
+  PS_REQUIRE(ps_conv_supported(g), "%s: unsupported geometry (%s)", who, ps_last_error());
+  const int es = ps_esize(g->dtype);
+  a.x = static_cast<const unsigned char*>(x);
+  a.dy = static_cast<const unsigned char*>(dy);
+  a.dw = dw;
+  a.H = g->h; a.W = g->w;
+  a.Ho = (g->h - 1) / g->stride + 1; a.Wo = (g->w - 1) / g->stride + 1;
+  a.M = g->n * a.Ho * a.Wo;
+  a.stride = g->stride; a.dil = g->dilation;
+  a.taps = g->ksize * g->ksize; a.ctr = g->ksize / 2;
+  a.cin = g->cin; a.cout = g->cout;
+  a.tpb = g->tiles_per_block;
+  a.x_pix_bytes = (long long)g->ldc_x * es;
+  a.dy_pix_bytes = (long long)g->ldc_y * es;
+  a.div_hw = make_fastdiv((uint32_t)(a.Ho * a.Wo));
+  a.div_w = make_fastdiv((uint32_t)a.Wo);
+  const long long xb = (long long)g->n * g->h * g->w * a.x_pix_bytes, gb = (long long)a.M * a.dy_pix_bytes;
+  PS_REQUIRE(xb < (1LL << 31) && gb < (1LL << 31), "%s: tensor larger than 2 GiB", who);
+  a.x_bytes = (unsigned)xb;
+  a.dy_bytes = (unsigned)gb;
+  a.part = nullptr;
+  a.part_stride = (long long)a.cout * a.taps * a.cin;
+  return PS_OK;
+}
+
+long long live_ranges_of(const ps_conv_geom* g, const WgradArgs& a) {
+  if (g->dtype == PS_BF16) return wgrad_live_ranges<WTraitsBF16>(a);
+  if (g->dtype == PS_F16) return wgrad_live_ranges<WTraitsF16>(a);
+  return wgrad_live_ranges<WTraitsF32>(a);
 }
 
 }  // namespace
@@ -677,30 +764,50 @@ extern "C" int ps_conv_wgrad_variant(const ps_conv_geom* g) {
 
 extern "C" int ps_conv2d_wgrad(const ps_conv_geom* g, const void* x, const void* dy, float* dw, void* stream) {
   PS_REQUIRE(g && x && dy && dw, "conv2d_wgrad: null argument");
-  PS_REQUIRE(ps_conv_supported(g), "conv2d_wgrad: unsupported geometry (%s)", ps_last_error());
   PS_REQUIRE(ps_aligned16(x) && ps_aligned16(dy) && ps_aligned16(dw), "conv2d_wgrad: misaligned pointer");
-  const int es = ps_esize(g->dtype);
   WgradArgs a{};
-  a.x = static_cast<const unsigned char*>(x);
-  a.dy = static_cast<const unsigned char*>(dy);
-  a.dw = dw;
-  a.H = g->h; a.W = g->w;
-  a.Ho = (g->h - 1) / g->stride + 1; a.Wo = (g->w - 1) / g->stride + 1;
-  a.M = g->n * a.Ho * a.Wo;
-  a.stride = g->stride; a.dil = g->dilation;
-  a.taps = g->ksize * g->ksize; a.ctr = g->ksize / 2;
-  a.cin = g->cin; a.cout = g->cout;
-  a.tpb = g->tiles_per_block;
-  a.x_pix_bytes = (long long)g->ldc_x * es;
-  a.dy_pix_bytes = (long long)g->ldc_y * es;
-  a.div_hw = make_fastdiv((uint32_t)(a.Ho * a.Wo));
-  a.div_w = make_fastdiv((uint32_t)a.Wo);
-  const long long xb = (long long)g->n * g->h * g->w * a.x_pix_bytes, gb = (long long)a.M * a.dy_pix_bytes;
-  PS_REQUIRE(xb < (1LL << 31) && gb < (1LL << 31), "conv2d_wgrad: tensor larger than 2 GiB");
-  a.x_bytes = (unsigned)xb;
-  a.dy_bytes = (unsigned)gb;
+  if (int rc = fill_wgrad_args(g, x, dy, dw, a, "conv2d_wgrad")) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (g->dtype == PS_BF16) return dispatch_wgrad<WTraitsBF16>(a, s);
   if (g->dtype == PS_F16) return dispatch_wgrad<WTraitsF16>(a, s);
   return dispatch_wgrad<WTraitsF32>(a, s);
+}
+
+extern "C" int64_t ps_conv2d_wgrad_det_workspace_bytes(const ps_conv_geom* g) {
+  WgradArgs a{};
+  if (fill_wgrad_args(g, nullptr, nullptr, nullptr, a, "conv2d_wgrad_det_workspace_bytes") != PS_OK) return -1;
+  const long long live = live_ranges_of(g, a);
+  return live <= 1 ? 0 : (int64_t)(live * a.part_stride * 4);
+}
+
+extern "C" int ps_conv2d_wgrad_det(const ps_conv_geom* g, const void* x, const void* dy, float* dw, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+  PS_REQUIRE(g && x && dy && dw, "conv2d_wgrad_det: null argument");
+  PS_REQUIRE(ps_aligned16(x) && ps_aligned16(dy) && ps_aligned16(dw), "conv2d_wgrad_det: misaligned pointer");
+  WgradArgs a{};
+  if (int rc = fill_wgrad_args(g, x, dy, dw, a, "conv2d_wgrad_det")) return rc;
+  const long long live = live_ranges_of(g, a);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (live <= 1) {
+    // one pixel range: every element of dw receives exactly ONE addition, which is the same in every run -- the atomic kernels as they are
+    if (g->dtype == PS_BF16) return dispatch_wgrad<WTraitsBF16>(a, s);
+    if (g->dtype == PS_F16) return dispatch_wgrad<WTraitsF16>(a, s);
+    return dispatch_wgrad<WTraitsF32>(a, s);
+  }
+  const long long need = live * a.part_stride * 4;
+  PS_REQUIRE(workspace && ps_aligned16(workspace) && workspace_bytes >= need,
+             "conv2d_wgrad_det: workspace of %lld bytes needed (ps_conv2d_wgrad_det_workspace_bytes), got %lld at %p", need,
+             (long long)workspace_bytes, workspace);
+  PS_REQUIRE(a.part_stride * 4 < (1LL << 31), "conv2d_wgrad_det: weight tensor larger than 2 GiB");
+  a.part = static_cast<float*>(workspace);
+  int rc;
+  if (g->dtype == PS_BF16) rc = dispatch_wgrad<WTraitsBF16, true>(a, s);
+  else if (g->dtype == PS_F16) rc = dispatch_wgrad<WTraitsF16, true>(a, s);
+  else rc = dispatch_wgrad<WTraitsF32, true>(a, s);
+  if (rc != PS_OK) return rc;
+  const long long n4 = a.part_stride / 4;  // cin is a multiple of 32: whole float4s
+  const unsigned blocks = (unsigned)std::min<long long>((n4 + 255) / 256, 8LL * ps_num_cus());
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.part, dw, n4, (int)live, n4);
+  PS_CHECK_LAUNCH("wgrad_reduce");
+  return PS_OK;
 }

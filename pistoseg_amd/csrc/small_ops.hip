@@ -394,22 +394,35 @@ __global__ __launch_bounds__(256) void fc8_bwd_kernel(const T* __restrict__ x, i
   }
 }
 
-// dw[j] += sum over the pixel blocks b of partial[b][j], j < C*K: a thread sums four consecutive j over a slice of the blocks
-// (blockIdx.y), the slices meet in dw with one atomic each.
+// dw[j] += sum over the pixel blocks b of partial[b][j], j < C*K, in a FIXED order (deterministic: no atomics).  A block of 256 threads
+// owns 16 groups of four consecutive j; thread (slice, jq) sums slice `slice` of the pixel blocks for group jq in block order, the 16
+// slice sums of a group meet in LDS and one thread adds them up in slice order and updates dw (the only writer of those four elements).
 __global__ __launch_bounds__(256) void fc8_dw_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int ck, int nblocks,
                                                             int per_slice) {
-  const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (j >= ck) return;
-  const int b0 = blockIdx.y * per_slice, b1 = min(nblocks, b0 + per_slice);
+  __shared__ float4 part[16][16];
+  const int jq = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int j = (blockIdx.x * 16 + jq) * 4;
+  const int b0 = slice * per_slice, b1 = min(nblocks, b0 + per_slice);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int b = b0; b < b1; ++b) {
-    const float4 v = *reinterpret_cast<const float4*>(partial + (long long)b * ck + j);
-    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  if (j < ck) {
+    for (int b = b0; b < b1; ++b) {
+      const float4 v = *reinterpret_cast<const float4*>(partial + (long long)b * ck + j);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
   }
-  atomicAdd(dw + j, acc.x);
-  atomicAdd(dw + j + 1, acc.y);
-  atomicAdd(dw + j + 2, acc.z);
-  atomicAdd(dw + j + 3, acc.w);
+  part[slice][jq] = acc;
+  __syncthreads();
+  if (slice == 0 && j < ck) {
+    float4 t = part[0][jq];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+      const float4 v = part[k][jq];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    float4 d = *reinterpret_cast<float4*>(dw + j);
+    d.x += t.x; d.y += t.y; d.z += t.z; d.w += t.w;
+    *reinterpret_cast<float4*>(dw + j) = d;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -778,8 +791,8 @@ extern "C" int ps_fc8_bwd_ws(int32_t dtype, const void* x, int32_t ldc_x, const 
   PS_CHECK_LAUNCH("fc8_bwd");
   if (workspace) {
     const int ck = c * k;
-    const int slices = mblocks < 16 ? 1 : 16, per_slice = (mblocks + slices - 1) / slices;
-    hipLaunchKernelGGL(fc8_dw_reduce_kernel, dim3((ck / 4 + 255) / 256, slices), dim3(256), 0, s, workspace, dw, ck, mblocks, per_slice);
+    const int per_slice = (mblocks + 15) / 16;  // 16 slices of the pixel blocks per group of four outputs, combined in slice order
+    hipLaunchKernelGGL(fc8_dw_reduce_kernel, dim3((ck / 4 + 15) / 16), dim3(256), 0, s, workspace, dw, ck, mblocks, per_slice);
     PS_CHECK_LAUNCH("fc8_dw_reduce");
   }
   return PS_OK;

@@ -155,8 +155,35 @@ def conv2d_dgrad(spec: ConvSpec, dy: Tensor, w_dgrad: Tensor, x_hw, *, add0=None
             lambda: _lib.check(lib.ps_conv2d_dgrad(C.byref(g), dy.data_ptr(), w_dgrad.data_ptr(), C.byref(e), _stream()), "ps_conv2d_dgrad"))
 
 
-def conv2d_wgrad(spec: ConvSpec, x: Tensor, dy: Tensor, dw: Tensor) -> None:
-    """dw[cout][kh][kw][cin] (f32, channels-last OIHW storage) += sum_pixels dy * x@tap."""
+# Deterministic weight gradients (ps_conv2d_wgrad_det): partial sums of the pixel ranges go to a workspace and are added up in range
+# order instead of by f32 atomics -- the reference's `torch.use_deterministic_algorithms(True)` / `Trainer(deterministic=True)`
+# (revise_pseudo_labels.py:140-146, segmentation_train.py:153-160).  None = follow torch's own switch, i.e. exactly what those two
+# reference call sites set (`torch.are_deterministic_algorithms_enabled()`); True / False force it (the native trainers'
+# `deterministic=` argument).  Read when a launch is enqueued.  The workspace is one grow-only buffer per (device, stream): launches
+# on one stream run in order and may share it.
+DETERMINISTIC: Optional[bool] = None
+_WGRAD_WS: dict = {}
+
+
+def deterministic_enabled(override: Optional[bool] = None) -> bool:
+    if override is not None:
+        return override
+    return torch.are_deterministic_algorithms_enabled() if DETERMINISTIC is None else DETERMINISTIC
+
+
+def _wgrad_workspace(nbytes: int, device) -> Tensor:
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WGRAD_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        with torch.cuda.stream(torch.cuda.current_stream(device)):
+            ws = torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)
+        _WGRAD_WS[key] = ws
+    return ws
+
+
+def conv2d_wgrad(spec: ConvSpec, x: Tensor, dy: Tensor, dw: Tensor, deterministic: Optional[bool] = None) -> None:
+    """dw[cout][kh][kw][cin] (f32, channels-last OIHW storage) += sum_pixels dy * x@tap.  deterministic (default: the module switch
+    DETERMINISTIC): no atomics, bit-identical from run to run."""
     _require_gpu(x, dy, dw)
     n, h, w, c = x.shape
     assert c == spec.cin and dy.shape[3] == spec.cout and dw.dtype == torch.float32 and x.dtype == dy.dtype
@@ -164,7 +191,17 @@ def conv2d_wgrad(spec: ConvSpec, x: Tensor, dy: Tensor, dw: Tensor) -> None:
     g = _geom(spec, _dt(x), n, h, w, _ldc(x), _ldc(dy))
     lib = _lib.load()
     mo = n * dy.shape[1] * dy.shape[2]
-    _launch(_conv_label("wgrad", g) if PROFILE is not None else "", 2.0 * mo * spec.cout * spec.cin * spec.ksize**2,
+    flops = 2.0 * mo * spec.cout * spec.cin * spec.ksize**2
+    if deterministic_enabled(deterministic):
+        need = int(lib.ps_conv2d_wgrad_det_workspace_bytes(C.byref(g)))
+        if need < 0:
+            _lib.check(-1, "ps_conv2d_wgrad_det_workspace_bytes")
+        ws = _wgrad_workspace(need, x.device) if need > 0 else None
+        _launch(_conv_label("wgrad", g) if PROFILE is not None else "", flops,
+                lambda: _lib.check(lib.ps_conv2d_wgrad_det(C.byref(g), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(ws), need, _stream()),
+                                   "ps_conv2d_wgrad_det"))
+        return
+    _launch(_conv_label("wgrad", g) if PROFILE is not None else "", flops,
             lambda: _lib.check(lib.ps_conv2d_wgrad(C.byref(g), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _stream()), "ps_conv2d_wgrad"))
 
 

@@ -91,9 +91,12 @@ class _ArenaMixin:
 class SegTrainer(_ArenaMixin):
     def __init__(self, model: ResNet38dSeg, lr: float = 1e-3, weight_decay: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8,
                  ignore_index: Optional[int] = 3, process_group=None, bucket_mb: float = 48.0, track_iou: bool = True,
-                 loss_scale: Optional[float] = None, overlap_wgrad: bool = True):
+                 loss_scale: Optional[float] = None, overlap_wgrad: bool = True, deterministic: Optional[bool] = None):
         assert next(model.parameters()).is_cuda, "move the model to the GPU first"
         self.model = model
+        # `pl.Trainer(deterministic=True)` (segmentation_train.py:153-160): weight gradients without atomics (ps_conv2d_wgrad_det), so two
+        # identical runs are bit-identical.  None = follow torch.are_deterministic_algorithms_enabled(), the switch that call site sets.
+        self.deterministic = deterministic
         # weight gradients on a second stream (see Net.backward_backbone)
         self.wgrad_stream = torch.cuda.Stream(device=next(model.parameters()).device) if overlap_wgrad else None
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
@@ -158,8 +161,12 @@ class SegTrainer(_ArenaMixin):
         if self.reducer is not None:
             self.reducer.begin_step()
             self.reducer.on_unit_done("fc8")
-        model.backward_backbone(saved, g_x7, self.grads, after_unit=self.reducer.on_unit_done if self.reducer is not None else None,
-                                wgrad_stream=self.wgrad_stream)
+        prev, ops.DETERMINISTIC = ops.DETERMINISTIC, (self.deterministic if self.deterministic is not None else ops.DETERMINISTIC)
+        try:
+            model.backward_backbone(saved, g_x7, self.grads, after_unit=self.reducer.on_unit_done if self.reducer is not None else None,
+                                    wgrad_stream=self.wgrad_stream)
+        finally:
+            ops.DETERMINISTIC = prev
         if self.reducer is not None:
             self.reducer.finish()
         if self.dynamic_scale:
@@ -191,11 +198,12 @@ class RFMTrainer(_ArenaMixin):
     """
 
     def __init__(self, model, lr: float = 0.01, wt_dec: float = 5e-4, max_step: int = 1000, power: float = 0.9, process_group=None,
-                 bucket_mb: float = 48.0, loss_scale: Optional[float] = None, overlap_wgrad: bool = True):
+                 bucket_mb: float = 48.0, loss_scale: Optional[float] = None, overlap_wgrad: bool = True, deterministic: Optional[bool] = None):
         from .revise_net import FCAT, Net
 
         assert isinstance(model, Net) and next(model.parameters()).is_cuda
         self.model, self.FCAT = model, FCAT
+        self.deterministic = deterministic  # torch.use_deterministic_algorithms(True) of revise_pseudo_labels.py:140-146; None = follow that switch
         self.wgrad_stream = torch.cuda.Stream(device=next(model.parameters()).device) if overlap_wgrad else None  # see backward_backbone
         self.lr0, self.wt_dec, self.max_step, self.power = lr, wt_dec, max_step, power
         self.global_step = 0
@@ -265,7 +273,11 @@ class RFMTrainer(_ArenaMixin):
             elif self.reducer is not None:
                 self.reducer.on_unit_done(name)
 
-        model.rfm_backward(ctx, list(d_outs), self.grads, after_unit=after, wgrad_stream=self.wgrad_stream)
+        prev, ops.DETERMINISTIC = ops.DETERMINISTIC, (self.deterministic if self.deterministic is not None else ops.DETERMINISTIC)
+        try:
+            model.rfm_backward(ctx, list(d_outs), self.grads, after_unit=after, wgrad_stream=self.wgrad_stream)
+        finally:
+            ops.DETERMINISTIC = prev
         if self.reducer is not None:
             self.reducer.finish()
         if self.dynamic_scale:

@@ -345,6 +345,38 @@ def test_seg_trainer_side_stream_weight_gradients_match_single_stream():
     assert flips <= 1e-4 * d.numel(), flips
 
 
+@pytest.mark.selfcheck
+@pytest.mark.parametrize("precision,n,s", [("fp32", 4, 64), ("bf16", 4, 64), ("bf16", 24, 224)])
+def test_seg_trainer_deterministic_runs_are_bit_identical(precision, n, s):
+    """`pl.Trainer(deterministic=True)` (segmentation_train.py:153-160): with `SegTrainer(deterministic=True)` two identical runs of three
+    optimisation steps end with BIT-IDENTICAL losses and f32 master weights -- weight gradients through ps_conv2d_wgrad_det, fc8's dW
+    through its ordered workspace reduction, everything else on the path has no atomics -- also with the weight gradients on the second
+    stream; and the deterministic gradient equals the atomic one up to f32 summation order.  (n = 24 at 224 x 224: the persistent kernels.)"""
+    from pistoseg_amd.seg_model import ResNet38dSeg
+    from pistoseg_amd.trainer import SegTrainer, init_weights_he
+
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(n, 3, s, s, generator=g).to(D)
+    y = torch.randint(0, 4, (n, s, s), generator=g).to(D)
+    runs = []
+    for det in (True, True, False):
+        torch.manual_seed(0)  # the Dropout2d masks are keyed by torch's seed
+        model = ResNet38dSeg(3, precision)
+        init_weights_he(model, 42)
+        model = model.to(D)
+        tr = SegTrainer(model, lr=1e-3, weight_decay=0.05, ignore_index=3, track_iou=False, deterministic=det)
+        losses = [float(tr.train_step(x, y)) for _ in range(3)]
+        torch.cuda.synchronize()
+        runs.append((losses, tr.p_flat.clone(), tr.g_flat.clone()))
+    (l0, p0, g0), (l1, p1, g1), (l2, p2, g2) = runs
+    assert l0 == l1 and torch.equal(p0, p1) and torch.equal(g0, g1)
+    assert l0[0] == l2[0]  # the forward is the same code either way
+    # (the last step's gradients of the atomic run belong to slightly different weights by then: compare loosely, and the first loss exactly)
+    e = float((g0.double() - g2.double()).norm() / g2.double().norm())
+    print(f"[selfcheck] deterministic vs atomic weight gradients after 3 steps ({precision}, n={n}, {s}x{s}): L2 rel diff {e:.2e}")
+    assert e < 5e-2
+
+
 def test_bench_batch_bf16_logits_vs_oracle():
     """BASELINE configs[1] says "logits checked vs CPU": the exact batch `bench.py` trains on (bs=64, 224x224, seed 1234, He-init weights
     seed 42, bf16 storage / f32 accumulate) goes through the model in one launch sequence; tiles 0 and 37 are compared with the CPU

@@ -623,6 +623,57 @@ def test_wgrad_large_tile_persistent_kernel(case, dtype, library):
         assert rel_err(dw.cpu(), got[0].cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [
+    # (n, h, w, cin, cout, k, s, d)
+    (2, 13, 10, 128, 256, 3, 2, 1), (3, 9, 11, 256, 512, 1, 2, 1), (2, 13, 10, 512, 64, 1, 1, 1), (6, 28, 28, 256, 192, 1, 1, 1),  # 128x128 .. 64x64 tiles, split over pixel ranges
+    (16, 28, 28, 512, 512, 3, 1, 1), (8, 28, 28, 2048, 4096, 1, 1, 1), (21, 56, 56, 256, 512, 3, 2, 1),  # 16-bit: the persistent 256x128 kernel by geometry
+])
+def test_wgrad_deterministic_mode(case, dtype, library):
+    """ps_conv2d_wgrad_det (pixel ranges store partial sums into a workspace, a second kernel adds them in range order): ACCUMULATES
+    into dw like the atomic entry point, matches CPU autograd, and is BIT-IDENTICAL from launch to launch -- the reference's
+    torch.use_deterministic_algorithms(True) / Trainer(deterministic=True) (revise_pseudo_labels.py:140-146, segmentation_train.py:153-160)."""
+    import ctypes as C
+
+    from pistoseg_amd import _lib, ops
+
+    lib = _lib.load()
+    n, h, w, cin, cout, k, s_, d = case
+    spec = ops.ConvSpec(cin, cout, k, s_, d)
+    g = torch.Generator().manual_seed(cin + cout + k + n)
+    q = quant(dtype)
+    x = q(torch.randn(n, cin, h, w, generator=g))
+    wt = (torch.randn(cout, cin, k, k, generator=g) * 0.05).requires_grad_(True)
+    y = F.conv2d(x, wt, stride=s_, padding=d if k == 3 else 0, dilation=d)
+    gy = q(torch.randn(y.shape, generator=g))
+    y.backward(gy)
+    D = dev()
+    xd, gyd = nhwc(x).to(D, dtype), nhwc(gy).to(D, dtype)
+    init = torch.randn(cout, k, k, cin, generator=g)
+    geom = ops._geom(spec, ops._dt(dtype), n, h, w, cin, cout)
+    need = int(lib.ps_conv2d_wgrad_det_workspace_bytes(C.byref(geom)))
+    assert need >= 0 and need % (cout * k * k * cin * 4) == 0
+    outs = []
+    for rep in range(3):
+        dw = init.clone().to(D)
+        if rep == 2:  # garbage in the workspace must not matter
+            ops._wgrad_workspace(max(need, 16), D).fill_(0x7F)
+        ops.conv2d_wgrad(spec, xd, gyd, dw, deterministic=True)
+        outs.append(dw)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    ref = w_fwd_layout(wt.grad)
+    tol = F32_TOL if dtype == torch.float32 else 1e-4  # 16-bit: exact products of identically rounded operands, f32 accumulation
+    assert rel_err((outs[0].cpu() - init), ref) < tol
+    atomic = init.clone().to(D)
+    ops.conv2d_wgrad(spec, xd, gyd, atomic, deterministic=False)
+    assert rel_err(outs[0].cpu() - init, atomic.cpu() - init) < 1e-5
+    if need > 0:  # a split problem without (enough) workspace is refused, not silently run on atomics
+        dw = init.clone().to(D)
+        rc = lib.ps_conv2d_wgrad_det(C.byref(geom), xd.data_ptr(), gyd.data_ptr(), dw.data_ptr(), None, 0, torch.cuda.current_stream().cuda_stream)
+        assert rc != 0 and b"workspace" in lib.ps_last_error()
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case,family", [
     # (n, h, w, cin, cout, k, s, d): the smallest batches at which the GEOMETRY selects each persistent kernel (>= 256 tiles), ragged:

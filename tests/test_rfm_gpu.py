@@ -377,6 +377,32 @@ def test_rfm_trainer_step_at_baseline_config3_shape_vs_oracle():
         torch.cuda.empty_cache()
 
 
+@pytest.mark.selfcheck
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_rfm_trainer_deterministic_runs_are_bit_identical(precision):
+    """torch.use_deterministic_algorithms(True) of stage 3 (revise_pseudo_labels.py:140-146): `RFMTrainer(deterministic=True)` twice on the
+    same batch, three steps: bit-identical losses and master weights."""
+    from pistoseg_amd.revise_net import Net
+    from pistoseg_amd.trainer import RFMTrainer
+
+    n, s, c = 4, 96, 4
+    sd = ref_cpu.make_state_dict(c, True, seed=42)
+    x, pmask, pcam, lab = make_inputs(n, s, c, seed=190)
+    pm, pc, label = with_bg(pmask, pcam, lab)
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(0)
+        model = Net(c, precision)
+        model.load_state_dict(sd)
+        model = model.to(D)
+        tr = RFMTrainer(model, lr=0.01, wt_dec=5e-4, max_step=10, deterministic=True)
+        losses = [[float(v) for v in tr.train_step(x.to(D), pm.to(D), pc.to(D), label.reshape(n, c).to(D))] for _ in range(3)]
+        torch.cuda.synchronize()
+        runs.append((losses, tr.p_flat.clone()))
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][1], runs[1][1])
+
+
 @pytest.mark.parametrize("largest", [True, False])
 @pytest.mark.parametrize("shape", [(5, 50176), (3, 200704), (2, 777), (1, 64)])
 def test_topk_select_multi_block_matches_torch_topk(shape, largest):
