@@ -72,8 +72,8 @@ def parse():
 
 
 def spawn_ranks(args) -> int:
-    """--gpus N > 1 without a launcher: start N ranks of this script under torch.distributed.run as a child process.  Nothing in this
-    process has touched the GPU yet (device_count() does not initialise HIP) and it never exec()s -- it waits and relays."""
+    """--gpus N > 1 without a launcher: start N ranks of this script under torch.distributed.run as a CHILD process; this process only
+    counts devices, waits and relays the child's exit code -- it never exec()s, so it does not matter whether device_count() touched HIP."""
     import socket
     import subprocess
 

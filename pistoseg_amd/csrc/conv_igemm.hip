@@ -1616,6 +1616,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
 #endif
 }
 
+#ifdef PS_DEBUG_HOOKS
+constexpr bool kDebugBuild = true;
+#else
+constexpr bool kDebugBuild = false;
+#endif
 PS_TUNABLE g_use_glds = 2;  // staging mode: 0 registers, 1 global_load_lds, 2 buffer_load ... lds
 PS_TUNABLE g_use_pp = 0;       // experimental ping-pong kernel (correct, slower: r01 measurements)
 PS_TUNABLE g_use_ws = 1;       // wave-specialised (loader/consumer) kernel for big problems
@@ -1637,12 +1642,17 @@ int launch_igemm(const IgemmArgs& a0, hipStream_t stream) {
   const int grid = a.ntm * a.ntn;
   const size_t lds = 2 * (BM * 128 + BN * 128);
   const dim3 block(64 * WMW * WNW);
-  if (g_use_glds == 2) {
-    hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WMW, WNW, 2>), dim3(grid), block, lds, stream, a);
-  } else if (g_use_glds == 1) {
+  // (the alternative staging modes, like every kernel variant below that only a `ps_debug_set_*` switch can select, are instantiated in
+  // the debug library only: the product library carries no code it cannot reach)
+#ifdef PS_DEBUG_HOOKS
+  if (g_use_glds == 1) {
     hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WMW, WNW, 1>), dim3(grid), block, lds, stream, a);
-  } else {
+  } else if (g_use_glds == 0) {
     hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WMW, WNW, 0>), dim3(grid), block, lds, stream, a);
+  } else
+#endif
+  {
+    hipLaunchKernelGGL((conv_igemm_kernel<Tr, BM, BN, WMW, WNW, 2>), dim3(grid), block, lds, stream, a);
   }
   PS_CHECK_LAUNCH("conv_igemm");
   return PS_OK;
@@ -1740,6 +1750,7 @@ static int pick_ws_variant(long long M, int Cd, int esize, bool halo_ok) {
 
 template <typename Tr>
 int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
+#ifdef PS_DEBUG_HOOKS  // experimental kernels (measured slower, kept for the variant sweeps of the parity suite)
   // big problems: 256 x 128 tile, 3-stage LDS-DMA ring (1 block of 8 waves per CU)
   if (g_use_3stage && g_use_glds == 2 && a.Cd % 128 == 0 && (long long)((a.M + 255) / 256) * (a.Cd / 128) >= 256) {
     IgemmArgs b = a;
@@ -1768,11 +1779,15 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
       return PS_OK;
     }
   }
+#endif
   const int adil = a.dstep < 0 ? -a.dstep : a.dstep;
   const bool halo_ok = a.taps == 9 && a.mul == 1 && a.div_shift == 0 && a.Hs == a.Ho && a.Ws == a.Wo && halo_tile_width(a.Ws) != 0 && adil <= 4;
   if (const int v = pick_ws_variant(a.M, a.Cd, (int)sizeof(typename Tr::elem), halo_ok)) {
     IgemmArgs b = a;
     b.ntn = a.Cd / 128;
+    // (f32 problems reach the halo / large-tile kernels only through the debug switches: pick_ws_variant)
+    constexpr bool kLargeTiles = kDebugBuild || sizeof(typename Tr::elem) == 2;
+    if constexpr (kLargeTiles) {
     if (v == PS_CONV_HALO) {
       const int tw = halo_tile_width(a.Ws);
       b.ntm = (a.M / a.Ws + 7) / 8 * (a.Ws / tw);  // blocks of 8 global rows x column blocks of tw
@@ -1789,12 +1804,18 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
       b.ntm -= tail_ptiles;
       const dim3 hgrid(ps_persistent_grid((long long)b.ntm * b.ntn, b.nb, b.tpb));
       if (tw == 28) {
+#ifdef PS_DEBUG_HOOKS
         if (g_halo_ring == 5) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 5>), hgrid, dim3(512), 2 * 9 * 4096 + 5 * 16384, s, b);
         else if (g_halo_ring == 4) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 4>), hgrid, dim3(512), 2 * 9 * 4096 + 4 * 16384, s, b);
-        else hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 3>), hgrid, dim3(512), 2 * 9 * 4096 + 3 * 16384, s, b);
+        else
+#endif
+        hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 3>), hgrid, dim3(512), 2 * 9 * 4096 + 3 * 16384, s, b);
       } else {
+#ifdef PS_DEBUG_HOOKS
         if (g_halo_ring >= 4) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32, 4>), hgrid, dim3(512), 2 * 10 * 4096 + 4 * 16384, s, b);
-        else hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32, 3>), hgrid, dim3(512), 2 * 10 * 4096 + 3 * 16384, s, b);
+        else
+#endif
+        hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32, 3>), hgrid, dim3(512), 2 * 10 * 4096 + 3 * 16384, s, b);
       }
       PS_CHECK_LAUNCH("conv_igemm_halo");
       if constexpr (sizeof(typename Tr::elem) == 2) {
@@ -1811,15 +1832,26 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
       }
       return PS_OK;
     }
+    }
     const int bm = v == PS_CONV_WS2_256 ? 256 : v == PS_CONV_WS2_224 ? 224 : v == PS_CONV_WS_128 ? 128 : 112;
     b.ntm = (a.M + bm - 1) / bm;
     const dim3 grid((unsigned)(b.ntm * b.ntn));
     b.nb = ps_num_cus();
     b.tpb = a.tpb;
     const dim3 pgrid(ps_persistent_grid((long long)b.ntm * b.ntn, b.nb, b.tpb));  // persistent: one block per CU (per batch)
-    if (v == PS_CONV_WS2_256) hipLaunchKernelGGL((conv_igemm_ws2_kernel<Tr, 256>), pgrid, dim3(512), 3 * (256 * 128 + 128 * 128), s, b);
-    else if (v == PS_CONV_WS2_224) hipLaunchKernelGGL((conv_igemm_ws2_kernel<Tr, 224>), pgrid, dim3(512), 3 * (224 * 128 + 128 * 128), s, b);
-    else if (v == PS_CONV_WS_112) hipLaunchKernelGGL((conv_igemm_ws_kernel<Tr, 112>), grid, dim3(512), 2 * (112 * 128 + 128 * 128) + 1024, s, b);
+    if constexpr (kLargeTiles) {
+      if (v == PS_CONV_WS2_256) {
+        hipLaunchKernelGGL((conv_igemm_ws2_kernel<Tr, 256>), pgrid, dim3(512), 3 * (256 * 128 + 128 * 128), s, b);
+        PS_CHECK_LAUNCH("conv_igemm_ws2");
+        return PS_OK;
+      }
+      if (v == PS_CONV_WS2_224) {
+        hipLaunchKernelGGL((conv_igemm_ws2_kernel<Tr, 224>), pgrid, dim3(512), 3 * (224 * 128 + 128 * 128), s, b);
+        PS_CHECK_LAUNCH("conv_igemm_ws2");
+        return PS_OK;
+      }
+    }
+    if (v == PS_CONV_WS_112) hipLaunchKernelGGL((conv_igemm_ws_kernel<Tr, 112>), grid, dim3(512), 2 * (112 * 128 + 128 * 128) + 1024, s, b);
     else hipLaunchKernelGGL((conv_igemm_ws_kernel<Tr, 128>), grid, dim3(512), 2 * (128 * 128 + 128 * 128) + 1024, s, b);
     PS_CHECK_LAUNCH("conv_igemm_ws");
     return PS_OK;
@@ -1832,8 +1864,10 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
     const long long c128 = ((t128 * n128 + 255) / 256) * 128, c112 = ((t112 * n128 + 255) / 256) * 112;
     const bool big = t128 * n128 >= 512 || g_force_bn == 128;
     if (big && (g_force_bm == 112 || (g_force_bm == 0 && c112 * 100 < c128 * 90))) return launch_igemm<Tr, 112, 128, 1, 4>(a, s);
+#ifdef PS_DEBUG_HOOKS
     if (big && g_force_bm == 1288) return launch_igemm<Tr, 128, 128, 2, 4>(a, s);  // experiment: 8 waves of 64x32
     if (big && g_force_bm == 1289) return launch_igemm<Tr, 128, 128, 4, 2>(a, s);  // experiment: 8 waves of 32x64
+#endif
     if (big) return launch_igemm<Tr, 128, 128, 2, 2>(a, s);
   }
   return launch_igemm<Tr, 128, 64, 4, 1>(a, s);

@@ -601,7 +601,7 @@ extern "C" int ps_argmax_mask(const float* x, const float* label, const uint8_t*
   PS_REQUIRE(n > 0 && c > 0 && c < 255 && h > 0 && w > 0 && first_ch >= 0 && first_ch < c, "argmax_mask: bad shape");
   const long long hw = (long long)h * w;
   const int fast = (long long)n * hw < (1LL << 31) ? 1 : 0;
-  const FastDiv div_hw = make_fastdiv((uint32_t)hw);
+  const FastDiv div_hw = make_fastdiv((uint32_t)std::min<long long>(hw, 0x7fffffff));  // only used when `fast` (then hw < 2^31), as in ps_softmax_ce
   auto launch = [&](auto kernel) {
     hipLaunchKernelGGL(kernel, dim3(grid_for((long long)n * hw, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, label, tissue, mask_out,
                        entropy_out, mode, softmax_first, mode == PS_MASK_FILL ? 0 : first_ch, n, c, hw, fast, div_hw);

@@ -22,7 +22,7 @@ int ps_num_cus(void);  // compute units of the current device (api.cpp)
 #ifdef PS_DEBUG_HOOKS
 #define PS_TUNABLE static int
 #else
-#define PS_TUNABLE static constexpr int
+#define PS_TUNABLE [[maybe_unused]] static constexpr int
 #endif
 // grid of a persistent kernel over nitems work items (see ps_block_items)
 static inline unsigned ps_persistent_grid(long long nitems, int nb, int tpb) {
@@ -147,9 +147,10 @@ struct FastDiv {
 };
 static inline FastDiv make_fastdiv(uint32_t d) {
   FastDiv f;
+  if (d > 0x80000000u) d = 0x80000000u;  // callers divide 31-bit quantities only; keeps the shift below defined for any argument
   f.d = d;
   uint32_t l = 0;
-  while ((1u << l) < d) ++l;
+  while (l < 31 && (1u << l) < d) ++l;
   f.shift = 31 + l;
   f.magic = static_cast<uint32_t>(((1ull << f.shift) + d - 1) / d);
   return f;

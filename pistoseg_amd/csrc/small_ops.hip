@@ -3,7 +3,10 @@
 #include <math.h>
 
 #include <algorithm>
+#include <mutex>
 #include <type_traits>
+#include <utility>
+#include <vector>
 
 #include "ps_internal.h"
 
@@ -286,10 +289,19 @@ __global__ __launch_bounds__(256) void fc8_fwd_kernel(const T* __restrict__ x, i
 // Resident 256-thread blocks per CU of a kernel (from its register use), queried once per instantiation: the fc8 kernels size
 // their per-wave / per-block pixel ranges so that the grid is a whole number of full rounds (at the training shape the fixed
 // 8 / 64 pixels gave 2.04 rounds, i.e. three).
+// Cached per KERNEL POINTER (instantiations that share a function-pointer type share one generic-lambda body, so a `static` inside the
+// lambda would hand the first variant's occupancy to the others) -- a handful of entries, looked up linearly under a mutex.
 template <typename Kern>
 static int ps_blocks_per_cu(Kern kernel) {
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, int>> cache;
+  const void* key = reinterpret_cast<const void*>(kernel);
+  std::lock_guard<std::mutex> lock(mu);
+  for (const auto& e : cache)
+    if (e.first == key) return e.second;
   int n = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, 0) != hipSuccess || n < 1) n = 1;
+  cache.emplace_back(key, n);
   return n;
 }
 
@@ -676,7 +688,7 @@ extern "C" int ps_conv1a_fwd(int32_t out_dtype, const float* x, const float* w, 
   // the 16-bit kernels walk the pixels with a grid stride: exactly the resident blocks (one round, equal shares) -- the fixed cap of
   // 2048 blocks was 2.67 rounds of the 3 blocks a CU held
   auto lowp = [&](auto kernel, auto* oa, auto* orw) {
-    static const int bpc = ps_blocks_per_cu(kernel);
+    const int bpc = ps_blocks_per_cu(kernel);
     hipLaunchKernelGGL(kernel, dim3(std::min(grid, ps_num_cus() * bpc)), dim3(256), 0, s, x, w, scale, shift, oa, orw, n, h, wd, div_hw, div_w);
   };
   if (out_dtype == PS_BF16) {
@@ -708,7 +720,7 @@ extern "C" int ps_fc_head_fwd(int32_t dtype, const void* x, int32_t ldc_x, const
   PS_REQUIRE(ps_dtype_ok(dtype), "fc_head_fwd: dtype %d unsupported", dtype);
   // pixels per wave: one (or a whole number of) full round(s) of resident waves, at most ~24 pixels each
   auto launch = [&](auto kernel, auto xp) {
-    static const int bpc = ps_blocks_per_cu(kernel);
+    const int bpc = ps_blocks_per_cu(kernel);
     const long long cap = (long long)ps_num_cus() * bpc * 4;
     const long long rounds = (m_total + cap * 24 - 1) / (cap * 24);
     const int ppw = (int)((m_total + cap * rounds - 1) / (cap * rounds));
@@ -764,7 +776,7 @@ extern "C" int ps_fc8_bwd_ws(int32_t dtype, const void* x, int32_t ldc_x, const 
   PS_REQUIRE(ps_dtype_ok(dtype), "fc8_bwd: dtype %d unsupported", dtype);
   int mblocks = 0, rc = PS_OK;
   auto launch = [&](auto kernel, auto xp, auto dxp) {
-    static const int bpc = ps_blocks_per_cu(kernel);
+    const int bpc = ps_blocks_per_cu(kernel);
     const int ppb = fc8_bwd_ppb(m_total, ppi, k / 2048, bpc);
     mblocks = (m_total + ppb - 1) / ppb;
     if (workspace && workspace_floats < (int64_t)mblocks * c * k) {
