@@ -99,6 +99,7 @@ enum {
   PS_CONV_WS2_256 = 4,  /* conv_igemm_ws2_kernel<256>: 256x128 tile, one block per CU, 3-stage ring */
   PS_CONV_WS2_224 = 5,  /* conv_igemm_ws2_kernel<224> */
   PS_CONV_OTHER = 6,    /* an experimental kernel forced through the testing hooks */
+  PS_CONV_GEMM256 = 8,  /* conv_gemm256_kernel: plain GEMMs (1x1 stride-1, 16-bit), 256x256 tile, all eight waves compute, two wave groups alternate load / MFMA phases */
   PS_CONV_HALO = 7      /* conv_igemm_halo_kernel: 3x3 stride-1, width % 28 == 0 (224x128 tile of 8 rows x 28 columns) or % 32 == 0 (256x128, 8 x 32), pixel window + halo staged once per tap row */
 };
 int ps_conv_variant(const ps_conv_geom* g, int32_t dgrad);

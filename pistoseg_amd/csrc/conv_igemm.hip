@@ -1266,6 +1266,173 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
 }
 
 // ------------------------------------------------------------------------------------------------
+// 256 x 256 tile kernel for the PLAIN GEMMs of the net: 1x1 stride-1 layers (forward and data gradient; the bottleneck units'
+// K-concatenated shortcut + last conv included), 16-bit operands.
+//   The ws2 kernel stages (256 + 128) x 128 B per K-step for 256 x 128 x 64 MACs and is bound by the L2 -> LDS fill rate (~65 GB/s per
+//   CU); a 256 x 256 tile stages 64 KiB for twice the MACs: 1.5x fewer staged bytes (and LDS-DMA pieces) per FLOP.  Its
+//   64 K accumulators need all eight waves of the block as MFMA waves (128 accumulator registers each), so there are no loader waves:
+//   the block's two wave GROUPS (waves 0-3 and 4-7, one wave of each per SIMD) alternate roles, offset by one barrier -- while a
+//   group runs the 16 MFMAs of one output QUADRANT (64 pixels x 32 couts x one 64-deep K-tile), its SIMD partners issue their next
+//   fragment reads and their share of the LDS-DMA, so the matrix pipe of every SIMD always has an MFMA wave (the structure of the
+//   programming guide's 256^2 "8-phase" GEMM, restated for this data layout).
+//   * waves: (grp = wave >> 2) picks the pixel half, (wc = wave & 3) the 64-cout quarter: per wave 128 pixels x 64 couts = 8 x 4
+//     fragments -- the same per-wave shape, fragment layout and epilogue as the ws2 consumers.
+//   * LDS: two K-tile buffers of [256 pixel rows | 256 weight rows] x 128 B, XOR-swizzled exactly like the other kernels' images.
+//   * per K-tile and group four phases  L(q) | barrier | C(q) | barrier :  L = this quadrant's new fragment reads + ONE quarter tile
+//     (64 rows, 8 KiB: two 1-KiB pieces per wave) of LDS-DMA + counted vmcnt + lgkmcnt(0); C = 16 MFMAs.  Quadrants
+//     (A0,B0) (A0,B1) (A1,B1) (A1,B0): reads 8 / 4 / 8 / 4 (B0 of the NEXT K-tile is read in the last phase, into its second register set).
+//   * staging schedule (intervals between barriers; G0's L(q_j) of K-tile t is interval 8t + 2j, G1's 8t + 2j + 1): group g stages
+//     quarters g and g + 2 of A(t+1) in L(q0), L(q1) and of B(t+2) in L(q2), L(q3).  WAR: every L ends with lgkmcnt(0) BEFORE its
+//     barrier, so a quarter may be re-staged from the interval after its last read: B(t) is last read in interval 8t + 3 (restaged
+//     from 8t + 4), A rows of group h in interval 8t + 4 + h (restaged from 8(t+1) + ...).  RAW: a wave's pieces issued in one of its L
+//     phases have landed by the end of its L phase after next (vmcnt(4) = the two newest phases' pieces may be in flight), which is
+//     at least two intervals before any wave reads them.
+// ------------------------------------------------------------------------------------------------
+template <typename Tr>
+__global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const IgemmArgs a) {
+  typedef typename Tr::elem T;
+  static_assert(sizeof(T) == 2, "16-bit operands");
+  constexpr int BM = 256, BN = 256, MI = 8, WI = 4;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;  // 64 KiB per K-tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wc = wave & 3;
+  int tm, tn;
+  ps_tile_of_block(ps_xcd_remap(blockIdx.x, gridDim.x), a.ntn, a.ntm, tm, tn, a.supertile);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int NT = a.klines;
+
+  // ---- staging: this group's quarters {grp, grp + 2} of the pixel rows and of the weight rows; wave wc owns pieces 2 wc, 2 wc + 1
+  const int srow = lane >> 3;
+  const int chunk_off = ((lane & 7) ^ srow) << 4;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, (int)a.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.wgt, 0, (int)a.wgt_bytes, 0x00020000);
+  unsigned aoff[2][2], woff[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int rowq = (grp + 2 * h) * 64 + (2 * wc + p) * 8 + srow;  // row of the 256-row tile
+      const int m = m0 + rowq;
+      aoff[h][p] = m < a.M ? (unsigned)(m * (int)a.pix_bytes) + chunk_off : PAD_ROW;
+      const int within = rowq & 63, fi = within >> 4, rho = within & 15;  // weight rows are permuted inside each 64-row wave block
+      const int cout = n0 + (rowq & ~63) + 4 * WI * (rho >> 2) + 4 * fi + (rho & 3);
+      woff[h][p] = (unsigned)(cout * (int)a.wrow_bytes) + chunk_off;
+    }
+  auto stage_a = [&](int buf, int h, int kt) {
+    unsigned char* dst = smem + buf * BUF + ((grp + 2 * h) * 64 + 2 * wc * 8) * 128;
+    BLDS16(rsA, dst, aoff[h][0], kt * 128);
+    BLDS16(rsA, dst + 1024, aoff[h][1], kt * 128);
+  };
+  auto stage_b = [&](int buf, int h, int kt) {
+    unsigned char* dst = smem + buf * BUF + A_BYTES + ((grp + 2 * h) * 64 + 2 * wc * 8) * 128;
+    BLDS16(rsB, dst, woff[h][0], kt * 128);
+    BLDS16(rsB, dst + 1024, woff[h][1], kt * 128);
+  };
+
+  // ---- fragments
+  const int frow = lane & 15, g = lane >> 4, sw = lane & 7;
+  const int coff[2] = {(g ^ sw) << 4, ((g + 4) ^ sw) << 4};
+  const int xbase = (grp * 128 + frow) * 128, wbase = A_BYTES + (wc * 64 + frow) * 128;
+  f32x4 acc[MI][WI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int i = 0; i < WI; ++i) acc[mi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 xf[4][2];      // A0 or A1: 4 pixel fragments x 2 K-halves
+  u32x4 wf0[2][2][2];  // B0 (cout fragments 0, 1) of the current and of the next K-tile: [set][fragment][K-half]
+  u32x4 wf1[2][2];     // B1 (cout fragments 2, 3)
+  auto read_x = [&](const unsigned char* cb, int sub) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) xf[j][kh] = *reinterpret_cast<const u32x4*>(cb + xbase + (4 * sub + j) * 2048 + coff[kh]);
+  };
+  auto read_w = [&](const unsigned char* cb, int sub, u32x4 (&w)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) w[i][kh] = *reinterpret_cast<const u32x4*>(cb + wbase + (2 * sub + i) * 2048 + coff[kh]);
+  };
+  auto mma_quadrant = [&](int msub, int nsub, const u32x4 (&w)[2][2]) {  // 16 MFMAs; the same accumulator recurs every 8th
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) Tr::mma(w[i][kh], xf[j][kh], acc[4 * msub + j][2 * nsub + i]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // end of a load phase: the pieces of the two newest load phases may stay in flight; every LDS read retired BEFORE the barrier
+  auto end_load = [&](bool staged) {
+    if (staged) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+  auto end_compute = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // ---- prologue: A(0), B(0), B(1)
+  stage_a(0, 0, 0);
+  stage_a(0, 1, 0);
+  stage_b(0, 0, 0);
+  stage_b(0, 1, 0);
+  if (NT > 1) {
+    stage_b(1, 0, 1);
+    stage_b(1, 1, 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  read_w(smem, 0, wf0[0]);
+  if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger: G1 runs one barrier behind G0
+
+  auto ktile = [&](auto parity, int t) {
+    constexpr int P = decltype(parity)::value;
+    const unsigned char* cb = smem + P * BUF;
+    const bool s1 = t + 1 < NT, s2 = t + 2 < NT;
+    // L(q0): A0
+    read_x(cb, 0);
+    if (s1) stage_a(P ^ 1, 0, t + 1);
+    end_load(s1);
+    mma_quadrant(0, 0, wf0[P]);
+    end_compute();
+    // L(q1): B1
+    read_w(cb, 1, wf1);
+    if (s1) stage_a(P ^ 1, 1, t + 1);
+    end_load(s1);
+    mma_quadrant(0, 1, wf1);
+    end_compute();
+    // L(q2): A1
+    read_x(cb, 1);
+    if (s2) stage_b(P, 0, t + 2);
+    end_load(s2);
+    mma_quadrant(1, 1, wf1);
+    end_compute();
+    // L(q3): B0 of the NEXT K-tile (resident since two K-tiles ago)
+    if (s1) read_w(smem + (P ^ 1) * BUF, 0, wf0[P ^ 1]);
+    if (s2) stage_b(P, 1, t + 2);
+    end_load(s2);
+    mma_quadrant(1, 0, wf0[P]);
+    end_compute();
+  };
+  int t = 0;
+  for (; t + 1 < NT; t += 2) {
+    ktile(std::integral_constant<int, 0>{}, t);
+    ktile(std::integral_constant<int, 1>{}, t + 1);
+  }
+  if (t < NT) ktile(std::integral_constant<int, 0>{}, t);
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+  conv_epilogue<T, MI, WI, 0>(a, acc, m0 + grp * 128, n0 + wc * 64, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Halo kernel: 3x3 STRIDE-1 convolutions on feature maps whose width is a multiple of 28 (28 / 56 / 112; dilation <= 4; forward and
 // data gradient), persistent
 // 224 x 128 tiles, 4 consumer + 4 loader waves as conv_igemm_ws2_kernel -- but the pixel operand is staged as a WINDOW with
@@ -1628,6 +1795,7 @@ PS_TUNABLE g_use_ws2 = 1;
 PS_TUNABLE g_use_halo = 1;     // window + halo staging for 3x3 stride-1 layers (width a multiple of 28): 0 off, 1 for big 16-bit problems, 2 forced      // large-tile wave-specialised kernel: 0 off, 1 by cost model, 256 / 224 force that pixel tile
 PS_TUNABLE g_halo_tail = 1;   // halo kernel: a partial last round (<= half the CUs) as a second launch of 64-cout half tiles: 0 off, 1 on
 PS_TUNABLE g_halo_ring = 3;   // weight ring depth of the halo kernel (3 | 4 | 5 stages of 16 KiB; 256-pixel tiles: <= 4)
+PS_TUNABLE g_gemm256 = 1;      // 256 x 256 tile kernel for the plain GEMMs (1x1 stride-1, 16-bit): 0 off, 1 by shape, 2 whenever legal
 PS_TUNABLE g_use_3stage = 0;  // experimental 256x128 three-stage kernel: correct but slower than two 128x128 blocks per CU (r01 measurements)
 PS_TUNABLE g_ablate = 0;
 PS_TUNABLE g_supertile = 4;  // measured best of {0,4,8,16} on the wide 28x28 layers (r01)
@@ -1748,8 +1916,27 @@ static int pick_ws_variant(long long M, int Cd, int esize, bool halo_ok) {
   return 0;
 }
 
+// The 256 x 256 tile kernel serves plain GEMMs: one tap, no gather arithmetic, 16-bit operands, whole 256-cout tiles, K >= 256.
+// By shape (g_gemm256 == 1): at least one full round of tiles and K >= 512 -- below that the per-tile prologue / epilogue of this
+// non-persistent kernel outweighs its main loop's advantage (measured r03, profiles/r03_gemm256_vs_ws2.txt).
+static bool use_gemm256(long long M, int Cd, int esize, int taps, int mul, int div_shift, int klines) {
+  if (!g_gemm256 || g_use_glds != 2 || esize != 2 || taps != 1 || mul != 1 || div_shift != 0 || Cd % 256 != 0 || klines < 4) return false;
+  if (g_gemm256 == 2) return true;
+  return ((M + 255) / 256) * (Cd / 256) >= 256 && klines >= 8;
+}
+
 template <typename Tr>
 int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
+  if constexpr (sizeof(typename Tr::elem) == 2) {
+    if (a.tpb == 0 && use_gemm256(a.M, a.Cd, 2, a.taps, a.mul, a.div_shift, a.klines)) {
+      IgemmArgs b = a;
+      b.ntn = a.Cd / 256;
+      b.ntm = (a.M + 255) / 256;
+      hipLaunchKernelGGL((conv_gemm256_kernel<Tr>), dim3((unsigned)(b.ntm * b.ntn)), dim3(512), 2 * (256 * 128 + 256 * 128), s, b);
+      PS_CHECK_LAUNCH("conv_gemm256");
+      return PS_OK;
+    }
+  }
 #ifdef PS_DEBUG_HOOKS  // experimental kernels (measured slower, kept for the variant sweeps of the parity suite)
   // big problems: 256 x 128 tile, 3-stage LDS-DMA ring (1 block of 8 waves per CU)
   if (g_use_3stage && g_use_glds == 2 && a.Cd % 128 == 0 && (long long)((a.M + 255) / 256) * (a.Cd / 128) >= 256) {
@@ -1885,6 +2072,7 @@ extern "C" void ps_debug_set_pp(int v) { g_use_pp = v; }
 extern "C" void ps_debug_set_ws(int v) { g_use_ws = v; }
 extern "C" void ps_debug_set_ws2(int v) { g_use_ws2 = v; }
 extern "C" void ps_debug_set_halo(int v) { g_use_halo = v; }
+extern "C" void ps_debug_set_gemm256(int v) { g_gemm256 = v; }
 #ifdef PS_HALO_STAMPS
 extern "C" int ps_debug_read_stamps(unsigned long long* host_out) {  // 256 x 4 x 4 values; synchronises the device
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_halo_stamps), sizeof(g_halo_stamps)) == hipSuccess ? 0 : -2;
@@ -1902,6 +2090,9 @@ extern "C" int ps_conv_variant(const ps_conv_geom* g, int32_t dgrad) {
   const long long ho = (g->h - 1) / g->stride + 1, wo = (g->w - 1) / g->stride + 1;
   const long long M = dgrad ? (long long)g->n * g->h * g->w : (long long)g->n * ho * wo;
   if (g_use_3stage + g_use_pp != 0) return PS_CONV_OTHER;
+  if (g->tiles_per_block == 0 && use_gemm256(M, dgrad ? g->cin : g->cout, ps_esize(g->dtype), g->ksize * g->ksize, dgrad ? 1 : g->stride,
+                                              dgrad && g->stride == 2 ? 1 : 0, (dgrad ? g->cout : g->cin) * ps_esize(g->dtype) / 128))
+    return PS_CONV_GEMM256;
   // both directions of a stride-1 3x3 layer gather on the input grid h x w
   const bool halo_ok = g->ksize == 3 && g->stride == 1 && halo_tile_width(g->w) != 0 && g->dilation <= 4;
   const int v = pick_ws_variant(M, dgrad ? g->cin : g->cout, ps_esize(g->dtype), halo_ok);

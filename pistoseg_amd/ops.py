@@ -24,7 +24,7 @@ PROFILE = None
 
 
 _VARIANT_NAMES = {1: "conv_igemm_kernel", 2: "conv_igemm_ws_kernel", 3: "conv_igemm_ws_kernel", 4: "conv_igemm_ws2_kernel", 5: "conv_igemm_ws2_kernel",
-                  6: "conv_igemm_experimental", 7: "conv_igemm_halo_kernel"}
+                  6: "conv_igemm_experimental", 7: "conv_igemm_halo_kernel", 8: "conv_gemm256_kernel"}
 
 
 def _conv_label(kind: str, g: ConvGeom) -> str:

@@ -30,7 +30,7 @@ def library(request):
 
 debug_only = pytest.mark.parametrize("library", ["debug"], indirect=True)  # tests that drive `ps_debug_set_*`
 # conv_igemm.hip's variant codes (include/pistoseg_hip.h)
-V_4WAVE, V_WS_128, V_WS_112, V_WS2_256, V_WS2_224, V_OTHER, V_HALO = 1, 2, 3, 4, 5, 6, 7
+V_4WAVE, V_WS_128, V_WS_112, V_WS2_256, V_WS2_224, V_OTHER, V_HALO, V_GEMM256 = 1, 2, 3, 4, 5, 6, 7, 8
 
 
 def conv_variant(spec, dtype, n, h, w, kind):
@@ -680,9 +680,10 @@ def test_wgrad_deterministic_mode(case, dtype, library):
     ((19, 28, 28, 128, 512, 3, 1, 1), "halo"),    # 66.5 pixel tiles of 8 x 28: straddles images, ragged last tile; tail half tiles
     ((10, 56, 56, 64, 256, 3, 1, 2), "halo"),     # two column blocks per row, dilation 2
     ((17, 32, 32, 64, 512, 3, 1, 4), "halo"),     # 256-pixel tiles (the maps of 256 x 256 inputs), dilation 4
-    ((8, 28, 28, 2048, 4096, 1, 1, 1), "ws2"),    # b7's 1x1 shape
-    ((37, 28, 28, 512, 1024, 1, 1, 1), "ws2"),    # odd image count: ragged last pixel tile
-    ((21, 56, 56, 256, 512, 3, 2, 1), "ws2"),     # stride-2 3x3 (b4's first conv)
+    ((8, 28, 28, 2048, 4096, 1, 1, 1), "gemm256"),  # b7's 1x1 shape: the 256 x 256 tile GEMM kernel, 24.5 pixel tiles (ragged)
+    ((37, 28, 28, 512, 1024, 1, 1, 1), "gemm256"),  # odd image count: ragged last pixel tile, 8 K-tiles
+    ((37, 28, 28, 512, 256, 1, 1, 1), "ws2"),       # one 256-cout tile column: too few tiles for the 256 x 256 kernel -> ws2 (2 x 128 couts)
+    ((21, 56, 56, 256, 512, 3, 2, 1), "ws2"),       # stride-2 3x3 (b4's first conv)
 ])
 def test_persistent_kernels_selected_by_geometry_match_cpu(case, family, dtype, library):
     """The kernels the benchmark runs (conv_igemm_halo_kernel, conv_igemm_ws2_kernel, conv_wgrad_ws2_kernel), reached WITHOUT any debug
@@ -693,7 +694,7 @@ def test_persistent_kernels_selected_by_geometry_match_cpu(case, family, dtype, 
 
     n, h, w, cin, cout, k, s_, d = case
     spec = ops.ConvSpec(cin, cout, k, s_, d)
-    want = (V_HALO,) if family == "halo" else (V_WS2_256, V_WS2_224)
+    want = {"halo": (V_HALO,), "ws2": (V_WS2_256, V_WS2_224), "gemm256": (V_GEMM256,)}[family]
     assert conv_variant(spec, dtype, n, h, w, "fwd") in want
     wg_ws2 = conv_variant(spec, dtype, n, h, w, "wgrad") == 1
     assert wg_ws2 or cout % 256 or cin % 128  # every eligible shape here is big enough for the persistent weight-gradient kernel
@@ -762,7 +763,7 @@ def test_full_size_layers_kernel_families_agree(case, library):
         return gx, dw
 
     # the persistent kernels are what the geometry selects, in either library
-    want = (V_HALO,) if k == 3 else (V_WS2_256, V_WS2_224)
+    want = (V_HALO,) if k == 3 else (V_GEMM256,)
     for kind in ("fwd", "dgrad"):
         assert conv_variant(spec, dtype, n, hw, hw, kind) in want, kind
     assert conv_variant(spec, dtype, n, hw, hw, "wgrad") == 1
@@ -845,6 +846,69 @@ def test_persistent_kernels_batched_work_split_is_exact(tpb, library):
             ops.TILES_PER_BLOCK = 0
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
         assert rel_err(got[2].cpu(), ref[2].cpu()) < 1e-5
+
+
+@debug_only
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [
+    # (n, h, w, cin, cout): 1x1 stride 1.  K-tiles (cin / 64): 4 (the minimum), 5 (odd: the unpaired tail K-tile), 8, 17; pixel counts that
+    # are not multiples of 256 (zero-filled tail rows, rows dropped by the epilogue), down to a tile with 2 live rows; 1..3 cout tiles
+    (3, 15, 14, 256, 256), (1, 16, 16, 320, 512), (2, 13, 10, 512, 768), (1, 2, 129, 1088, 256), (5, 28, 28, 512, 512),
+])
+def test_gemm256_kernel_forced_on_small_problems(case, dtype):
+    """conv_gemm256_kernel (256 x 256 tile, eight MFMA waves in two alternating groups) forced on small ragged problems: forward with
+    the full epilogue, data gradient with the ReLU-mask epilogue -- against the CPU, against the ws2 / 4-wave kernels (same MFMA chain
+    per output element: BIT-IDENTICAL), and repeated (race screen: every LDS hand-off in this kernel is ordered by counted waits)."""
+    from pistoseg_amd import _lib, ops
+
+    lib = _lib.load()
+    n, h, w, cin, cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    q = quant(dtype)
+    x = q(torch.randn(n, cin, h, w, generator=g)).requires_grad_(True)
+    wt = q(torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5)
+    y = F.conv2d(x, wt)
+    res = q(torch.randn(y.shape, generator=g))
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    drop = (torch.rand(n, cout, generator=g) > 0.3).float() / 0.7
+    act = F.relu((y + res) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)) * drop.view(n, cout, 1, 1)
+    gy = q(torch.randn(y.shape, generator=g))
+    y.backward(gy)
+    # data gradient of a layer with `cout` inputs: produces cout channels from cin
+    wt_t = q(torch.randn(cin, cout, 1, 1, generator=g) * 0.05)
+    gy_t = q(torch.randn(n, cin, h, w, generator=g))
+    mask_src = q(F.relu(torch.randn(n, cout, h, w, generator=g)))
+    sc2 = torch.rand(cout, generator=g) + 0.5
+    gx_ref = torch.where(mask_src > 0, torch.nn.grad.conv2d_input((n, cout, h, w), wt_t, gy_t) * sc2.view(1, -1, 1, 1), torch.zeros(()))
+    tol = TOL[dtype]
+    spec, spec_t = ops.ConvSpec(cin, cout, 1, 1, 1), ops.ConvSpec(cout, cin, 1, 1, 1)
+    D = dev()
+    xd, wf, resd = nhwc(x.detach()).to(D, dtype), w_fwd_layout(wt).to(D, dtype), nhwc(res).to(D, dtype)
+    gyd, wdt, maskd = nhwc(gy_t).to(D, dtype), w_dgrad_layout(wt_t).to(D, dtype), nhwc(mask_src).to(D, dtype)
+
+    def run():
+        out_raw = torch.full((n, h, w, cout), float("nan"), device=D, dtype=dtype)
+        out_act = torch.full((n, h, w, cout), float("nan"), device=D, dtype=dtype)
+        ops.conv2d_fwd(spec, xd, wf, add0=resd, out_raw=out_raw, bn_scale=scale.to(D), bn_shift=shift.to(D), drop=drop.to(D), out_act=out_act)
+        gx = torch.full((n, h, w, cout), float("nan"), device=D, dtype=dtype)
+        ops.conv2d_dgrad(spec_t, gyd, wdt, (h, w), mask_src=maskd, bn_scale=sc2.to(D), out=gx)
+        return out_raw, out_act, gx
+
+    try:
+        lib.ps_debug_set_gemm256(2)
+        assert conv_variant(spec, dtype, n, h, w, "fwd") == V_GEMM256 and conv_variant(spec_t, dtype, n, h, w, "dgrad") == V_GEMM256
+        got = [run() for _ in range(4)]
+        lib.ps_debug_set_gemm256(0)
+        assert conv_variant(spec, dtype, n, h, w, "fwd") != V_GEMM256
+        other = run()
+    finally:
+        lib.ps_debug_set_gemm256(1)
+    refs = (nhwc((y + res).detach()), nhwc(act.detach()), nhwc(gx_ref))
+    for a_, r_, o_ in zip(got[0], refs, other):
+        assert rel_err(a_.float().cpu(), r_) < tol
+        assert torch.equal(a_, o_)  # K order and MFMA chain per output element are the other kernels'
+    for trial in got[1:]:
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(trial, got[0]))
 
 
 @debug_only

@@ -73,6 +73,7 @@ def main():
                     lib.ps_debug_set_ws(1)
                     lib.ps_debug_set_ws2(1)
                     lib.ps_debug_set_halo(1)
+                    lib.ps_debug_set_gemm256(1)
                     lib.ps_debug_set_halo_ring(args.halo_ring)
                     lib.ps_debug_set_halo_tail(1)
                     lib.ps_debug_set_ablate(0)
@@ -103,6 +104,7 @@ def main():
     lib.ps_debug_set_ws(1)
     lib.ps_debug_set_ws2(1)
     lib.ps_debug_set_halo(1)
+    lib.ps_debug_set_gemm256(1)
     lib.ps_debug_set_wgrad_ws2(1)
     lib.ps_debug_set_wgrad_ablate(0)
     lib.ps_debug_set_wgrad_raster(-1)
