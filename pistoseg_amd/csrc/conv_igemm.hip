@@ -1917,12 +1917,12 @@ static int pick_ws_variant(long long M, int Cd, int esize, bool halo_ok) {
 }
 
 // The 256 x 256 tile kernel serves plain GEMMs: one tap, no gather arithmetic, 16-bit operands, whole 256-cout tiles, K >= 256.
-// By shape (g_gemm256 == 1): at least one full round of tiles and K >= 512 -- below that the per-tile prologue / epilogue of this
-// non-persistent kernel outweighs its main loop's advantage (measured r03, profiles/r03_gemm256_vs_ws2.txt).
+// By shape (g_gemm256 == 1): K >= 2048 and >= 2048 produced channels -- measured r03 (profiles/r03_gemm256_vs_ws2.txt): +13..27 % there,
+// +-5 % on the K = 1024 / 1024-channel layers, whose 784-tile launches are 3.06 rounds of this non-persistent kernel.
 static bool use_gemm256(long long M, int Cd, int esize, int taps, int mul, int div_shift, int klines) {
   if (!g_gemm256 || g_use_glds != 2 || esize != 2 || taps != 1 || mul != 1 || div_shift != 0 || Cd % 256 != 0 || klines < 4) return false;
   if (g_gemm256 == 2) return true;
-  return ((M + 255) / 256) * (Cd / 256) >= 256 && klines >= 8;
+  return ((M + 255) / 256) * (Cd / 256) >= 512 && klines >= 32 && Cd >= 2048;
 }
 
 template <typename Tr>
