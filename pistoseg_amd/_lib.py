@@ -154,6 +154,7 @@ DEBUG_PROTOTYPES = {
     "ps_debug_set_s2split": (None, [C.c_int]),
     "ps_debug_set_wgrad_ws": (None, [C.c_int]),
     "ps_debug_set_wgrad_ws2": (None, [C.c_int]),
+    "ps_debug_set_wgrad256": (None, [C.c_int]),
     "ps_debug_set_wgrad_ablate": (None, [C.c_int]),
     "ps_debug_set_wgrad_ovh": (None, [C.c_int]),
     "ps_debug_set_supertile": (None, [C.c_int]),

@@ -33,6 +33,7 @@ struct WgradArgs {
   int raster;                  // block order (see kernel)
   int ablate;                  // timing experiments only (results WRONG): 1 = no atomics, 2 = plain stores instead of atomics
   int nb, tpb;                 // persistent kernel: blocks per batch (#CUs), items per block (0 = one batch), see ps_block_items
+  int cig, cog;                // item order: cin / cout tiles per group of consecutive items (see decode_item)
   float* part;                 // deterministic mode (DET kernels): workspace [pixel range][cout][taps][cin] f32 for the partial sums
   long long part_stride;       // elements per pixel range = cout * taps * cin
 };
@@ -595,11 +596,239 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 256 cout x 256 cin tile, all eight waves MFMA waves (r03): the weight-gradient counterpart of conv_gemm256_kernel.
+//   A SIMD's instruction issue -- MFMAs (8 cycles each), transposed LDS reads, LDS-DMA pieces (60-100 cycles each) -- is what
+//   paces the wave-specialised kernel above: per 64-pixel K-step its consumer wave issues 64 MFMAs + 48 reads and its loader
+//   partner 12 DMA pieces + the pixel tracking, ~2100 issue cycles for 1024 matrix-pipe cycles.  A 256 x 256 tile stages
+//   64 KiB per K-step for twice the MACs: 8 pieces per wave, and both waves of a SIMD are MFMA waves.
+//   * waves: grp = wave >> 2 picks the 128-cout half, wc = wave & 3 the 64-cin quarter: 8 x 4 fragments per wave, the ws2 consumers'
+//     shape, fragment reads (ds_read_b64_tr_b16 on the K(pixel)-major images), swizzle and atomic epilogue.
+//   * LDS: two K-step buffers of [64 pixel rows x 512 B of dY | 64 x 512 B of X].
+//   * schedule: exactly conv_gemm256_kernel's -- two wave groups one barrier apart, per K-step and group four phases
+//     L(q) | barrier | C(q) | barrier over the quadrants (A0,B0) (A0,B1) (A1,B1) (A1,B0) with A = dY fragments, B = X fragments;
+//     a group stages row quarters {grp, grp + 2} (16 pixel rows = 8 pieces, two per wave) of dY(t+1) in L(q0), L(q1) and of X(t+2)
+//     in L(q2), L(q3); every L ends with vmcnt(4) + lgkmcnt(0) before its barrier.  (All 64 rows of dY(t+1) are first read in
+//     interval 8t + 8; the last quarter is staged in 8t + 3 and waited for in 8t + 7.)
+//   * one work item (tile, tap, pixel range) per block, item order as decode_item; f32 atomics or, DET, plain stores into the range's
+//     workspace slice.
+// ------------------------------------------------------------------------------------------------
+template <bool F16, int XM, bool DET = false>
+__global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a) {
+  constexpr int ES = 2, KP = 64, RB = 512;                    // both LDS images: 64 pixel rows x 512 B (256 channels)
+  constexpr int IMG = KP * RB, BUF = 2 * IMG;                 // 32 KiB per operand, 64 KiB per K-step
+  constexpr int MI = 8, NI = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wc = wave & 3;
+  const int per = (a.ksteps + a.splits - 1) / a.splits;
+  // item -> (cin tile, cout tile, tap, pixel range); see launch_wgrad256 for the order
+  int item = ps_xcd_remap(blockIdx.x, gridDim.x);
+  const int t_lo = item % a.cig; item /= a.cig;
+  const int tap = item % a.taps; item /= a.taps;
+  const int u_lo = item % a.cog; item /= a.cog;
+  const int ci_hi = item % (a.tiles_ci / a.cig); item /= (a.tiles_ci / a.cig);
+  const int co_hi = item % (a.tiles_co / a.cog); item /= (a.tiles_co / a.cog);
+  const int tci = ci_hi * a.cig + t_lo, tco = co_hi * a.cog + u_lo;
+  const int ks0 = item * per, ks1 = min(a.ksteps, ks0 + per);
+  const int NT = ks1 - ks0;
+  if (NT <= 0) return;
+  const int ty = a.taps == 1 ? a.ctr : tap / 3, tx = a.taps == 1 ? a.ctr : tap - (tap / 3) * 3;
+  const int dy_off = (ty - a.ctr) * a.dil, dx_off = (tx - a.ctr) * a.dil;
+
+  // ---- staging: this group's row quarters {grp, grp + 2} of both images; wave wc owns pieces 2 wc, 2 wc + 1 (two pixel rows each)
+  const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)a.dy_bytes, 0x00020000);
+  const int xpad = XM == 1 ? (a.dil * a.W + a.dil) * (int)a.x_pix_bytes : 0;  // see conv_wgrad_ws2_kernel
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x - xpad), 0, (int)a.x_bytes + xpad, 0x00020000);
+  const int rowin = lane >> 5, pos = lane & 31;
+  // Pixel row of piece (h, p): R = 16 grp + 32 h + 4 wc + 2 p + rowin.  Its swizzle only depends on p (R & 3 = 2 p + rowin,
+  // (R >> 3) & 1 = wc >> 1), so one lane offset per p serves both quarters; the quarter's 32 rows go into the SCALAR offset.
+  const int R0 = 16 * grp + 4 * wc + rowin;
+  unsigned goff[2], xoff[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int R = R0 + 2 * p;
+    const unsigned sw = (unsigned)((pos ^ row_swz<ES, RB>(R)) << 4);
+    static_assert(XM >= 1, "stride-1 layers only (the lane offset of an X row is a constant)");
+    goff[p] = (unsigned)(R * (int)a.dy_pix_bytes + tco * 256 * ES) + sw;
+    xoff[p] = (unsigned)(R * (int)a.x_pix_bytes + tci * 256 * ES) + sw;
+  }
+  auto stage_g = [&](int buf, int h, int ks) {  // dY rows of K-step ks (absolute), quarter grp + 2 h
+    unsigned char* dst = smem + buf * BUF + ((grp + 2 * h) * 8 + 2 * wc) * 1024;
+    const int gso = (ks * KP + 32 * h) * (int)a.dy_pix_bytes;
+    BLDS16(rsG, dst, goff[0], gso);
+    BLDS16(rsG, dst + 1024, goff[1], gso);
+  };
+  // X rows of K-step ks: the tap's row is the pixel's row shifted by a constant, i.e. lane constant + scalar offset from a descriptor that
+  // starts (d W + d) pixels before the tensor; 3x3: rows whose shifted coordinates leave the image are padding (zero-filled) -- the test
+  // is recomputed from the pixel index (two magic-number divisions per row: no per-lane state, this kernel has no registers to spare)
+  auto stage_x = [&](int buf, int h, int ks) {
+    unsigned char* dst = smem + buf * BUF + IMG + ((grp + 2 * h) * 8 + 2 * wc) * 1024;
+    const int xso = (ks * KP + 32 * h + dy_off * a.W + dx_off) * (int)a.x_pix_bytes + xpad;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      if constexpr (XM == 2) {
+        BLDS16(rsX, dst + p * 1024, xoff[p], xso);  // (rows past the last pixel: outside the descriptor -> zeros)
+      } else {
+        const uint32_t m = (uint32_t)(ks * KP + 32 * h + R0 + 2 * p);
+        const uint32_t n = fdiv(m, a.div_hw);
+        const uint32_t rem = m - n * a.div_hw.d;
+        const uint32_t pp = fdiv(rem, a.div_w);
+        const int y = (int)pp + dy_off, xx = (int)(rem - pp * a.div_w.d) + dx_off;
+        const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;  // (past the last image: outside the descriptor)
+        BLDS16(rsX, dst + p * 1024, ok ? xoff[p] : PAD_ROW, xso);
+      }
+    }
+  };
+
+  // ---- fragments (see conv_wgrad_ws2_kernel for the address algebra)
+  const int g = lane >> 4, l16 = lane & 15, q4 = l16 >> 2, p4 = l16 & 3;
+  const int s3 = row_swz<ES, RB>(8 * g + q4) >> 1;
+  const int a_base = (8 * g + q4) * RB + (p4 & 1) * 8 + (((grp * 16) + (p4 >> 1)) << 4);
+  const int b_base = IMG + (8 * g + q4) * RB + (p4 & 1) * 8 + ((((wc ^ (s3 >> 2)) << 3) + (p4 >> 1)) << 4);
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[4][2];      // A0 or A1: 4 cout fragments x 2 K-halves
+  bf16x8 bf0[2][2][2];  // B0 (cin fragments 0, 1) of the current and of the next K-step: [set][fragment][K-half]
+  bf16x8 bf1[2][2];     // B1 (cin fragments 2, 3)
+  auto tr_read = [&](const unsigned char* ptr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ptr));
+  };
+  auto read_a = [&](const unsigned char* cb, int sub) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bf16x4 t = tr_read(cb + a_base + (kk * 32 + 4 * h) * RB + (((4 * sub + j) ^ s3) << 5));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) af[j][kk][4 * h + e] = t[e];
+        }
+  };
+  auto read_b = [&](const unsigned char* cb, int sub, bf16x8 (&b)[2][2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bf16x4 t = tr_read(cb + b_base + (kk * 32 + 4 * h) * RB + (((2 * sub + j) ^ (s3 & 3)) << 5));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b[j][kk][4 * h + e] = t[e];
+        }
+  };
+  auto mfma1 = [&](f32x4& c, const bf16x8& x, const bf16x8& y) {
+    if constexpr (F16) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
+    else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
+  };
+  auto mma_quadrant = [&](int msub, int nsub, const bf16x8 (&b)[2][2]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) mfma1(acc[4 * msub + j][2 * nsub + i], af[j][kk], b[i][kk]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto end_load = [&](bool staged) {
+    if (staged) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+  auto end_compute = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // ---- prologue: dY(0), X(0), X(1)
+  stage_g(0, 0, ks0);
+  stage_g(0, 1, ks0);
+  stage_x(0, 0, ks0);
+  stage_x(0, 1, ks0);
+  if (NT > 1) {
+    stage_x(1, 0, ks0 + 1);
+    stage_x(1, 1, ks0 + 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  read_b(smem, 0, bf0[0]);
+  if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger: G1 runs one barrier behind G0
+
+  auto kstep = [&](auto parity, int t) {
+    constexpr int P = decltype(parity)::value;
+    const unsigned char* cb = smem + P * BUF;
+    const bool s1 = t + 1 < NT, s2 = t + 2 < NT;
+    read_a(cb, 0);
+    if (s1) stage_g(P ^ 1, 0, ks0 + t + 1);
+    end_load(s1);
+    mma_quadrant(0, 0, bf0[P]);
+    end_compute();
+    read_b(cb, 1, bf1);
+    if (s1) stage_g(P ^ 1, 1, ks0 + t + 1);
+    end_load(s1);
+    mma_quadrant(0, 1, bf1);
+    end_compute();
+    read_a(cb, 1);
+    if (s2) stage_x(P, 0, ks0 + t + 2);
+    end_load(s2);
+    mma_quadrant(1, 1, bf1);
+    end_compute();
+    if (s1) read_b(smem + (P ^ 1) * BUF, 0, bf0[P ^ 1]);
+    if (s2) stage_x(P, 1, ks0 + t + 2);
+    end_load(s2);
+    mma_quadrant(1, 0, bf0[P]);
+    end_compute();
+  };
+  int t = 0;
+  for (; t + 1 < NT; t += 2) {
+    kstep(std::integral_constant<int, 0>{}, t);
+    kstep(std::integral_constant<int, 1>{}, t + 1);
+  }
+  if (t < NT) kstep(std::integral_constant<int, 0>{}, t);
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue: conv_wgrad_ws2_kernel's (4 x 4 lane <-> fragment transpose, one 256-byte row segment per wave instruction)
+  const long long wrow = (long long)a.taps * a.cin;
+  float* const dst_base = DET ? a.part + (long long)(ks0 / per) * a.part_stride : a.dw;
+  const __amdgpu_buffer_rsrc_t rs_dw = __builtin_amdgcn_make_buffer_rsrc((void*)dst_base, 0, (int)((long long)a.cout * wrow * 4), 0x00020000);
+  const unsigned row_bytes = (unsigned)wrow * 4u;
+  const unsigned item_off = (unsigned)(((long long)(tco * 256 + grp * 128) * wrow + (long long)tap * a.cin + tci * 256 + wc * 64) * 4);
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      uint32_t v0 = __float_as_uint(acc[i][0][r]), v1 = __float_as_uint(acc[i][1][r]);
+      uint32_t v2 = __float_as_uint(acc[i][2][r]), v3 = __float_as_uint(acc[i][3][r]);
+      auto s02 = __builtin_amdgcn_permlane32_swap(v0, v2, false, false);
+      auto s13 = __builtin_amdgcn_permlane32_swap(v1, v3, false, false);
+      v0 = s02[0]; v2 = s02[1]; v1 = s13[0]; v3 = s13[1];
+      auto s01 = __builtin_amdgcn_permlane16_swap(v0, v1, false, false);
+      auto s23 = __builtin_amdgcn_permlane16_swap(v2, v3, false, false);
+      const float o[4] = {__uint_as_float(s01[0]), __uint_as_float(s01[1]), __uint_as_float(s23[0]), __uint_as_float(s23[1])};
+#pragma unroll
+      for (int jp = 0; jp < 4; ++jp) {
+        const unsigned voff = item_off + (unsigned)(i * 16 + 4 * jp + r) * row_bytes + (unsigned)lane * 4u;
+        if constexpr (DET) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[jp]), rs_dw, voff, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(o[jp], rs_dw, voff, 0, 0);
+      }
+    }
+}
+
 PS_TUNABLE g_wgrad_ws = 1;
 PS_TUNABLE g_wgrad_ablate = 0;
 PS_TUNABLE g_wgrad_ovh = 16;  // per-item overhead of the persistent kernel in K-step units (atomics + pipeline refill)
 PS_TUNABLE g_wgrad_ws2 = 1;  // large-tile persistent kernel for 16-bit operands with cout % 256 == 0, cin % 128 == 0
 
+PS_TUNABLE g_wgrad256 = 1;   // 256 x 256 tile kernel (cout % 256 == 0, cin % 256 == 0, 16-bit): 0 off, 1 by shape, 2 whenever legal
 PS_TUNABLE g_wgrad_raster = -1;  // -1: by shape (measured r01: pixel-range-slowest wins for 3x3 layers with >= 64 tiles)
 
 // Geometry-derived fields + split-K choice of conv_wgrad_kernel; returns the number of pixel ranges that get work.
@@ -686,6 +915,57 @@ int launch_wgrad_ws2(WgradArgs a, hipStream_t s) {
   return PS_OK;
 }
 
+// Geometry-derived fields + pixel-range count + item order of conv_wgrad256_kernel; returns the number of ranges that get work.
+static long long plan_wgrad256(WgradArgs& a) {
+  a.tiles_co = a.cout / 256;
+  a.tiles_ci = a.cin / 256;
+  a.ksteps = (a.M + 63) / 64;
+  a.dq = 64 % a.Wo;
+  a.dp = (64 / a.Wo) % a.Ho;
+  a.dn = 64 / (a.Wo * a.Ho);
+  a.raster = 0;
+  a.ablate = 0;
+  const long long tiles = (long long)a.tiles_co * a.tiles_ci * a.taps;
+  const int ncu = ps_num_cus();
+  // one block per item, one resident block per CU: rounds x (K-steps per item + prologue / epilogue in K-step units)
+  long long splits = 1, best = -1;
+  const long long max_splits = std::max<long long>(1, a.ksteps / 8);
+  for (long long sp = 1; sp <= max_splits && tiles * sp <= 65536; ++sp) {
+    const long long per = (a.ksteps + sp - 1) / sp, live = (a.ksteps + per - 1) / per;
+    const long long rounds = (tiles * live + ncu - 1) / ncu;
+    const long long cost = rounds * (per + g_wgrad_ovh);
+    if (best < 0 || cost < best) { best = cost; splits = sp; }
+  }
+  a.splits = (int)splits;
+  a.nb = ncu;
+  // Item order: consecutive items = the blocks that run together on one XCD and stream a pixel range through its L2.  An item stages its
+  // 256 couts of dY and 256 cins of X per K-step; the taps of one (cin, cout) tile pair read the SAME dY rows and X rows that coincide up
+  // to a skew of a few K-steps, so taps vary fastest after a small group of cin tiles, then a group of cout tiles:
+  //   [cig cin tiles][taps][cog cout tiles][remaining cin groups][remaining cout groups][pixel range]
+  a.cig = a.taps == 9 ? (a.tiles_ci % 2 == 0 ? 2 : 1) : (a.tiles_ci % 4 == 0 ? 4 : (a.tiles_ci % 2 == 0 ? 2 : 1));
+  const int want_co = std::max(1, 32 / (a.cig * a.taps));
+  a.cog = 1;
+  while (a.cog * 2 <= want_co && a.tiles_co % (a.cog * 2) == 0) a.cog *= 2;
+  const long long per = (a.ksteps + splits - 1) / splits;
+  return (a.ksteps + per - 1) / per;
+}
+
+template <typename Tr, bool DET = false>
+int launch_wgrad256(WgradArgs a, hipStream_t s) {
+  const long long live = plan_wgrad256(a);
+  const long long items = (long long)a.tiles_co * a.tiles_ci * a.taps * live;
+  const size_t lds = 2 * 2 * 64 * 512;
+  if (a.taps == 1) hipLaunchKernelGGL((conv_wgrad256_kernel<Tr::F16, 2, DET>), dim3((unsigned)items), dim3(512), lds, s, a);
+  else hipLaunchKernelGGL((conv_wgrad256_kernel<Tr::F16, 1, DET>), dim3((unsigned)items), dim3(512), lds, s, a);
+  PS_CHECK_LAUNCH("conv_wgrad256");
+  return PS_OK;
+}
+
+static bool use_wgrad256(int esize, long long M, int cout, int cin, int taps, int tpb, int stride) {
+  if (!g_wgrad256 || esize != 2 || cout % 256 != 0 || cin % 256 != 0 || tpb != 0 || stride != 1) return false;
+  return g_wgrad256 > 1 || M * cout * cin * taps >= (1LL << 31);
+}
+
 static bool use_wgrad_ws2(int esize, long long M, int cout, int cin, int taps) {
   return g_wgrad_ws2 && esize == 2 && cout % 256 == 0 && cin % 128 == 0 && (g_wgrad_ws2 > 1 || M * cout * cin * taps >= (1LL << 31));
 }
@@ -693,6 +973,7 @@ static bool use_wgrad_ws2(int esize, long long M, int cout, int cin, int taps) {
 template <typename Tr, bool DET = false>
 int dispatch_wgrad(const WgradArgs& a, hipStream_t s) {
   if constexpr (Tr::ES == 2) {
+    if (use_wgrad256(Tr::ES, a.M, a.cout, a.cin, a.taps, a.tpb, a.stride)) return launch_wgrad256<Tr, DET>(a, s);
     if (use_wgrad_ws2(Tr::ES, a.M, a.cout, a.cin, a.taps)) return launch_wgrad_ws2<Tr, DET>(a, s);
   }
   const bool co128 = a.cout % 128 == 0, ci128 = a.cin % 128 == 0;
@@ -705,6 +986,7 @@ int dispatch_wgrad(const WgradArgs& a, hipStream_t s) {
 // Pixel ranges (split-K parts) the dispatcher will cut this problem into: the same plan functions the launchers use.
 template <typename Tr>
 long long wgrad_live_ranges(WgradArgs a) {
+  if (use_wgrad256(Tr::ES, a.M, a.cout, a.cin, a.taps, a.tpb, a.stride)) return plan_wgrad256(a);
   if (use_wgrad_ws2(Tr::ES, a.M, a.cout, a.cin, a.taps)) return plan_wgrad_ws2(a);
   const bool co128 = a.cout % 128 == 0, ci128 = a.cin % 128 == 0;
   if (co128 && ci128) return plan_wgrad<Tr, 128, 128>(a);
@@ -751,6 +1033,7 @@ long long live_ranges_of(const ps_conv_geom* g, const WgradArgs& a) {
 #ifdef PS_DEBUG_HOOKS
 extern "C" void ps_debug_set_wgrad_ws(int v) { g_wgrad_ws = v; }
 extern "C" void ps_debug_set_wgrad_ws2(int v) { g_wgrad_ws2 = v; }
+extern "C" void ps_debug_set_wgrad256(int v) { g_wgrad256 = v; }
 extern "C" void ps_debug_set_wgrad_ablate(int v) { g_wgrad_ablate = v; }
 extern "C" void ps_debug_set_wgrad_ovh(int v) { g_wgrad_ovh = v; }
 extern "C" void ps_debug_set_wgrad_raster(int v) { g_wgrad_raster = v; }
@@ -759,6 +1042,7 @@ extern "C" void ps_debug_set_wgrad_raster(int v) { g_wgrad_raster = v; }
 extern "C" int ps_conv_wgrad_variant(const ps_conv_geom* g) {
   if (!g || !ps_conv_supported(g)) return -1;
   const long long ho = (g->h - 1) / g->stride + 1, wo = (g->w - 1) / g->stride + 1;
+  if (use_wgrad256(ps_esize(g->dtype), (long long)g->n * ho * wo, g->cout, g->cin, g->ksize * g->ksize, g->tiles_per_block, g->stride)) return 2;
   return use_wgrad_ws2(ps_esize(g->dtype), (long long)g->n * ho * wo, g->cout, g->cin, g->ksize * g->ksize) ? 1 : 0;
 }
 

@@ -31,7 +31,8 @@ def _conv_label(kind: str, g: ConvGeom) -> str:
     """Kernel family serving this launch (asked of the library: ps_conv_variant mirrors the dispatcher)."""
     dt = {PS_BF16: "bf16", PS_F16: "f16"}.get(g.dtype, "f32")
     if kind == "wgrad":
-        return f"conv_wgrad_ws2_kernel<{dt}>" if int(_lib.load().ps_conv_wgrad_variant(C.byref(g))) == 1 else f"conv_wgrad_kernel<{dt}>"
+        v = int(_lib.load().ps_conv_wgrad_variant(C.byref(g)))
+        return f"{ {2: 'conv_wgrad256_kernel', 1: 'conv_wgrad_ws2_kernel'}.get(v, 'conv_wgrad_kernel') }<{dt}>"
     v = int(_lib.load().ps_conv_variant(C.byref(g), 1 if kind == "dgrad" else 0))
     return f"{_VARIANT_NAMES.get(v, 'conv_igemm_kernel')}<{dt}>"
 

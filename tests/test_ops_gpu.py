@@ -579,6 +579,7 @@ def _halo_case(case, dtype, ring):
     # (n, h, w, cin, cout, k, s, d): ragged pixel counts (zero-filled K tail), 1 .. several work items per persistent block
     (2, 13, 10, 128, 256, 3, 2, 1), (2, 13, 10, 256, 256, 3, 1, 1), (3, 9, 11, 256, 512, 1, 2, 1), (2, 13, 10, 512, 1024, 3, 1, 2),
     (4, 14, 14, 1024, 2048, 3, 1, 4), (16, 28, 28, 512, 512, 3, 1, 1), (8, 28, 28, 2048, 4096, 1, 1, 1),
+    (1, 7, 9, 256, 256, 3, 1, 2), (3, 28, 28, 256, 512, 1, 1, 1), (5, 12, 28, 512, 256, 3, 1, 4),  # 1 / 37 / 27 K-steps (odd counts, one step)
 ])
 def test_wgrad_large_tile_persistent_kernel(case, dtype, library):
     """conv_wgrad_ws2_kernel (256x128 tile, persistent, 3-stage ring) against the CPU autograd weight gradient on identically rounded
@@ -589,7 +590,7 @@ def test_wgrad_large_tile_persistent_kernel(case, dtype, library):
     lib = _lib.load()
     n, h, w, cin, cout, k, s, d = case
     spec = ops.ConvSpec(cin, cout, k, s, d)
-    if library == "product" and conv_variant(spec, dtype, n, h, w, "wgrad") != 1:
+    if library == "product" and conv_variant(spec, dtype, n, h, w, "wgrad") not in (1, 2):
         pytest.skip("the product library serves this small problem with the 128x128 kernel (covered by test_conv_fwd_dgrad_wgrad)")
     g = torch.Generator().manual_seed(cin + cout + k)
     q = quant(dtype)
@@ -601,21 +602,34 @@ def test_wgrad_large_tile_persistent_kernel(case, dtype, library):
     D = dev()
     xd, gyd = nhwc(x).to(D, dtype), nhwc(gy).to(D, dtype)
     old = None
-    try:
-        if library == "debug":
-            lib.ps_debug_set_wgrad_ws2(2)
-        got = []
-        for _ in range(3):  # race screen: repeated launches agree up to f32 atomic ordering
+    got = []
+
+    def launches(k_):  # race screen: repeated launches agree up to f32 atomic ordering
+        for _ in range(k_):
             dw = torch.zeros((cout, k, k, cin), device=D, dtype=torch.float32)
             ops.conv2d_wgrad(spec, xd, gyd, dw)
             got.append(dw)
+
+    try:
         if library == "debug":
+            lib.ps_debug_set_wgrad256(0)
+            lib.ps_debug_set_wgrad_ws2(2)   # conv_wgrad_ws2_kernel forced
+            assert conv_variant(spec, dtype, n, h, w, "wgrad") == 1
+            launches(3)
+            if s == 1 and cin % 256 == 0:
+                lib.ps_debug_set_wgrad256(2)  # conv_wgrad256_kernel forced (stride 1, 256-channel tiles both ways)
+                assert conv_variant(spec, dtype, n, h, w, "wgrad") == 2
+                launches(3)
+            lib.ps_debug_set_wgrad256(0)
             lib.ps_debug_set_wgrad_ws2(0)
             old = torch.zeros((cout, k, k, cin), device=D, dtype=torch.float32)
             ops.conv2d_wgrad(spec, xd, gyd, old)
+        else:
+            launches(3)
     finally:
         if library == "debug":
             lib.ps_debug_set_wgrad_ws2(1)
+            lib.ps_debug_set_wgrad256(1)
     ref = w_fwd_layout(wt.grad)
     for dw in got:
         assert rel_err(dw.cpu(), ref) < 1e-4   # exact products, f32 accumulation
@@ -696,7 +710,7 @@ def test_persistent_kernels_selected_by_geometry_match_cpu(case, family, dtype, 
     spec = ops.ConvSpec(cin, cout, k, s_, d)
     want = {"halo": (V_HALO,), "ws2": (V_WS2_256, V_WS2_224), "gemm256": (V_GEMM256,)}[family]
     assert conv_variant(spec, dtype, n, h, w, "fwd") in want
-    wg_ws2 = conv_variant(spec, dtype, n, h, w, "wgrad") == 1
+    wg_ws2 = conv_variant(spec, dtype, n, h, w, "wgrad") in (1, 2)
     assert wg_ws2 or cout % 256 or cin % 128  # every eligible shape here is big enough for the persistent weight-gradient kernel
     g = torch.Generator().manual_seed(sum(case))
     q = quant(dtype)
@@ -766,7 +780,7 @@ def test_full_size_layers_kernel_families_agree(case, library):
     want = (V_HALO,) if k == 3 else (V_GEMM256,)
     for kind in ("fwd", "dgrad"):
         assert conv_variant(spec, dtype, n, hw, hw, kind) in want, kind
-    assert conv_variant(spec, dtype, n, hw, hw, "wgrad") == 1
+    assert conv_variant(spec, dtype, n, hw, hw, "wgrad") == 2  # the 256 x 256 tile kernel (every case here has cin, cout % 256 == 0)
     y, (gx, dw) = run(x), run_bwd()
     if library == "debug":
         try:
@@ -836,7 +850,7 @@ def test_persistent_kernels_batched_work_split_is_exact(tpb, library):
 
         # every launch here is served by a persistent kernel by the geometry alone (no switch needed in either library)
         assert conv_variant(spec, dtype, n, h, w, "fwd") in (V_HALO, V_WS2_224, V_WS2_256)
-        assert conv_variant(spec, dtype, n, h, w, "wgrad") == 1
+        assert conv_variant(spec, dtype, n, h, w, "wgrad") in (1, 2)
         try:
             ops.TILES_PER_BLOCK = 0
             ref = run()
