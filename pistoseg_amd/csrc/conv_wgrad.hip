@@ -667,18 +667,27 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
   auto stage_x = [&](int buf, int h, int ks) {
     unsigned char* dst = smem + buf * BUF + IMG + ((grp + 2 * h) * 8 + 2 * wc) * 1024;
     const int xso = (ks * KP + 32 * h + dy_off * a.W + dx_off) * (int)a.x_pix_bytes + xpad;
+    bool ok[2] = {true, true};
+    if constexpr (XM == 1) {  // ONE division pair per call: the second piece's rows are two pixels further along the image row
+      const uint32_t m = (uint32_t)(ks * KP + 32 * h + R0);
+      const uint32_t n = fdiv(m, a.div_hw);
+      const uint32_t rem = m - n * a.div_hw.d;
+      const uint32_t pp = fdiv(rem, a.div_w);
+      int y = (int)pp + dy_off, xx = (int)(rem - pp * a.div_w.d) + dx_off;
+      ok[0] = (unsigned)y < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;  // (past the last image: outside the descriptor)
+      xx += 2;
+      const bool wrap = xx >= a.W + dx_off;  // the unshifted column left the row: first columns of the next row (of the next image: row 0)
+      xx -= wrap ? a.W : 0;
+      y += wrap ? 1 : 0;
+      y -= (y >= a.H + dy_off) ? a.H : 0;
+      ok[1] = (unsigned)y < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+    }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       if constexpr (XM == 2) {
         BLDS16(rsX, dst + p * 1024, xoff[p], xso);  // (rows past the last pixel: outside the descriptor -> zeros)
       } else {
-        const uint32_t m = (uint32_t)(ks * KP + 32 * h + R0 + 2 * p);
-        const uint32_t n = fdiv(m, a.div_hw);
-        const uint32_t rem = m - n * a.div_hw.d;
-        const uint32_t pp = fdiv(rem, a.div_w);
-        const int y = (int)pp + dy_off, xx = (int)(rem - pp * a.div_w.d) + dx_off;
-        const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;  // (past the last image: outside the descriptor)
-        BLDS16(rsX, dst + p * 1024, ok ? xoff[p] : PAD_ROW, xso);
+        BLDS16(rsX, dst + p * 1024, ok[p] ? xoff[p] : PAD_ROW, xso);
       }
     }
   };
@@ -696,33 +705,51 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
   bf16x8 af[4][2];      // A0 or A1: 4 cout fragments x 2 K-halves
   bf16x8 bf0[2][2][2];  // B0 (cin fragments 0, 1) of the current and of the next K-step: [set][fragment][K-half]
   bf16x8 bf1[2][2];     // B1 (cin fragments 2, 3)
-  auto tr_read = [&](const unsigned char* ptr) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ptr));
+  // The transposed reads are INLINE ASM on purpose: through the builtin, hipcc cannot tell them from the LDS-DMA destinations of this
+  // same wave and puts `s_waitcnt vmcnt(0)` in front of the first read after every barrier -- draining the two K-steps of prefetch
+  // this schedule keeps in flight (measured r03: 937-1025 TFLOP/s with the builtin).  Ordering is this kernel's own: every load
+  // phase ends with lgkmcnt(0) before its barrier (end_load), and no MFMA is scheduled above that point (sched_barrier).
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  // fragment i of A / j of B: lane address = base + ((i ^ s) << 5), rebuilt per fragment (one xor + one add per four reads) instead of
+  // living in 12 registers -- the kernel sits at the 256-VGPR limit
+  const unsigned a_lane = lds0 + (unsigned)a_base, b_lane = lds0 + (unsigned)b_base;
+  const unsigned a_sw = (unsigned)s3 << 5, b_sw = (unsigned)(s3 & 3) << 5;
+#define PS_TR_READ(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+  auto read_a = [&](auto bufc, int sub) {
+    constexpr int BO = decltype(bufc)::value * BUF;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16x4 t[4];
+      const unsigned ad = a_lane + (a_sw ^ (unsigned)((4 * sub + j) << 5)) + BO;  // (the 16-bit offset field cannot hold the second buffer's 64 KiB)
+      PS_TR_READ(t[0], ad, 0 * RB);
+      PS_TR_READ(t[1], ad, 4 * RB);
+      PS_TR_READ(t[2], ad, 32 * RB);
+      PS_TR_READ(t[3], ad, 36 * RB);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        af[j][0][e] = t[0][e]; af[j][0][4 + e] = t[1][e];
+        af[j][1][e] = t[2][e]; af[j][1][4 + e] = t[3][e];
+      }
+    }
   };
-  auto read_a = [&](const unsigned char* cb, int sub) {
+  auto read_b = [&](auto bufc, int sub, bf16x8 (&b)[2][2]) {
+    constexpr int BO = decltype(bufc)::value * BUF;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 2; ++j) {
+      bf16x4 t[4];
+      const unsigned ad = b_lane + (b_sw ^ (unsigned)((2 * sub + j) << 5)) + BO;
+      PS_TR_READ(t[0], ad, 0 * RB);
+      PS_TR_READ(t[1], ad, 4 * RB);
+      PS_TR_READ(t[2], ad, 32 * RB);
+      PS_TR_READ(t[3], ad, 36 * RB);
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const bf16x4 t = tr_read(cb + a_base + (kk * 32 + 4 * h) * RB + (((4 * sub + j) ^ s3) << 5));
-#pragma unroll
-          for (int e = 0; e < 4; ++e) af[j][kk][4 * h + e] = t[e];
-        }
+      for (int e = 0; e < 4; ++e) {
+        b[j][0][e] = t[0][e]; b[j][0][4 + e] = t[1][e];
+        b[j][1][e] = t[2][e]; b[j][1][4 + e] = t[3][e];
+      }
+    }
   };
-  auto read_b = [&](const unsigned char* cb, int sub, bf16x8 (&b)[2][2]) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const bf16x4 t = tr_read(cb + b_base + (kk * 32 + 4 * h) * RB + (((2 * sub + j) ^ (s3 & 3)) << 5));
-#pragma unroll
-          for (int e = 0; e < 4; ++e) b[j][kk][4 * h + e] = t[e];
-        }
-  };
+#undef PS_TR_READ
   auto mfma1 = [&](f32x4& c, const bf16x8& x, const bf16x8& y) {
     if constexpr (F16) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
     else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
@@ -760,12 +787,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  read_b(smem, 0, bf0[0]);
+  read_b(std::integral_constant<int, 0>{}, 0, bf0[0]);
   if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger: G1 runs one barrier behind G0
 
   auto kstep = [&](auto parity, int t) {
     constexpr int P = decltype(parity)::value;
-    const unsigned char* cb = smem + P * BUF;
+    constexpr std::integral_constant<int, P> cb{};
+    constexpr std::integral_constant<int, P ^ 1> nb{};
     const bool s1 = t + 1 < NT, s2 = t + 2 < NT;
     read_a(cb, 0);
     if (s1) stage_g(P ^ 1, 0, ks0 + t + 1);
@@ -782,7 +810,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
     end_load(s2);
     mma_quadrant(1, 1, bf1);
     end_compute();
-    if (s1) read_b(smem + (P ^ 1) * BUF, 0, bf0[P ^ 1]);
+    if (s1) read_b(nb, 0, bf0[P ^ 1]);
     if (s2) stage_x(P, 1, ks0 + t + 2);
     end_load(s2);
     mma_quadrant(1, 0, bf0[P]);
@@ -961,8 +989,8 @@ int launch_wgrad256(WgradArgs a, hipStream_t s) {
   return PS_OK;
 }
 
-static bool use_wgrad256(int esize, long long M, int cout, int cin, int taps, int tpb, int stride) {
-  if (!g_wgrad256 || esize != 2 || cout % 256 != 0 || cin % 256 != 0 || tpb != 0 || stride != 1) return false;
+static bool use_wgrad256(int esize, long long M, int cout, int cin, int taps, int tpb, int stride, int W) {
+  if (!g_wgrad256 || esize != 2 || cout % 256 != 0 || cin % 256 != 0 || tpb != 0 || stride != 1 || W < 2) return false;
   return g_wgrad256 > 1 || M * cout * cin * taps >= (1LL << 31);
 }
 
@@ -973,7 +1001,7 @@ static bool use_wgrad_ws2(int esize, long long M, int cout, int cin, int taps) {
 template <typename Tr, bool DET = false>
 int dispatch_wgrad(const WgradArgs& a, hipStream_t s) {
   if constexpr (Tr::ES == 2) {
-    if (use_wgrad256(Tr::ES, a.M, a.cout, a.cin, a.taps, a.tpb, a.stride)) return launch_wgrad256<Tr, DET>(a, s);
+    if (use_wgrad256(Tr::ES, a.M, a.cout, a.cin, a.taps, a.tpb, a.stride, a.W)) return launch_wgrad256<Tr, DET>(a, s);
     if (use_wgrad_ws2(Tr::ES, a.M, a.cout, a.cin, a.taps)) return launch_wgrad_ws2<Tr, DET>(a, s);
   }
   const bool co128 = a.cout % 128 == 0, ci128 = a.cin % 128 == 0;
@@ -986,7 +1014,7 @@ int dispatch_wgrad(const WgradArgs& a, hipStream_t s) {
 // Pixel ranges (split-K parts) the dispatcher will cut this problem into: the same plan functions the launchers use.
 template <typename Tr>
 long long wgrad_live_ranges(WgradArgs a) {
-  if (use_wgrad256(Tr::ES, a.M, a.cout, a.cin, a.taps, a.tpb, a.stride)) return plan_wgrad256(a);
+  if (use_wgrad256(Tr::ES, a.M, a.cout, a.cin, a.taps, a.tpb, a.stride, a.W)) return plan_wgrad256(a);
   if (use_wgrad_ws2(Tr::ES, a.M, a.cout, a.cin, a.taps)) return plan_wgrad_ws2(a);
   const bool co128 = a.cout % 128 == 0, ci128 = a.cin % 128 == 0;
   if (co128 && ci128) return plan_wgrad<Tr, 128, 128>(a);
@@ -1042,7 +1070,7 @@ extern "C" void ps_debug_set_wgrad_raster(int v) { g_wgrad_raster = v; }
 extern "C" int ps_conv_wgrad_variant(const ps_conv_geom* g) {
   if (!g || !ps_conv_supported(g)) return -1;
   const long long ho = (g->h - 1) / g->stride + 1, wo = (g->w - 1) / g->stride + 1;
-  if (use_wgrad256(ps_esize(g->dtype), (long long)g->n * ho * wo, g->cout, g->cin, g->ksize * g->ksize, g->tiles_per_block, g->stride)) return 2;
+  if (use_wgrad256(ps_esize(g->dtype), (long long)g->n * ho * wo, g->cout, g->cin, g->ksize * g->ksize, g->tiles_per_block, g->stride, g->w)) return 2;
   return use_wgrad_ws2(ps_esize(g->dtype), (long long)g->n * ho * wo, g->cout, g->cin, g->ksize * g->ksize) ? 1 : 0;
 }
 

@@ -694,8 +694,8 @@ def test_wgrad_deterministic_mode(case, dtype, library):
     ((19, 28, 28, 128, 512, 3, 1, 1), "halo"),    # 66.5 pixel tiles of 8 x 28: straddles images, ragged last tile; tail half tiles
     ((10, 56, 56, 64, 256, 3, 1, 2), "halo"),     # two column blocks per row, dilation 2
     ((17, 32, 32, 64, 512, 3, 1, 4), "halo"),     # 256-pixel tiles (the maps of 256 x 256 inputs), dilation 4
-    ((9, 28, 28, 2048, 4096, 1, 1, 1), "gemm256"),  # b7's 1x1 shape: the 256 x 256 tile GEMM kernel, 27.6 pixel tiles (ragged)
-    ((17, 28, 28, 2048, 2048, 1, 1, 1), "gemm256"), # odd image count: ragged last pixel tile (52.06 tiles of 256 pixels)
+    ((11, 28, 28, 2048, 4096, 1, 1, 1), "gemm256"), # b7's 1x1 shape: the 256 x 256 tile GEMM kernel, 33.7 pixel tiles (ragged)
+    ((21, 28, 28, 2048, 2048, 1, 1, 1), "gemm256"), # odd image count: ragged last pixel tile (64.3 tiles of 256 pixels)
     ((37, 28, 28, 512, 1024, 1, 1, 1), "ws2"),      # K = 512: below the 256 x 256 kernel's range -> ws2, ragged last pixel tile
     ((21, 56, 56, 256, 512, 3, 2, 1), "ws2"),       # stride-2 3x3 (b4's first conv)
 ])
