@@ -1367,12 +1367,17 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const IgemmArgs a)
     __builtin_amdgcn_s_setprio(0);
   };
   // end of a load phase: the pieces of the two newest load phases may stay in flight; every LDS read retired BEFORE the barrier
-  auto end_load = [&](bool staged) {
+  // End of a load phase.  The phase's LDS reads retire AFTER the barrier (lgkmcnt(0) in front of the first MFMA), so their latency
+  // overlaps the barrier -- except where the NEXT interval already re-stages what was just read: G1's B1 reads of L(q1) (interval
+  // 8t + 3) and G0's LDS-DMA of L(q2) (interval 8t + 4) into the same rows; there the reads are drained before the barrier.
+  auto end_load = [&](bool staged, bool drain_reads) {
     if (staged) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (drain_reads) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
   };
   auto end_compute = [&]() {
     __builtin_amdgcn_sched_barrier(0);
@@ -1400,25 +1405,25 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const IgemmArgs a)
     // L(q0): A0
     read_x(cb, 0);
     if (s1) stage_a(P ^ 1, 0, t + 1);
-    end_load(s1);
+    end_load(s1, false);
     mma_quadrant(0, 0, wf0[P]);
     end_compute();
     // L(q1): B1
     read_w(cb, 1, wf1);
     if (s1) stage_a(P ^ 1, 1, t + 1);
-    end_load(s1);
+    end_load(s1, grp == 1);
     mma_quadrant(0, 1, wf1);
     end_compute();
     // L(q2): A1
     read_x(cb, 1);
     if (s2) stage_b(P, 0, t + 2);
-    end_load(s2);
+    end_load(s2, false);
     mma_quadrant(1, 1, wf1);
     end_compute();
     // L(q3): B0 of the NEXT K-tile (resident since two K-tiles ago)
     if (s1) read_w(smem + (P ^ 1) * BUF, 0, wf0[P ^ 1]);
     if (s2) stage_b(P, 1, t + 2);
-    end_load(s2);
+    end_load(s2, false);
     mma_quadrant(1, 0, wf0[P]);
     end_compute();
   };

@@ -764,12 +764,17 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
         for (int i = 0; i < 2; ++i) mfma1(acc[4 * msub + j][2 * nsub + i], af[j][kk], b[i][kk]);
     __builtin_amdgcn_s_setprio(0);
   };
-  auto end_load = [&](bool staged) {
+  // End of a load phase.  The phase's LDS reads retire AFTER the barrier (lgkmcnt(0) in front of the first MFMA), so their latency
+  // overlaps the barrier -- except where the NEXT interval already re-stages what was just read: G1's B1 reads of L(q1) (interval
+  // 8t + 3) and G0's LDS-DMA of L(q2) (interval 8t + 4) into the same rows; there the reads are drained before the barrier.
+  auto end_load = [&](bool staged, bool drain_reads) {
     if (staged) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (drain_reads) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
   };
   auto end_compute = [&]() {
     __builtin_amdgcn_sched_barrier(0);
@@ -797,22 +802,22 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
     const bool s1 = t + 1 < NT, s2 = t + 2 < NT;
     read_a(cb, 0);
     if (s1) stage_g(P ^ 1, 0, ks0 + t + 1);
-    end_load(s1);
+    end_load(s1, false);
     mma_quadrant(0, 0, bf0[P]);
     end_compute();
     read_b(cb, 1, bf1);
     if (s1) stage_g(P ^ 1, 1, ks0 + t + 1);
-    end_load(s1);
+    end_load(s1, grp == 1);
     mma_quadrant(0, 1, bf1);
     end_compute();
     read_a(cb, 1);
     if (s2) stage_x(P, 0, ks0 + t + 2);
-    end_load(s2);
+    end_load(s2, false);
     mma_quadrant(1, 1, bf1);
     end_compute();
     if (s1) read_b(nb, 0, bf0[P ^ 1]);
     if (s2) stage_x(P, 1, ks0 + t + 2);
-    end_load(s2);
+    end_load(s2, false);
     mma_quadrant(1, 0, bf0[P]);
     end_compute();
   };
