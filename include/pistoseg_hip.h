@@ -103,8 +103,8 @@ enum {
   PS_CONV_HALO = 7      /* conv_igemm_halo_kernel: 3x3 stride-1, width % 28 == 0 (224x128 tile of 8 rows x 28 columns) or % 32 == 0 (256x128, 8 x 32), pixel window + halo staged once per tap row */
 };
 int ps_conv_variant(const ps_conv_geom* g, int32_t dgrad);
-/* 2 if ps_conv2d_wgrad will launch conv_wgrad256_kernel (256x256 tile, eight MFMA waves), 1 for conv_wgrad_ws2_kernel (256x128 tile,
- * persistent, wave-specialised), 0 for conv_wgrad_kernel, -1 unsupported. */
+/* 1 if ps_conv2d_wgrad will launch conv_wgrad_ws2_kernel (256x128 tile, persistent, wave-specialised), 0 for conv_wgrad_kernel, -1 unsupported
+ * (2: conv_wgrad256_kernel, an experiment that only the debug library can select). */
 int ps_conv_wgrad_variant(const ps_conv_geom* g);
 
 /* y = conv(x, W_fwd) with epilogue.  x: [n,h,w,cin]; produces [n,ho,wo,cout], ho = (h-1)/stride+1. */

@@ -52,7 +52,8 @@ void ps_debug_set_s2split(int v);  /* stride-2 3x3 data gradient as four parity-
 void ps_debug_set_wgrad_ws(int v);
 /* Testing hook: large-tile persistent weight-gradient kernel (256x128 tile, one block per CU): 0 off, 1 (default) for big 16-bit problems, 2 forced. */
 void ps_debug_set_wgrad_ws2(int v);
-/* Testing hook: conv_wgrad256_kernel (256x256 tile): 0 off, 1 (default) by shape, 2 whenever legal (cout % 256 == 0, cin % 256 == 0, 16-bit). */
+/* Experiment hook: conv_wgrad256_kernel (256x256 tile; measured slower than the ws2 kernel, r03): 0 (default) off, 1 by shape, 2 whenever legal
+ * (stride 1, cout % 256 == 0, cin % 256 == 0, 16-bit). */
 void ps_debug_set_wgrad256(int v);
 /* Timing experiments only (results WRONG): 1 = the large-tile weight-gradient kernel skips its atomics, 2 = plain stores instead,
  * 3 = it stages its first three K-steps only (consumer-only rate). */

@@ -597,7 +597,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
 }
 
 // ------------------------------------------------------------------------------------------------
-// 256 cout x 256 cin tile, all eight waves MFMA waves (r03): the weight-gradient counterpart of conv_gemm256_kernel.
+// EXPERIMENT, debug library only (r03; built, parity-green, measured SLOWER than the wave-specialised kernel above and therefore not
+// selected: profiles/r03_wgrad256_vs_ws2.txt).  256 cout x 256 cin tile, all eight waves MFMA waves: the weight-gradient counterpart
+// of conv_gemm256_kernel.
 //   A SIMD's instruction issue -- MFMAs (8 cycles each), transposed LDS reads, LDS-DMA pieces (60-100 cycles each) -- is what
 //   paces the wave-specialised kernel above: per 64-pixel K-step its consumer wave issues 64 MFMAs + 48 reads and its loader
 //   partner 12 DMA pieces + the pixel tracking, ~2100 issue cycles for 1024 matrix-pipe cycles.  A 256 x 256 tile stages
@@ -856,12 +858,18 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad256_kernel(const WgradArgs a
     }
 }
 
+#ifdef PS_DEBUG_HOOKS
+constexpr bool kWgradDebugBuild = true;
+#else
+constexpr bool kWgradDebugBuild = false;
+#endif
 PS_TUNABLE g_wgrad_ws = 1;
 PS_TUNABLE g_wgrad_ablate = 0;
 PS_TUNABLE g_wgrad_ovh = 16;  // per-item overhead of the persistent kernel in K-step units (atomics + pipeline refill)
 PS_TUNABLE g_wgrad_ws2 = 1;  // large-tile persistent kernel for 16-bit operands with cout % 256 == 0, cin % 128 == 0
 
-PS_TUNABLE g_wgrad256 = 1;   // 256 x 256 tile kernel (cout % 256 == 0, cin % 256 == 0, 16-bit): 0 off, 1 by shape, 2 whenever legal
+PS_TUNABLE g_wgrad256 = 0;   // EXPERIMENT (debug library only; measured r03, profiles/r03_wgrad256_vs_ws2.txt: 3-15 % SLOWER than ws2 on every
+                              // layer but 4096->4096): 256 x 256 tile kernel (cout, cin % 256 == 0, 16-bit): 0 off, 1 by shape, 2 whenever legal
 PS_TUNABLE g_wgrad_raster = -1;  // -1: by shape (measured r01: pixel-range-slowest wins for 3x3 layers with >= 64 tiles)
 
 // Geometry-derived fields + split-K choice of conv_wgrad_kernel; returns the number of pixel ranges that get work.
@@ -985,6 +993,10 @@ static long long plan_wgrad256(WgradArgs& a) {
 
 template <typename Tr, bool DET = false>
 int launch_wgrad256(WgradArgs a, hipStream_t s) {
+#ifndef PS_DEBUG_HOOKS
+  (void)a; (void)s;
+  return PS_ERR_ARG;  // unreachable: use_wgrad256 is false in the product build
+#else
   const long long live = plan_wgrad256(a);
   const long long items = (long long)a.tiles_co * a.tiles_ci * a.taps * live;
   const size_t lds = 2 * 2 * 64 * 512;
@@ -992,9 +1004,11 @@ int launch_wgrad256(WgradArgs a, hipStream_t s) {
   else hipLaunchKernelGGL((conv_wgrad256_kernel<Tr::F16, 1, DET>), dim3((unsigned)items), dim3(512), lds, s, a);
   PS_CHECK_LAUNCH("conv_wgrad256");
   return PS_OK;
+#endif
 }
 
 static bool use_wgrad256(int esize, long long M, int cout, int cin, int taps, int tpb, int stride, int W) {
+  if (!kWgradDebugBuild) return false;  // the product library carries no kernel it cannot reach
   if (!g_wgrad256 || esize != 2 || cout % 256 != 0 || cin % 256 != 0 || tpb != 0 || stride != 1 || W < 2) return false;
   return g_wgrad256 > 1 || M * cout * cin * taps >= (1LL << 31);
 }

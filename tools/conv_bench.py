@@ -78,7 +78,7 @@ def main():
                     lib.ps_debug_set_halo_tail(1)
                     lib.ps_debug_set_ablate(0)
                     lib.ps_debug_set_wgrad_ws2(1)
-                    lib.ps_debug_set_wgrad256(1)
+                    lib.ps_debug_set_wgrad256(0)
                     lib.ps_debug_set_wgrad_ablate(0)
                     lib.ps_debug_set_wgrad_ovh(16)
                     lib.ps_debug_set_supertile(4)
