@@ -332,11 +332,18 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
   const int live = (a.ksteps + per - 1) / per;                    // ranges that get work
   int first, G, nitems;  // this block's items: first, first + G, ... < nitems
   ps_block_items(blockIdx.x, gridDim.x, a.tiles_co * a.tiles_ci * a.taps * live, a.nb, a.tpb, first, G, nitems);
-  // item -> (ci tile, co tile, tap, pixel range), pixel range slowest (co-running blocks share their dY / X chunks in L2)
+  // item -> (ci tile, co tile, tap, pixel range), pixel range slowest (co-running blocks share their dY / X chunks in L2).  Inside a
+  // range the order is [cig cin tiles][taps][cog cout tiles][other cin groups][other cout groups] (plan_wgrad_ws2): the ~32 consecutive
+  // items that run together on one XCD then need few DISTINCT dY / X rows per K-step -- the taps of a (cin, cout) tile pair read the same dY
+  // rows, and X rows that coincide up to a skew of a few K-steps (r03: L2-miss traffic of the 3x3 layers, profiles/r03_pmc_hbm_traffic.json).
+  // One branch-free formula for every layer (a run-time SWITCH between orders made hipcc triplicate the loaders' issue code: -12 %).
   auto decode = [&](int item, int& tci, int& tco, int& tap, int& ks0, int& ks1) {
-    tci = item % a.tiles_ci; item /= a.tiles_ci;
-    tco = item % a.tiles_co; item /= a.tiles_co;
+    const int t_lo = item % a.cig; item /= a.cig;
     tap = item % a.taps; item /= a.taps;
+    const int u_lo = item % a.cog; item /= a.cog;
+    const int nci = a.tiles_ci / a.cig, nco = a.tiles_co / a.cog;
+    tci = (item % nci) * a.cig + t_lo; item /= nci;
+    tco = (item % nco) * a.cog + u_lo; item /= nco;
     ks0 = item * per;
     ks1 = min(a.ksteps, ks0 + per);
   };
@@ -939,6 +946,11 @@ static long long plan_wgrad_ws2(WgradArgs& a) {
   }
   a.splits = (int)splits;
   a.nb = ncu;
+  // item order inside a pixel range (see the kernel's decode): an item stages 16 KiB of X (128 cins) and 32 KiB of dY (256 couts) per K-step;
+  // 3x3: 4 cin tiles x 9 taps of ONE cout tile = 36 items sharing 64 + 32 KiB; 1x1: 8 cin x 4 cout tiles = 128 + 128 KiB
+  auto pow2_div = [](int n, int cap) { int g = 1; while (g * 2 <= cap && n % (g * 2) == 0) g *= 2; return g; };
+  a.cig = pow2_div(a.tiles_ci, a.taps == 9 ? 4 : 8);
+  a.cog = pow2_div(a.tiles_co, std::max(1, 32 / (a.cig * a.taps)));
   const long long per = (a.ksteps + splits - 1) / splits;
   return (a.ksteps + per - 1) / per;
 }
