@@ -1698,15 +1698,53 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
 #endif
   for (int tile = first; tile < ntiles; tile += G) {
     f32x4 acc[MI][WI];
+#ifndef PS_HALO_MFMA32_TIMING
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int i = 0; i < WI; ++i) acc[mi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
     u32x4 wf0[WI], xf0[MI], wf1[WI], xf1[MI];
+#ifdef PS_HALO_MFMA32_TIMING
+    // A/B TIMING build (results WRONG): the same reads, loaders, barriers and accumulator registers, but every PAIR of 16x16x32 MFMAs is
+    // replaced by ONE v_mfma_f32_32x32x16 (same FLOPs, half the MFMA instructions, 32-cycle issue gaps that hide the ds_read_b128
+    // issue): what the consumer loop would gain from the 32x32 shape before anyone rewrites the fragment layout and the epilogue
+    // (tools/mfma_shape_probe.hip: +25 % for a lone MFMA wave per SIMD; profiles/r03_mfma_shape_probe.txt).
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 acc16[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc16[mi][e] = 0.f;
+#endif
     // One K-half: the NR = WI + MI fragment reads interleaved with the MFMAs whose operands are already in registers
     // (see conv_igemm_ws2_kernel); a pixel fragment address = centre address + scalar (window buffer, tap column) [^ K-half].
     auto half = [&](const unsigned char* wst, int wcoff, int soff, int flip, u32x4 (&wfn)[WI], u32x4 (&xfn)[MI], const u32x4 (&wfo)[WI],
                     const u32x4 (&xfo)[MI], bool do_mma) {
+#ifdef PS_HALO_MFMA32_TIMING
+      constexpr int NR = WI + MI, NM = MI * WI / 2, PER = 1;
+      auto mma32 = [&](int q) {
+        acc16[q % MI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfo[(q / MI) % WI]), __builtin_bit_cast(bf16x8, xfo[q % MI]),
+                                                                acc16[q % MI], 0, 0, 0);
+      };
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        if (r < WI) wfn[r] = *reinterpret_cast<const u32x4*>(wst + r * 2048 + wcoff);
+        else xfn[r - WI] = *reinterpret_cast<const u32x4*>(smem + ((xa[r - WI] ^ flip) + soff));
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_mma) {
+          if (r < NM) mma32(r);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (do_mma) {
+#pragma unroll
+        for (int q = NR; q < NM; ++q) mma32(q);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      (void)PER;
+      return;
+#else
       constexpr int NR = WI + MI, NM = MI * WI, PER = PS_READ_PER;
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
@@ -1729,6 +1767,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
         for (int q = NR * PER; q < NM; ++q) Tr::mma(wfo[q % WI], xfo[q / WI], acc[q / WI][q % WI]);
       }
       __builtin_amdgcn_sched_barrier(0);
+#endif
     };
     auto kstep = [&](int tx, bool first_of_tile) {
       const unsigned char* wst = smem + cur * B_BYTES + wfrag;
@@ -1766,10 +1805,19 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
       if (++tx == 3) { tx = 0; wbuf ^= 1; }
     }
     // (after the last step tx wrapped to 0 and wbuf moved on to the next tile's first window)
+#ifndef PS_HALO_MFMA32_TIMING
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int i = 0; i < WI; ++i) Tr::mma(wf1[i], xf1[mi], acc[mi][i]);
+#else
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int i = 0; i < WI; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mi][i][r] = acc16[mi][(4 * i + r) & 15] + __uint_as_float(wf1[i][r] & 0xffu) + __uint_as_float(xf1[mi][r] & 0xffu);
+#endif
     int tm, tn;
     ps_tile_of_block(tile, a.ntn, a.ntm, tm, tn, a.supertile);
       tm += a.tm0;
