@@ -33,4 +33,6 @@ python tools/pmc_mfma_report.py gpurun_out/pmc_${tag}_c5_mfma_1 > gpurun_out/${t
 python bench.py --workload rfm --batch 32 --steps 8 --warmup 3 > gpurun_out/${tag}_bench_cfg4_rfm_bs32.json 2>> gpurun_out/${tag}_bench_profiled.err &&
 python bench.py --workload infer2 --steps 20 > gpurun_out/${tag}_bench_cfg3_infer2.json 2>> gpurun_out/${tag}_bench_profiled.err &&
 python bench.py --workload infer2 --steps 20 --tta > gpurun_out/${tag}_bench_cfg3_infer2_tta.json 2>> gpurun_out/${tag}_bench_profiled.err &&
-python bench.py --tile 256 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_tile256.json 2>> gpurun_out/${tag}_bench_profiled.err
+python bench.py --tile 256 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_tile256.json 2>> gpurun_out/${tag}_bench_profiled.err &&
+python bench.py --workload infer4 --tile 256 --steps 20 > gpurun_out/${tag}_bench_stage4_infer4_tile256.json 2>> gpurun_out/${tag}_bench_profiled.err &&
+python bench.py --deterministic --no-cpu-baseline > gpurun_out/${tag}_bench_deterministic.json 2>> gpurun_out/${tag}_bench_profiled.err
