@@ -1356,15 +1356,20 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const IgemmArgs a)
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) w[i][kh] = *reinterpret_cast<const u32x4*>(cb + wbase + (2 * sub + i) * 2048 + coff[kh]);
   };
+#ifndef PS_GEMM256_PRIO
+#define PS_GEMM256_PRIO 1  // A/B builds: 0 = no priority change, 1 = the MFMA phase at priority 1 (default), 2 = the LOAD phase at priority 1
+#endif
   auto mma_quadrant = [&](int msub, int nsub, const u32x4 (&w)[2][2]) {  // 16 MFMAs; the same accumulator recurs every 8th
-    __builtin_amdgcn_s_setprio(1);
+    if constexpr (PS_GEMM256_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+    if constexpr (PS_GEMM256_PRIO == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 2; ++i) Tr::mma(w[i][kh], xf[j][kh], acc[4 * msub + j][2 * nsub + i]);
-    __builtin_amdgcn_s_setprio(0);
+    if constexpr (PS_GEMM256_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+    if constexpr (PS_GEMM256_PRIO == 2) __builtin_amdgcn_s_setprio(1);
   };
   // end of a load phase: the pieces of the two newest load phases may stay in flight; every LDS read retired BEFORE the barrier
   // End of a load phase.  The phase's LDS reads retire AFTER the barrier (lgkmcnt(0) in front of the first MFMA), so their latency
