@@ -273,6 +273,14 @@ int ps_ecr_tensor(const float* ref, const float* rv, const float* label, float* 
  * (thr/take from it; tie_counter: zeroed int32[n] scratch). */
 int ps_ecr_bwd(const float* ref, const float* rv, const float* label, const float* t, const float* thr, const int32_t* take,
                int32_t* tie_counter, float* drv, float grad_scale, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
+/* The same with a DETERMINISTIC choice among the elements exactly equal to the threshold: the first take[n] of them in a fixed order
+ * (pixel segments, 256-pixel chunks, channel, lane) instead of first come, first served -- torch.use_deterministic_algorithms(True) of
+ * revise_pseudo_labels.py:140-146.  seg_counts: int32 scratch of >= ps_tie_workspace_ints(n, h, w) entries (contents need not be
+ * initialised). */
+int64_t ps_tie_workspace_ints(int32_t n, int32_t h, int32_t w);
+int ps_ecr_bwd_det(const float* ref, const float* rv, const float* label, const float* t, const float* thr, const int32_t* take,
+                   int32_t* seg_counts, int64_t seg_counts_ints, float* drv, float grad_scale, int32_t n, int32_t c, int32_t h, int32_t w,
+                   void* stream);
 /* Per-row top-k by radix select (k largest if largest != 0 else k smallest).  replaces: torch.topk(...)[0] followed by
  * mean/sum (revise_pseudo_labels.py:120-122,277-278).  thr[row] = k-th value, take[row] = number of elements equal to thr
  * that belong to the selection, sums[row] = sum of the selected values (of relu(values) if relu != 0). */
@@ -300,6 +308,9 @@ int ps_chmax(const float* x, const float* label, float* m, uint8_t* arg, int32_t
 /* dx[n,arg,p] += grad_scale*label[n,arg] for the k smallest m (per ps_topk_select) that are > 0. */
 int ps_minpool_bwd(const float* m, const uint8_t* arg, const float* label, const float* thr, const int32_t* take, int32_t* tie_counter,
                    float* dx, float grad_scale, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
+/* Deterministic tie choice, as ps_ecr_bwd_det. */
+int ps_minpool_bwd_det(const float* m, const uint8_t* arg, const float* label, const float* thr, const int32_t* take, int32_t* seg_counts,
+                       int64_t seg_counts_ints, float* dx, float grad_scale, int32_t n, int32_t c, int32_t h, int32_t w, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimisers over a flat f32 arena.  replaces: torch.optim.AdamW (models/segmentation_module.py:86-90)

@@ -125,6 +125,8 @@ PROTOTYPES = {
     "ps_l1_masked": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _I, _P, _P]),
     "ps_ecr_tensor": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ps_ecr_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P]),
+    "ps_tie_workspace_ints": (C.c_int64, [_I, _I, _I]),
+    "ps_ecr_bwd_det": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _L, _P, _F, _I, _I, _I, _I, _P]),
     "ps_topk_select": (C.c_int, [_P, _I, _L, _I, _I, _I, _P, _P, _P, _P]),
     "ps_topk_select_workspace_bytes": (C.c_int64, [_I]),
     "ps_topk_select_ws": (C.c_int, [_P, _I, _L, _I, _I, _I, _P, _P, _P, _P, C.c_int64, _P]),
@@ -134,6 +136,7 @@ PROTOTYPES = {
     "ps_gap_bwd": (C.c_int, [_P, _P, _I, _L, _P]),
     "ps_chmax": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ps_minpool_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P]),
+    "ps_minpool_bwd_det": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _P, _F, _I, _I, _I, _I, _P]),
 }
 
 # symbols of include/pistoseg_hip_debug.h: exported by libpistoseg_hip_debug.so only (-DPS_DEBUG_HOOKS), never by the product library

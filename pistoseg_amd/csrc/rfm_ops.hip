@@ -833,6 +833,116 @@ __global__ __launch_bounds__(256) void minpool_bwd_kernel(const float* __restric
   }
 }
 
+// ---- deterministic choice among the elements EQUAL to a top-k threshold: the first take[img] of them in a fixed order ----------
+// (tie_ticket above is first come, first served: which tied elements carry the gradient then depends on wave timing.  The reference asks
+// for deterministic algorithms in stage 3, revise_pseudo_labels.py:140-146.)  An image's pixels are cut into `nseg` segments of `seg` pixels;
+// pass 1 counts the ties per segment, pass 2 gives every tied element the rank (ties in earlier segments) + (ties before it inside the
+// segment, in the order the block walks it: 256-pixel chunks, channel by channel, lane order) and selects ranks < take[img].
+// MODE 0: adaptive-min-pool map m[n][hw] (tie: v > 0 && v == thr);  MODE 1: ECR tensor t[n][c][hw] (tie: v == thr).
+template <int MODE>
+__global__ __launch_bounds__(256) void tie_count_kernel(const float* __restrict__ v, const float* __restrict__ thr, int* __restrict__ counts, int c,
+                                                        long long hw, int seg, int nseg) {
+  const int img = blockIdx.x / nseg, sg = blockIdx.x - img * nseg;
+  const long long p0 = (long long)sg * seg, p1 = min(hw, p0 + seg);
+  const float th = thr[img];
+  int cnt = 0;
+  for (long long pix = p0 + threadIdx.x; pix < p1; pix += 256) {
+    if constexpr (MODE == 0) {
+      const float x = v[img * hw + pix];
+      cnt += (x > 0.f && x == th) ? 1 : 0;
+    } else {
+      for (int k = 0; k < c; ++k) cnt += (v[(img * c + k) * hw + pix] == th) ? 1 : 0;
+    }
+  }
+  __shared__ int red[4];
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// Block-wide exclusive prefix of a per-thread flag (thread order) and the block total; `scratch` = 4 ints of LDS; two barriers.
+__device__ __forceinline__ int block_prefix_flag(bool flag, int* scratch, int& total) {
+  const unsigned long long m = __ballot(flag);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) scratch[wv] = __popcll(m);
+  __syncthreads();
+  int before = 0;
+  for (int w = 0; w < wv; ++w) before += scratch[w];
+  total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+  __syncthreads();
+  return before + __popcll(m & ((1ull << lane) - 1ull));
+}
+__global__ __launch_bounds__(256) void minpool_bwd_det_kernel(const float* __restrict__ m, const uint8_t* __restrict__ arg, const float* __restrict__ label,
+                                                              const float* __restrict__ thr, const int* __restrict__ take, const int* __restrict__ counts,
+                                                              float* __restrict__ dx, int c, long long hw, int seg, int nseg, float gscale) {
+  __shared__ int scratch[4];
+  const int img = blockIdx.x / nseg, sg = blockIdx.x - img * nseg;
+  const long long p0 = (long long)sg * seg, p1 = min(hw, p0 + seg);
+  int running = 0;
+  for (int s0 = 0; s0 < sg; ++s0) running += counts[img * nseg + s0];
+  const float th = thr[img];
+  const int quota = take[img];
+  for (long long base = p0; base < p1; base += 256) {
+    const long long pix = base + threadIdx.x;
+    const bool in = pix < p1;
+    const float v = in ? m[img * hw + pix] : 0.f;
+    const bool tie = in && v > 0.f && v == th;
+    int total;
+    const int rank = running + block_prefix_flag(tie, scratch, total);
+    running += total;
+    const bool sel = in && ((v > 0.f && v < th) || (tie && rank < quota));
+    if (sel) {
+      const int k = arg[img * hw + pix];
+      dx[(img * c + k) * hw + pix] += gscale * label[img * c + k];
+    }
+  }
+}
+__global__ __launch_bounds__(256) void ecr_bwd_det_kernel(const float* __restrict__ ref, const float* __restrict__ rv, const float* __restrict__ label,
+                                                          const float* __restrict__ t, const float* __restrict__ thr, const int* __restrict__ take,
+                                                          const int* __restrict__ counts, float* __restrict__ drv, int c, long long hw, int seg, int nseg,
+                                                          float gscale) {
+  __shared__ int scratch[4];
+  const int img = blockIdx.x / nseg, sg = blockIdx.x - img * nseg;
+  const long long p0 = (long long)sg * seg, p1 = min(hw, p0 + seg);
+  int running = 0;
+  for (int s0 = 0; s0 < sg; ++s0) running += counts[img * nseg + s0];
+  const float th = thr[img];
+  const int quota = take[img];
+  for (long long base = p0; base < p1; base += 256) {
+    const long long pix = base + threadIdx.x;
+    const bool in = pix < p1;
+    const float* rp = ref + (long long)img * c * hw + (in ? pix : p0);
+    float fgmax = -INFINITY;
+    for (int k = 1; k < c; ++k) fgmax = fmaxf(fgmax, rp[k * hw]);
+    for (int k = 0; k < c; ++k) {
+      const long long off = ((long long)img * c + k) * hw + (in ? pix : p0);
+      const float tv = t[off];
+      const bool tie = in && tv == th;
+      int total;
+      const int rank = running + block_prefix_flag(tie, scratch, total);
+      running += total;
+      const bool sel = in && (tv > th || (tie && rank < quota));
+      if (!sel) continue;
+      float oh = rp[k * hw];
+      if (k >= 1 && oh != fgmax) oh = 0.f;
+      const float l = label[img * c + k];
+      const float d = oh - rv[off] * l;
+      const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+      drv[off] -= sgn * l * gscale;
+    }
+  }
+}
+// segments per image: ~2048 blocks in all, at least 1024 pixels per segment
+static inline void tie_segments(int n, long long hw, int& seg, int& nseg) {
+  long long want = 2048 / (n > 0 ? n : 1);
+  if (want < 1) want = 1;
+  long long sl = (hw + want - 1) / want;
+  if (sl < 1024) sl = 1024;
+  sl = (sl + 255) / 256 * 256;
+  seg = (int)sl;
+  nseg = (int)((hw + sl - 1) / sl);
+}
+
 static inline int grid_for(long long items, int per_block, int cap = 2048) {
   long long b = (items + per_block - 1) / per_block;
   if (b < 1) b = 1;
@@ -962,6 +1072,29 @@ extern "C" int ps_ecr_bwd(const float* ref, const float* rv, const float* label,
   return PS_OK;
 }
 
+extern "C" int64_t ps_tie_workspace_ints(int32_t n, int32_t h, int32_t w) {
+  if (n <= 0 || h <= 0 || w <= 0) return 0;
+  int seg, nseg;
+  tie_segments(n, (long long)h * w, seg, nseg);
+  return (int64_t)n * nseg;
+}
+
+extern "C" int ps_ecr_bwd_det(const float* ref, const float* rv, const float* label, const float* t, const float* thr, const int32_t* take,
+                              int32_t* seg_counts, int64_t seg_counts_ints, float* drv, float grad_scale, int32_t n, int32_t c, int32_t h, int32_t w,
+                              void* stream) {
+  PS_REQUIRE(ref && rv && label && t && thr && take && seg_counts && drv && n > 0 && c > 0, "ecr_bwd_det: bad argument");
+  const long long hw = (long long)h * w;
+  int seg, nseg;
+  tie_segments(n, hw, seg, nseg);
+  PS_REQUIRE(seg_counts_ints >= (int64_t)n * nseg, "ecr_bwd_det: workspace of %lld ints, need %lld (ps_tie_workspace_ints)", (long long)seg_counts_ints,
+             (long long)n * nseg);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(tie_count_kernel<1>, dim3(n * nseg), dim3(256), 0, s, t, thr, seg_counts, c, hw, seg, nseg);
+  hipLaunchKernelGGL(ecr_bwd_det_kernel, dim3(n * nseg), dim3(256), 0, s, ref, rv, label, t, thr, take, seg_counts, drv, c, hw, seg, nseg, grad_scale);
+  PS_CHECK_LAUNCH("ecr_bwd_det");
+  return PS_OK;
+}
+
 extern "C" int ps_topk_select(const float* x, int32_t rows, int64_t row_len, int32_t k, int32_t largest, int32_t relu, float* thr, int32_t* take,
                               float* sums, void* stream) {
   PS_REQUIRE(x && thr && take && sums && rows > 0 && row_len > 0 && k >= 1 && k <= row_len, "topk_select: bad argument (k=%d, len=%lld)", k,
@@ -1045,6 +1178,21 @@ extern "C" int ps_chmax(const float* x, const float* label, float* m, uint8_t* a
   const long long hw = (long long)h * w;
   hipLaunchKernelGGL(chmax_kernel, dim3(grid_for((long long)n * hw, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, label, m, arg, n, c, hw);
   PS_CHECK_LAUNCH("chmax");
+  return PS_OK;
+}
+
+extern "C" int ps_minpool_bwd_det(const float* m, const uint8_t* arg, const float* label, const float* thr, const int32_t* take, int32_t* seg_counts,
+                                  int64_t seg_counts_ints, float* dx, float grad_scale, int32_t n, int32_t c, int32_t h, int32_t w, void* stream) {
+  PS_REQUIRE(m && arg && label && thr && take && seg_counts && dx && n > 0 && c > 0, "minpool_bwd_det: bad argument");
+  const long long hw = (long long)h * w;
+  int seg, nseg;
+  tie_segments(n, hw, seg, nseg);
+  PS_REQUIRE(seg_counts_ints >= (int64_t)n * nseg, "minpool_bwd_det: workspace of %lld ints, need %lld (ps_tie_workspace_ints)",
+             (long long)seg_counts_ints, (long long)n * nseg);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(tie_count_kernel<0>, dim3(n * nseg), dim3(256), 0, s, m, thr, seg_counts, c, hw, seg, nseg);
+  hipLaunchKernelGGL(minpool_bwd_det_kernel, dim3(n * nseg), dim3(256), 0, s, m, arg, label, thr, take, seg_counts, dx, c, hw, seg, nseg, grad_scale);
+  PS_CHECK_LAUNCH("minpool_bwd_det");
   return PS_OK;
 }
 

@@ -520,8 +520,14 @@ def ecr_tensor(ref: Tensor, rv: Tensor, label: Tensor, out: Tensor) -> None:
 
 def ecr_bwd(ref, rv, label, t, thr, take, drv, grad_scale: float) -> None:
     n, c, h, w = rv.shape
-    counter = torch.zeros(n, device=rv.device, dtype=torch.int32)
     lib = _lib.load()
+    if deterministic_enabled():  # ties at the threshold taken in index order (ps_ecr_bwd_det) instead of first come, first served
+        need = int(lib.ps_tie_workspace_ints(n, h, w))
+        counts = torch.empty(need, device=rv.device, dtype=torch.int32)
+        _lib.check(lib.ps_ecr_bwd_det(ref.data_ptr(), rv.data_ptr(), label.data_ptr(), t.data_ptr(), thr.data_ptr(), take.data_ptr(), counts.data_ptr(),
+                                      need, drv.data_ptr(), grad_scale, n, c, h, w, _stream()), "ps_ecr_bwd_det")
+        return
+    counter = torch.zeros(n, device=rv.device, dtype=torch.int32)
     _lib.check(lib.ps_ecr_bwd(ref.data_ptr(), rv.data_ptr(), label.data_ptr(), t.data_ptr(), thr.data_ptr(), take.data_ptr(), counter.data_ptr(),
                               drv.data_ptr(), grad_scale, n, c, h, w, _stream()), "ps_ecr_bwd")
 
@@ -580,8 +586,14 @@ def chmax(x: Tensor, label: Tensor):
 
 def minpool_bwd(m, arg, label, thr, take, dx, grad_scale: float) -> None:
     n, c, h, w = dx.shape
-    counter = torch.zeros(n, device=dx.device, dtype=torch.int32)
     lib = _lib.load()
+    if deterministic_enabled():
+        need = int(lib.ps_tie_workspace_ints(n, h, w))
+        counts = torch.empty(need, device=dx.device, dtype=torch.int32)
+        _lib.check(lib.ps_minpool_bwd_det(m.data_ptr(), arg.data_ptr(), label.data_ptr(), thr.data_ptr(), take.data_ptr(), counts.data_ptr(), need,
+                                          dx.data_ptr(), grad_scale, n, c, h, w, _stream()), "ps_minpool_bwd_det")
+        return
+    counter = torch.zeros(n, device=dx.device, dtype=torch.int32)
     _lib.check(lib.ps_minpool_bwd(m.data_ptr(), arg.data_ptr(), label.data_ptr(), thr.data_ptr(), take.data_ptr(), counter.data_ptr(), dx.data_ptr(),
                                   grad_scale, n, c, h, w, _stream()), "ps_minpool_bwd")
 

@@ -257,7 +257,11 @@ class RFMTrainer(_ArenaMixin):
         self.f9_packed.zero_()
         drop = model.sample_dropout(x.shape[0], x.device)
         outs, ctx = model.rfm_forward(x, pmask, pcam, save=True, drop=drop)
-        losses, d_outs = rfm_losses(outs, pmask, pcam, label, want_grad=True, grad_scale=self.loss_scale / self.world)
+        prev, ops.DETERMINISTIC = ops.DETERMINISTIC, (self.deterministic if self.deterministic is not None else ops.DETERMINISTIC)
+        try:  # (the loss block's top-k backward chooses among exact ties: deterministic mode takes them in index order)
+            losses, d_outs = rfm_losses(outs, pmask, pcam, label, want_grad=True, grad_scale=self.loss_scale / self.world)
+        finally:
+            ops.DETERMINISTIC = prev
         if self.reducer is not None:
             self.reducer.begin_step()
 

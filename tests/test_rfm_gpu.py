@@ -379,12 +379,11 @@ def test_rfm_trainer_step_at_baseline_config3_shape_vs_oracle():
 
 @pytest.mark.selfcheck
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_rfm_trainer_deterministic_mode_repeats(precision):
+def test_rfm_trainer_deterministic_runs_are_bit_identical(precision):
     """torch.use_deterministic_algorithms(True, warn_only=True) of stage 3 (revise_pseudo_labels.py:140-146): `RFMTrainer(deterministic=True)`
-    twice on the same batch, three steps.  Everything on the path is order-independent (weight gradients through ps_conv2d_wgrad_det,
-    ordered fc8 reduction) EXCEPT which of the elements exactly EQUAL to a top-k threshold carry the gradient (`tie_ticket`: first come,
-    first served -- torch.topk leaves that choice open as well, and the reference only warns).  Asserted: the first step's losses (pure
-    forward) bit-identical, later losses and the master weights equal to 1e-6 of their scale; reported: whether the runs were bit-identical."""
+    twice on the same batch, three steps: BIT-IDENTICAL losses and master weights -- weight gradients through ps_conv2d_wgrad_det, ordered
+    fc8 reduction, and the elements exactly equal to a top-k threshold taken in index order (ps_minpool_bwd_det / ps_ecr_bwd_det) instead of
+    first come, first served."""
     from pistoseg_amd.revise_net import Net
     from pistoseg_amd.trainer import RFMTrainer
 
@@ -402,12 +401,76 @@ def test_rfm_trainer_deterministic_mode_repeats(precision):
         losses = [[float(v) for v in tr.train_step(x.to(D), pm.to(D), pc.to(D), label.reshape(n, c).to(D))] for _ in range(3)]
         torch.cuda.synchronize()
         runs.append((losses, tr.p_flat.clone()))
-    (l0, p0), (l1, p1) = runs
-    assert l0[0] == l1[0], (l0[0], l1[0])
-    for a, b in zip(l0[1:], l1[1:]):
-        assert all(abs(u - v) <= 1e-6 * abs(v) for u, v in zip(a, b)), (a, b)
-    assert float((p0 - p1).abs().max()) <= 1e-6 * float(p1.abs().max())
-    print(f"[selfcheck] RFM deterministic mode ({precision}): two runs bit-identical = {l0 == l1 and torch.equal(p0, p1)}")
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][1], runs[1][1])
+
+
+def test_topk_backward_deterministic_tie_choice():
+    """ps_minpool_bwd_det / ps_ecr_bwd_det on maps FULL of exact ties at the threshold (few distinct values, as the bf16-derived maps are):
+    the selected ties are the FIRST take[n] in the kernels' fixed order (checked element by element for the min-pool map, whose order is
+    the pixel index; three pixel segments per image here), every strictly-inside element is selected, repeated launches are bit-identical,
+    and the first-come-first-served kernels select the same NUMBER of elements."""
+    from pistoseg_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    n, c, h, w = 3, 4, 40, 52
+    hw = h * w
+    ones = torch.ones(n, c, device=D)
+
+    def both_modes(fn):
+        outs = []
+        for det in (True, True, False):
+            prev, ops.DETERMINISTIC = ops.DETERMINISTIC, det
+            try:
+                outs.append(fn())
+            finally:
+                ops.DETERMINISTIC = prev
+        assert torch.equal(outs[0], outs[1])  # deterministic mode repeats bit for bit
+        return outs[0], outs[2]
+
+    # --- adaptive min pooling: m = channel max in {0, .25, .5, .75, 1}; the k smallest positive-below-threshold values route the gradient
+    m = (torch.randint(0, 5, (n, hw), generator=g).float() / 4).to(D)
+    arg = torch.randint(1, c, (n, h, w), generator=g).to(torch.uint8).to(D)
+    k = hw // 4
+    thr, take, _ = ops.topk_select(m, k, largest=False, relu=True)
+
+    def run_minpool():
+        dx = torch.zeros(n, c, h, w, device=D)
+        ops.minpool_bwd(m, arg, ones, thr, take, dx, 1.0)
+        return dx
+
+    det, fcfs = both_modes(run_minpool)
+    for i in range(n):
+        sel = det[i].sum(0).reshape(-1) == 1.0
+        inside = (m[i] > 0) & (m[i] < thr[i])
+        ties = (m[i] > 0) & (m[i] == thr[i])
+        assert int(take[i]) <= int(ties.sum()) and int(ties.sum()) > 50  # the case is about ties
+        expect = inside.clone()
+        expect[torch.nonzero(ties).reshape(-1)[: int(take[i])]] = True
+        assert torch.equal(sel, expect), i
+        assert float(det[i].sum()) == float(fcfs[i].sum())  # same number of selected pixels either way
+    # --- ECR: |onehot(ref) - rv * label| with rv in {0, .25, .5, .75}: few distinct values, k largest
+    ref = torch.rand(n, c, h, w, generator=g).to(D)
+    rv = (torch.randint(0, 4, (n, c, h, w), generator=g).float() / 4).to(D)
+    t = torch.empty(n, c, h, w, device=D)
+    ops.ecr_tensor(ref, rv, ones, t)
+    k2 = int(0.2 * c * hw)
+    thr2, take2, _ = ops.topk_select(t.view(n, -1), k2, largest=True)
+
+    def run_ecr():
+        d = torch.zeros(n, c, h, w, device=D)
+        ops.ecr_bwd(ref, rv, ones, t, thr2, take2, d, 1.0)
+        return d
+
+    det, fcfs = both_modes(run_ecr)
+    for i in range(n):
+        strict = t[i] > thr2[i]
+        at = t[i] == thr2[i]
+        assert int(at.sum()) > int(take2[i]) > 0  # more ties than the quota: a real choice
+        assert torch.equal(det[i][strict], fcfs[i][strict])           # elements strictly inside the selection: both modes, same gradient
+        assert float(det[i][~strict & ~at].abs().max()) == 0.0        # nothing outside
+        # |gradient| is 1 on a selected element whose difference is non-zero (always, at a positive threshold): the tie quota is met exactly
+        assert int((det[i][at] != 0).sum()) == int(take2[i]) == int((fcfs[i][at] != 0).sum())
 
 
 @pytest.mark.parametrize("largest", [True, False])
