@@ -450,7 +450,7 @@ def test_topk_backward_deterministic_tie_choice():
         assert torch.equal(sel, expect), i
         assert float(det[i].sum()) == float(fcfs[i].sum())  # same number of selected pixels either way
     # --- ECR: |onehot(ref) - rv * label| with rv in {0, .25, .5, .75}: few distinct values, k largest
-    ref = torch.rand(n, c, h, w, generator=g).to(D)
+    ref = (torch.randint(0, 3, (n, c, h, w), generator=g).float() / 2).to(D)
     rv = (torch.randint(0, 4, (n, c, h, w), generator=g).float() / 4).to(D)
     t = torch.empty(n, c, h, w, device=D)
     ops.ecr_tensor(ref, rv, ones, t)
