@@ -1986,7 +1986,9 @@ static bool use_gemm256(long long M, int Cd, int esize, int taps, int mul, int d
 template <typename Tr>
 int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
   if constexpr (sizeof(typename Tr::elem) == 2) {
-    if (a.tpb == 0 && use_gemm256(a.M, a.Cd, 2, a.taps, a.mul, a.div_shift, a.klines)) {
+    // (one tile per block, dispatched by the hardware: this kernel re-balances around CUs held by a communication kernel by itself, so
+    // the tiles_per_block launch option of the persistent kernels does not apply to it)
+    if (use_gemm256(a.M, a.Cd, 2, a.taps, a.mul, a.div_shift, a.klines)) {
       IgemmArgs b = a;
       b.ntn = a.Cd / 256;
       b.ntm = (a.M + 255) / 256;
@@ -2148,7 +2150,7 @@ extern "C" int ps_conv_variant(const ps_conv_geom* g, int32_t dgrad) {
   const long long ho = (g->h - 1) / g->stride + 1, wo = (g->w - 1) / g->stride + 1;
   const long long M = dgrad ? (long long)g->n * g->h * g->w : (long long)g->n * ho * wo;
   if (g_use_3stage + g_use_pp != 0) return PS_CONV_OTHER;
-  if (g->tiles_per_block == 0 && use_gemm256(M, dgrad ? g->cin : g->cout, ps_esize(g->dtype), g->ksize * g->ksize, dgrad ? 1 : g->stride,
+  if (use_gemm256(M, dgrad ? g->cin : g->cout, ps_esize(g->dtype), g->ksize * g->ksize, dgrad ? 1 : g->stride,
                                               dgrad && g->stride == 2 ? 1 : 0, (dgrad ? g->cout : g->cin) * ps_esize(g->dtype) / 128))
     return PS_CONV_GEMM256;
   // both directions of a stride-1 3x3 layer gather on the input grid h x w
