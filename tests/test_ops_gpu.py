@@ -11,16 +11,18 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", autouse=True, params=["product", "debug"])
+@pytest.fixture(scope="module", autouse=True, params=["product"])
 def library(request):
-    """Every test of this module runs against BOTH binaries unless it says otherwise:
+    """Which binary a test of this module launches through:
 
-    * "product" = libpistoseg_hip.so, what `bench.py` and the model-level tests launch (tunables `constexpr`, no `ps_debug_*` symbols);
-      kernel selection there is a pure function of the geometry, so the cases below include shapes that SELECT the persistent
-      kernels (halo / ws2 / wgrad_ws2) by themselves -- asserted through `ps_conv_variant` / `ps_conv_wgrad_variant`;
-    * "debug" = libpistoseg_hip_debug.so (same sources, -DPS_DEBUG_HOOKS): the staging / tiling variant sweeps that force a kernel
-      through `ps_debug_set_*` exist only there (`@debug_only`).  Same sources is not same code (the hand-scheduled loops are
-      sensitive to any codegen change), hence both."""
+    * "product" (the default) = libpistoseg_hip.so, what `bench.py` and the model-level tests run (tunables `constexpr`, no `ps_debug_*`
+      symbols, only reachable kernels instantiated).  Kernel selection there is a pure function of the geometry, so the cases below include
+      shapes that SELECT the persistent kernels (halo / ws2 / gemm256 / wgrad_ws2) by themselves -- asserted through `ps_conv_variant` /
+      `ps_conv_wgrad_variant`;
+    * "debug" = libpistoseg_hip_debug.so (same sources, -DPS_DEBUG_HOOKS): only for the tests that drive `ps_debug_set_*` -- the staging /
+      tiling variant sweeps (`@debug_only`) and the tests that compare a forced variant with the default (`@both_libraries`: they run their
+      CPU comparison on the product library as well).  Same sources is not same code (the hand-scheduled loops are sensitive to any
+      codegen change), which is why the parity claim rests on the product runs."""
     from pistoseg_amd import _lib
 
     _lib.use_debug_library(request.param == "debug")
@@ -28,6 +30,7 @@ def library(request):
     _lib.use_debug_library(False)
 
 
+both_libraries = pytest.mark.parametrize("library", ["product", "debug"], indirect=True)
 debug_only = pytest.mark.parametrize("library", ["debug"], indirect=True)  # tests that drive `ps_debug_set_*`
 # conv_igemm.hip's variant codes (include/pistoseg_hip.h)
 V_4WAVE, V_WS_128, V_WS_112, V_WS2_256, V_WS2_224, V_OTHER, V_HALO, V_GEMM256 = 1, 2, 3, 4, 5, 6, 7, 8
@@ -574,6 +577,7 @@ def _halo_case(case, dtype, ring):
     assert all(torch.equal(a_, b_) for a_, b_ in zip(got[0], got[1]))  # deterministic (race screen)
 
 
+@both_libraries
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", [
     # (n, h, w, cin, cout, k, s, d): ragged pixel counts (zero-filled K tail), 1 .. several work items per persistent block
@@ -745,6 +749,7 @@ def test_persistent_kernels_selected_by_geometry_match_cpu(case, family, dtype, 
     assert rel_err(dw.cpu(), w_fwd_layout(wt.grad)) < 1e-4  # exact products of 16-bit operands, f32 accumulation
 
 
+@both_libraries
 @pytest.mark.parametrize("case", [(512, 512, 3, 1, 28), (1024, 2048, 3, 4, 28), (256, 256, 3, 1, 56), (2048, 4096, 1, 1, 28)])
 def test_full_size_layers_kernel_families_agree(case, library):
     """BASELINE-size layers (bs = 64, bf16), too big for a full CPU reference inside the suite: size-independent checks instead, plus
@@ -1014,6 +1019,7 @@ def test_weight_transpose_batched_matches_permute(dtype):
         assert torch.equal(dst, src.t())
 
 
+@both_libraries
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 # cin, cout, H, W, N (odd sizes: ragged classes); the last case is b4's first conv at a batch where the geometry itself selects the split
 @pytest.mark.parametrize("case", [(128, 256, 56, 56, 2), (256, 512, 28, 28, 3), (128, 128, 23, 31, 2), (256, 512, 56, 56, 37)])
@@ -1093,6 +1099,7 @@ def test_dropout2d_masks_kernel():
     assert not torch.equal(d1["dropout7"], d2["dropout7"])
 
 
+@both_libraries
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", [
     # (n, h, w, cin, cout, d): tile counts that leave a partial last round of <= half the 256 CUs, in whole pixel tiles:
