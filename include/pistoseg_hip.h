@@ -165,6 +165,16 @@ int ps_conv1a_fwd(int32_t out_dtype, const float* x_nchw, const float* w_oihw, c
  *   cam[m,c] = sum_k x[m,k] * (drop ? drop[n(m),k] : 1) * w[c,k]      cam: f32 [M, C] (pixel-major)   */
 int ps_fc8_fwd(int32_t dtype, const void* x, int32_t ldc_x, const float* w, const float* drop, float* cam, int32_t m_total,
                int32_t pix_per_image, int32_t k, int32_t c, void* stream);
+/* INFERENCE fusion of a wide 1x1 convolution, the eval-mode BN + ReLU behind it and the narrow head on its output:
+ *   cam[m, c] = sum_ch T(max(conv(x, W)[m, ch] * scale[ch] + shift[ch], 0)) * w_head[c * cout + ch]        (T = the storage type's rounding)
+ * without materialising the activated tensor.  replaces: b7's last 1x1 conv (the K-concatenated shortcut + branch2b2 of models/resnet38d.py:
+ * 76-97) + `relu(bn7(.))` (:186) + `fc8` (models/revise_net.py:50) when dropout is off -- conv6 (411 MB at bs = 64) is otherwise written only to
+ * be read back and reduced to C channels.  16-bit dtypes, 1x1 stride-1, cout % 256 == 0, cin >= 256, 1 <= classes <= 8; every (64-channel
+ * slice, pixel, class) partial sum goes to `workspace` (ps_conv1x1_head_workspace_floats(g, classes) floats, 0 = geometry not served: use
+ * ps_conv2d_fwd + ps_fc8_fwd) and a second kernel adds the slices in order (deterministic).  cam: f32 [M, classes] pixel-major. */
+int64_t ps_conv1x1_head_workspace_floats(const ps_conv_geom* g, int32_t classes);
+int ps_conv1x1_head_fwd(const ps_conv_geom* g, const void* x, const void* w_fwd, const float* scale, const float* shift, const float* w_head,
+                        int32_t classes, float* workspace, int64_t workspace_floats, float* cam, void* stream);
 /* General narrow 1x1 head: cam[m, c] (=|+=) sum_k x[m, k] * drop[n, k] * w[c * ldw + k] + bias[c]  (bias / drop may be NULL).
  * Lets a head over concatenated features run as one call per feature map without materialising the concat:
  * replaces `fc_cam(torch.cat([conv4, conv5, conv6], dim=1))` (OEEM/classification/network/wide_resnet.py:166-186). */

@@ -93,6 +93,8 @@ PROTOTYPES = {
     "ps_cast_f32_lowp": (C.c_int, [_P, _P, _I, _L, _P]),
     "ps_conv1a_fwd": (C.c_int, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ps_fc8_fwd": (C.c_int, [_I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ps_conv1x1_head_workspace_floats": (C.c_int64, [C.POINTER(ConvGeom), _I]),
+    "ps_conv1x1_head_fwd": (C.c_int, [C.POINTER(ConvGeom), _P, _P, _P, _P, _P, _I, _P, _L, _P, _P]),
     "ps_fc_head_fwd": (C.c_int, [_I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "ps_fc8_bwd": (C.c_int, [_I, _P, _I, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "ps_fc8_bwd_workspace_floats": (C.c_int64, [_I, _I, _I, _I]),

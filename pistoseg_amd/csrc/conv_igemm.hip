@@ -45,6 +45,11 @@ struct IgemmArgs {
   // class's sub-grid, pixel (p', q') of it is pixel (oy + 2p', ox + 2q') of the full Hf x Wf gradient, and only the taps in tap_mask
   // (those that hit dy at integer positions for this parity) are staged and multiplied.  epi_M = rows of the full tensor.
   int tap_mask, oy, ox, Hf, Wf;
+  // conv_gemm256_kernel<.., HEAD>: the narrow 1x1 head fused behind BN + ReLU (inference): per-block partial sums of
+  // cam[m][c] = sum_ch round(max(acc * scale + shift, 0))[m][ch] * head_w[c][ch] go to head_part[(tn * 4 + wave column)][m][c]
+  const float* head_w;
+  float* head_part;
+  int head_c;
   int tm0;                    // halo kernel: first pixel tile of this launch (a layer's tail tiles go to a second launch as 64-cout half tiles)
   ps_epilogue epi;
 };
@@ -1265,6 +1270,64 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
   }
 }
 
+// Head epilogue of conv_gemm256_kernel<.., HEAD> (inference): instead of storing the activated tile -- conv6, the net's second largest
+// tensor, written only to be read back by the 4096 -> C head (models/revise_net.py:50) -- the wave reduces it on the spot:
+//   v[m][ch] = T(max(acc * scale[ch] + shift[ch], 0))          (rounded to the storage type, exactly what conv6 would have held)
+//   part[j][m][c] = sum over this wave's 64 channels of v[m][ch] * head_w[c][ch],   j = (cout tile) * 4 + (wave column)
+// and head_reduce_kernel adds the parts in j order.  A lane owns 16 channels of one pixel per fragment row; the four lane groups of a
+// pixel meet through two cross-lane adds.
+template <typename T, int MI, int WI>
+__device__ __forceinline__ void conv_head_epilogue(const IgemmArgs& a, f32x4 (&acc)[MI][WI], int mbase, int cbase, int lane, int part_idx) {
+  static_assert(WI == 4, "a lane owns 16 channels");
+  const int frow = lane & 15, g = lane >> 4;
+  const int cb = cbase + 16 * g;
+  const ps_epilogue& e = a.epi;
+  float sc[16], sh[16];
+#pragma unroll
+  for (int i = 0; i < 16; i += 4) {
+    const float4 q = e.scale ? *reinterpret_cast<const float4*>(e.scale + cb + i) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 r = e.shift ? *reinterpret_cast<const float4*>(e.shift + cb + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    sc[i] = q.x; sc[i + 1] = q.y; sc[i + 2] = q.z; sc[i + 3] = q.w;
+    sh[i] = r.x; sh[i + 1] = r.y; sh[i + 2] = r.z; sh[i + 3] = r.w;
+  }
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float v = fmaxf(acc[mi][i >> 2][i & 3] * sc[i] + sh[i], 0.f);
+      if constexpr (std::is_same<T, __bf16>::value) acc[mi][i >> 2][i & 3] = __uint_as_float(static_cast<uint32_t>(ps_f32_to_bf16(v)) << 16);
+      else acc[mi][i >> 2][i & 3] = static_cast<float>(static_cast<_Float16>(v));
+    }
+  const long long plane = (long long)a.epi_M * a.head_c;
+  float* part = a.head_part + (long long)part_idx * plane;
+  for (int c = 0; c < a.head_c; ++c) {
+    float w[16];
+#pragma unroll
+    for (int i = 0; i < 16; i += 4) {
+      const float4 q = *reinterpret_cast<const float4*>(a.head_w + (long long)c * a.Cd + cb + i);
+      w[i] = q.x; w[i + 1] = q.y; w[i + 2] = q.z; w[i + 3] = q.w;
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      float p = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) p += acc[mi][i >> 2][i & 3] * w[i];
+      p += __shfl_xor(p, 16);
+      p += __shfl_xor(p, 32);
+      const int m = mbase + mi * 16 + frow;
+      if (g == 0 && m < a.epi_M) part[(long long)m * a.head_c + c] = p;
+    }
+  }
+}
+// cam[i] = part[0][i] + part[1][i] + ... (i over M x C), in part order: one thread per element, fixed summation order
+__global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restrict__ part, float* __restrict__ cam, long long n, int nparts) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float s = part[i];
+    for (int j = 1; j < nparts; ++j) s += part[(long long)j * n + i];
+    cam[i] = s;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 256 x 256 tile kernel for the PLAIN GEMMs of the net: 1x1 stride-1 layers (forward and data gradient; the bottleneck units'
 // K-concatenated shortcut + last conv included), 16-bit operands.
@@ -1288,7 +1351,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
 //     phases have landed by the end of its L phase after next (vmcnt(4) = the two newest phases' pieces may be in flight), which is
 //     at least two intervals before any wave reads them.
 // ------------------------------------------------------------------------------------------------
-template <typename Tr>
+template <typename Tr, bool HEAD = false>
 __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const IgemmArgs a) {
   typedef typename Tr::elem T;
   static_assert(sizeof(T) == 2, "16-bit operands");
@@ -1439,7 +1502,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const IgemmArgs a)
   }
   if (t < NT) ktile(std::integral_constant<int, 0>{}, t);
   if (grp == 0) __builtin_amdgcn_s_barrier();
-  conv_epilogue<T, MI, WI, 0>(a, acc, m0 + grp * 128, n0 + wc * 64, lane);
+  if constexpr (HEAD) conv_head_epilogue<T, MI, WI>(a, acc, m0 + grp * 128, n0 + wc * 64, lane, tn * 4 + wc);
+  else conv_epilogue<T, MI, WI, 0>(a, acc, m0 + grp * 128, n0 + wc * 64, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2157,6 +2221,64 @@ extern "C" int ps_conv_variant(const ps_conv_geom* g, int32_t dgrad) {
   const bool halo_ok = g->ksize == 3 && g->stride == 1 && halo_tile_width(g->w) != 0 && g->dilation <= 4;
   const int v = pick_ws_variant(M, dgrad ? g->cin : g->cout, ps_esize(g->dtype), halo_ok);
   return v ? v : PS_CONV_4WAVE;
+}
+
+// ---- 1x1 conv + BN + ReLU + narrow head in one launch (inference) ------------------------------------------------------------------
+static bool head_geom_ok(const ps_conv_geom* g, int classes) {
+  if (check_geom(g) != PS_OK || classes < 1 || classes > 8) return false;
+  const int es = ps_esize(g->dtype);
+  return es == 2 && g->ksize == 1 && g->stride == 1 && g->cout % 256 == 0 && (g->cin * es) / 128 >= 4;
+}
+
+extern "C" int64_t ps_conv1x1_head_workspace_floats(const ps_conv_geom* g, int32_t classes) {
+  if (!g || !head_geom_ok(g, classes)) return 0;
+  return (int64_t)(g->cout / 64) * g->n * g->h * g->w * classes;
+}
+
+extern "C" int ps_conv1x1_head_fwd(const ps_conv_geom* g, const void* x, const void* w_fwd, const float* scale, const float* shift, const float* w_head,
+                                   int32_t classes, float* workspace, int64_t workspace_floats, float* cam, void* stream) {
+  PS_REQUIRE(g && x && w_fwd && w_head && workspace && cam, "conv1x1_head_fwd: null argument");
+  PS_REQUIRE(head_geom_ok(g, classes), "conv1x1_head_fwd: geometry not served (16-bit 1x1 stride-1, cout %% 256 == 0, cin >= 256, 1..8 classes): %s",
+             ps_last_error());
+  PS_REQUIRE(ps_aligned16(x) && ps_aligned16(w_fwd) && ps_aligned16(w_head) && ps_aligned16(workspace), "conv1x1_head_fwd: misaligned pointer");
+  const int64_t need = ps_conv1x1_head_workspace_floats(g, classes);
+  PS_REQUIRE(workspace_floats >= need, "conv1x1_head_fwd: workspace of %lld floats, need %lld", (long long)workspace_floats, (long long)need);
+  const int es = 2;
+  IgemmArgs a{};
+  a.src = static_cast<const unsigned char*>(x);
+  a.wgt = static_cast<const unsigned char*>(w_fwd);
+  a.Hs = a.Ho = g->h; a.Ws = a.Wo = g->w;
+  a.M = g->n * g->h * g->w;
+  a.mul = 1; a.dstep = 1; a.div_shift = 0;
+  a.taps = 1; a.ctr = 0;
+  a.klines = g->cin * es / 128;
+  a.pix_bytes = (long long)g->ldc_x * es;
+  a.wrow_bytes = (long long)g->cin * es;
+  a.Cd = g->cout;
+  a.epi = ps_epilogue{};
+  a.epi.mode = PS_EPI_BNRELU;
+  a.epi.scale = scale;
+  a.epi.shift = shift;
+  a.head_w = w_head;
+  a.head_part = workspace;
+  a.head_c = classes;
+  const long long src_bytes = (long long)a.M * a.pix_bytes, wgt_bytes = (long long)g->cout * a.wrow_bytes;
+  PS_REQUIRE(src_bytes < (1LL << 31) && wgt_bytes < (1LL << 31), "conv1x1_head_fwd: tensor larger than 2 GiB");
+  a.src_bytes = (unsigned)src_bytes;
+  a.wgt_bytes = (unsigned)wgt_bytes;
+  a.epi_M = a.M;
+  a.supertile = g_supertile;
+  a.ntn = g->cout / 256;
+  a.ntm = (a.M + 255) / 256;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)(a.ntm * a.ntn));
+  if (g->dtype == PS_BF16) hipLaunchKernelGGL((conv_gemm256_kernel<TraitsBF16, true>), grid, dim3(512), 2 * (256 * 128 + 256 * 128), s, a);
+  else hipLaunchKernelGGL((conv_gemm256_kernel<TraitsF16, true>), grid, dim3(512), 2 * (256 * 128 + 256 * 128), s, a);
+  PS_CHECK_LAUNCH("conv_gemm256<head>");
+  const long long nel = (long long)a.M * classes;
+  hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)std::min<long long>((nel + 255) / 256, 4096)), dim3(256), 0, s, workspace, cam, nel, g->cout / 64);
+  PS_CHECK_LAUNCH("head_reduce");
+  return PS_OK;
 }
 
 extern "C" int ps_conv2d_fwd(const ps_conv_geom* g, const void* x, const void* w_fwd, const ps_epilogue* epi, void* stream) {

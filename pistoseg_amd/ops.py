@@ -156,6 +156,36 @@ def conv2d_dgrad(spec: ConvSpec, dy: Tensor, w_dgrad: Tensor, x_hw, *, add0=None
             lambda: _lib.check(lib.ps_conv2d_dgrad(C.byref(g), dy.data_ptr(), w_dgrad.data_ptr(), C.byref(e), _stream()), "ps_conv2d_dgrad"))
 
 
+def conv1x1_head_supported(spec: ConvSpec, x: Tensor, classes: int) -> int:
+    """Workspace floats ps_conv1x1_head_fwd needs for this launch, 0 if the fused kernel does not serve it (f32, narrow layers, ...)."""
+    if spec.ksize != 1 or spec.stride != 1 or x.dtype == torch.float32:
+        return 0
+    n, h, w, _ = x.shape
+    g = _geom(spec, _dt(x), n, h, w, _ldc(x), spec.cout)
+    return int(_lib.load().ps_conv1x1_head_workspace_floats(C.byref(g), classes))
+
+
+def conv1x1_head_fwd(spec: ConvSpec, x: Tensor, w_fwd: Tensor, bn_scale: Tensor, bn_shift: Tensor, w_head: Tensor, cam: Tensor) -> None:
+    """cam[n,h,w,C] (f32) = head(T(relu(bn(conv1x1(x))))) in one launch + an ordered reduction: the activated tensor is never written
+    (inference: b7's last conv + bn7 + ReLU + fc8, resnet38d.py:186 / revise_net.py:50).  w_head: [C, cout] f32."""
+    _require_gpu(x, w_fwd, w_head, cam)
+    n, h, w, _ = x.shape
+    classes = w_head.shape[0]
+    assert w_head.shape == (classes, spec.cout) and w_head.dtype == torch.float32 and w_head.is_contiguous()
+    assert cam.shape == (n, h, w, classes) and cam.dtype == torch.float32 and cam.is_contiguous()
+    g = _geom(spec, _dt(x), n, h, w, _ldc(x), spec.cout)
+    lib = _lib.load()
+    need = int(lib.ps_conv1x1_head_workspace_floats(C.byref(g), classes))
+    if need <= 0:
+        raise _lib.PsError("conv1x1_head_fwd: geometry not served by the fused kernel")
+    ws = torch.empty(need, device=x.device, dtype=torch.float32)
+    _launch(f"conv_gemm256_kernel<{ {PS_BF16: 'bf16', PS_F16: 'f16'}.get(g.dtype, 'f32') }>" if PROFILE is not None else "",
+            2.0 * n * h * w * spec.cout * spec.cin,
+            lambda: _lib.check(lib.ps_conv1x1_head_fwd(C.byref(g), x.data_ptr(), w_fwd.data_ptr(), bn_scale.data_ptr(), bn_shift.data_ptr(),
+                                                       w_head.data_ptr(), classes, ws.data_ptr(), need, cam.data_ptr(), _stream()),
+                               "ps_conv1x1_head_fwd"))
+
+
 # Deterministic weight gradients (ps_conv2d_wgrad_det): partial sums of the pixel ranges go to a workspace and are added up in range
 # order instead of by f32 atomics -- the reference's `torch.use_deterministic_algorithms(True)` / `Trainer(deterministic=True)`
 # (revise_pseudo_labels.py:140-146, segmentation_train.py:153-160).  None = follow torch's own switch, i.e. exactly what those two

@@ -322,8 +322,11 @@ class Net(nn.Module):
         }
 
     # ------------------------------------------------------------------ forward plan
-    def run_backbone(self, x: Tensor, save: bool, drop: Optional[Dict[str, Tensor]] = None):
-        """x: NCHW f32 on the GPU.  Returns ({conv3,conv4,conv5,conv6} channels-last, _Saved or None)."""
+    def run_backbone(self, x: Tensor, save: bool, drop: Optional[Dict[str, Tensor]] = None, head: Optional[Tensor] = None):
+        """x: NCHW f32 on the GPU.  Returns ({conv3,conv4,conv5,conv6} channels-last, _Saved or None).
+        head (inference only: save=False, no dropout): the narrow 1x1 head's weight [C, 4096] f32 on conv6.  Where the fused kernel serves
+        the last unit's final conv (16-bit paths), that launch reduces relu(bn7(.)) straight to `feats["cam"]` [n,h,w,C] f32 and conv6 is
+        never materialised (`feats` then has no "conv6")."""
         if not x.is_cuda:
             raise RuntimeError("pistoseg_amd.resnet38d.Net runs on the GPU only (no CPU fallback); move the module and input to cuda")
         x = x.contiguous().float()
@@ -395,8 +398,16 @@ class Net(nn.Module):
                 a3 = a_wide[..., cin:] if fused else new(ho, wo, cout // 2)
                 ops.conv2d_fwd(specs["conv_branch2b1"], a2, self.w_fwd(unit.conv_branch2b1, name + ".conv_branch2b1"), bn_scale=s2, bn_shift=b2, drop=d2, out_act=a3)
                 if fused:  # branch1(a) + branch2b2(a3) = one 1x1 conv over [a | a3]: no shortcut tensor, no residual read
-                    ops.conv2d_fwd(ConvSpec(cin + cout // 2, cout, 1), a_wide, self.w_fwd_cat(unit, name),
-                                   out_raw=xraw_next, bn_scale=nscale, bn_shift=nshift, out_act=a_next)
+                    cat_spec = ConvSpec(cin + cout // 2, cout, 1)
+                    last = i + 1 == len(self.units)
+                    if (last and head is not None and not save and xraw_next is None and head.shape[1] == cout
+                            and ops.conv1x1_head_supported(cat_spec, a_wide, head.shape[0]) > 0):
+                        cam = torch.empty((n, ho, wo, head.shape[0]), device=dev, dtype=torch.float32)
+                        ops.conv1x1_head_fwd(cat_spec, a_wide, self.w_fwd_cat(unit, name), nscale, nshift, head, cam)
+                        feats["cam"] = cam
+                        a_next = None
+                    else:
+                        ops.conv2d_fwd(cat_spec, a_wide, self.w_fwd_cat(unit, name), out_raw=xraw_next, bn_scale=nscale, bn_shift=nshift, out_act=a_next)
                 else:
                     ops.conv2d_fwd(specs["conv_branch2b2"], a3, self.w_fwd(unit.conv_branch2b2, name + ".conv_branch2b2"), add0=shortcut,
                                    out_raw=xraw_next, bn_scale=nscale, bn_shift=nshift, out_act=a_next)
@@ -404,7 +415,8 @@ class Net(nn.Module):
                     saved.mid[name] = (a2, a3)
                     saved.drop[name + ".dropout_2b1"], saved.drop[name + ".dropout_2b2"] = d1, d2
             a, a_wide, xraw, h, w = a_next, a_wide_next, xraw_next, ho, wo
-        feats["conv6"] = a
+        if a is not None:
+            feats["conv6"] = a
         if saved is not None:
             saved.conv6 = a
             saved.n = n

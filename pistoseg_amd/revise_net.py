@@ -108,14 +108,17 @@ class Net(ResNet38dSeg):
         x = x.contiguous().float()
         n, _, H, W = x.shape
         C = self.classes
-        feats, saved = self.run_backbone(x, save=save, drop=drop)
-        conv4, conv5, conv6 = feats["conv4"], feats["conv5"], feats["conv6"]
-        g1, g2 = conv6.shape[1:3]
+        head = self.fc8.weight.detach().reshape(C, 4096) if (self.fuse_head and not save and not drop) else None  # stage-4 inference: see run_backbone
+        feats, saved = self.run_backbone(x, save=save, drop=drop, head=head)
+        conv4, conv5 = feats["conv4"], feats["conv5"]
+        g1, g2 = conv5.shape[1:3]
         P = g1 * g2
         dev, dt = x.device, self.compute_dtype
-        # fc8 on dropout7(conv6)
-        cam_lr = torch.empty((n, g1, g2, C), device=dev, dtype=torch.float32)
-        ops.fc8_fwd(conv6, self.fc8.weight.detach().reshape(C, 4096), drop.get("dropout7"), cam_lr)
+        if "cam" in feats:
+            cam_lr = feats["cam"]
+        else:  # fc8 on dropout7(conv6)
+            cam_lr = torch.empty((n, g1, g2, C), device=dev, dtype=torch.float32)
+            ops.fc8_fwd(feats["conv6"], self.fc8.weight.detach().reshape(C, 4096), drop.get("dropout7"), cam_lr)
         # concat feature (revise_net.py:61-66)
         F = torch.zeros((n, g1, g2, FCAT), device=dev, dtype=dt)
         ops.conv2d_fwd(ConvSpec(512, 64, 1), conv4, self.w_fwd(self.f8_3, "f8_3"), out_act=F[..., 0:64])

@@ -28,6 +28,7 @@ class ResNet38dSeg(resnet38d.Net):
         self.from_scratch_layers = [self.fc8]
         self.not_training = [self.conv1a, self.b2, self.b2_1, self.b2_2]  # revise_net.py:27
         self.classes = classes
+        self.fuse_head = True  # inference: fc8 fused into b7's last conv launch (ps_conv1x1_head_fwd) where the geometry allows
         self.train(True)
 
     def dropout_segments(self):
@@ -63,7 +64,13 @@ class ResNet38dSeg(resnet38d.Net):
         if n > limit:  # the kernels address a tensor through 32-bit buffer offsets (< 2 GiB each): big inference batches
             return torch.cat([self.forward(x[i:i + limit]) for i in range(0, n, limit)], 0)  # (d4 TTA: 8 views x N) go in slices
         drop = self.sample_dropout(n, x.device) if self.training else {}
-        feats, _ = self.run_backbone(x, save=False, drop=drop)
+        # inference without dropout: fc8 folded into b7's last launch where the fused kernel serves it (16-bit paths); conv6 is then never written
+        head = self.fc8.weight.detach().reshape(self.classes, 4096) if (self.fuse_head and not drop) else None
+        feats, _ = self.run_backbone(x, save=False, drop=drop, head=head)
+        if "cam" in feats:
+            logits = torch.empty((n, self.classes, h, w), device=x.device, dtype=torch.float32)
+            ops.bilinear_fwd(feats["cam"], "nhwc", logits, "nchw", True)
+            return logits
         logits, _ = self.head_forward(feats["conv6"], drop.get("dropout7"), x.shape[-2:])
         return logits
 

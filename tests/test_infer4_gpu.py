@@ -103,3 +103,27 @@ def test_dataparallel_wrapper_and_module_prefixed_checkpoint(tmp_path):
         a = model(x.to(D), pm.to(D), pc.to(D))
         b = model.module(x.to(D), pm.to(D), pc.to(D))
     assert all(torch.equal(u, v) for u, v in zip(a, b))
+
+
+def test_stage4_bf16_fused_head_equals_unfused():
+    """Stage-4 inference on the bf16 path takes the fused b7 + bn7 + fc8 launch (revise_net.py:50 without dropout): the `cam` output equals the
+    unfused path's up to f32 summation order, and the masks of the three revised maps agree except where the normalised CAM's non-maximum
+    suppression (discontinuous in the CAM) sits on a tie."""
+    from pistoseg_amd.revise_net import Net
+
+    c, s, T = 4, 96, 3
+    sd = ref_cpu.make_state_dict(c, True, seed=42)
+    model = Net(c, "bf16")
+    model.load_state_dict(sd, strict=True)
+    model = model.to(D)
+    model.eval()
+    x, pmask, pcam, lab = make_inputs(T, s, c, seed=172)
+    pm, pc, _ = with_bg(pmask, pcam, lab)
+    with torch.no_grad():
+        fused = [o.cpu() for o in model(x.to(D), pm.to(D), pc.to(D))]
+        model.fuse_head = False
+        unfused = [o.cpu() for o in model(x.to(D), pm.to(D), pc.to(D))]
+    model.fuse_head = True
+    assert float((fused[0] - unfused[0]).abs().max()) <= 1e-5 * float(unfused[0].abs().max())
+    for a, b in zip(fused[1:], unfused[1:]):
+        assert float((a - b).abs().mean()) <= 1e-4 * float(b.abs().max())

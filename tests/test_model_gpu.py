@@ -118,6 +118,41 @@ def test_seg_forward_fp16_close_to_oracle():
     assert agree > 0.995, agree
 
 
+@pytest.mark.parametrize("precision,n,s", [("bf16", 2, 64), ("fp16", 3, 96), ("bf16", 5, 224)])
+def test_inference_head_fused_into_last_conv_launch(precision, n, s):
+    """Inference on the 16-bit paths folds relu(bn7(.)) + fc8 into b7's last conv launch (ps_conv1x1_head_fwd: conv6 is never written;
+    resnet38d.py:186, revise_net.py:50).  Same arithmetic on the same rounded activations, so the logits equal the unfused path's up to the
+    f32 summation order (1e-5), the fused launch really is the one taken, and both agree with the CPU oracle as the unfused path does."""
+    from pistoseg_amd import ops
+
+    c = 4
+    sd = ref_cpu.make_state_dict(c, False, seed=42)
+    model = build(c, precision, sd)
+    model.eval()
+    x, *_ = make_inputs(n, s, 4, 120 + n)
+    calls = []
+    orig = ops.conv1x1_head_fwd
+    ops.conv1x1_head_fwd = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            fused = model(x.to(D)).cpu()
+            assert len(calls) == 1
+            model.fuse_head = False
+            unfused = model(x.to(D)).cpu()
+            assert len(calls) == 1
+            ref = ref_cpu.seg_forward(sd, x)
+    finally:
+        ops.conv1x1_head_fwd = orig
+        model.fuse_head = True
+    assert rel_err(fused, unfused) < 1e-5
+    tol = 6e-2 if precision == "bf16" else 1e-2
+    assert rel_err(fused, ref) < tol and rel_err(unfused, ref) < tol
+    model.train()  # training (dropout7 active) keeps the unfused path
+    with torch.no_grad():
+        model(x.to(D))
+    assert len(calls) == 1
+
+
 @pytest.mark.selfcheck
 def test_seg_trainer_fp16_loss_scaling_tracks_fp32():
     """fp16 native step (dynamic loss scale, fp16 shadow weights) against the fp32 native step on the same batch and
