@@ -43,6 +43,8 @@ void ps_debug_set_ws2(int v);
 void ps_debug_set_halo(int v);
 /* Testing hook: conv_gemm256_kernel (256x256 tile, plain 1x1 stride-1 GEMMs, 16-bit): 0 off, 1 (default) by shape, 2 whenever legal. */
 void ps_debug_set_gemm256(int v);
+/* Testing hook: gemm256's partial last round as a second launch on the gathered-tile kernels: 0 off, 1 (default) on. */
+void ps_debug_set_gemm256_tail(int v);
 /* Tuning hook: weight ring depth of the halo kernel: 3, 4 or 5 stages of 16 KiB (256-pixel tiles: at most 4). */
 void ps_debug_set_halo_ring(int v);
 /* Testing hook: halo kernel, partial last round as a second launch of 64-cout half tiles: 0 off, 1 (default) on. */

@@ -50,6 +50,8 @@ struct IgemmArgs {
   const float* head_w;
   float* head_part;
   int head_c;
+  int m_off;                  // rows of the layer that precede this launch's row 0 (a gemm256 launch's tail rows go to a second launch on the
+                              // gathered-tile kernels, with every tensor pointer advanced): only the dropout epilogue's image index needs it
   int tm0;                    // halo kernel: first pixel tile of this launch (a layer's tail tiles go to a second launch as 64-cout half tiles)
   ps_epilogue epi;
 };
@@ -222,7 +224,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
     if (e.drop && e.mode != PS_EPI_NONE && MAP != 2) {
       const int hw = a.Ho * a.Wo;
       const int mf = row0 < a.epi_M ? row0 : 0, ml0 = row0 + (MI - 1) * RSTEP, ml = ml0 < a.epi_M ? ml0 : mf;
-      const int nf = mf / hw, nl = ml / hw, n0 = __builtin_amdgcn_readfirstlane(nf);
+      const int nf = (mf + a.m_off) / hw, nl = (ml + a.m_off) / hw, n0 = __builtin_amdgcn_readfirstlane(nf);
       fold = __builtin_amdgcn_ballot_w64(nf != n0 || nl != n0) == 0;
       if (fold) load_vec(e.drop + (long long)n0 * a.Cd + cb, dm);
     }
@@ -284,7 +286,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
       for (int mi = 0; mi < MI; ++mi) {
         const int m = row0 + mi * RSTEP;  // (MAP 2 never comes with dropout: the host keeps such launches on the plain path)
         if (m >= a.epi_M) continue;
-        const float* d = e.drop + (long long)(m / hw) * a.Cd + cb;
+        const float* d = e.drop + (long long)((m + a.m_off) / hw) * a.Cd + cb;
         float v[CW];
 #pragma unroll
         for (int i = 0; i < CW; ++i) v[i] = acc[mi][(c0 + i) / 4][i & 3];
@@ -1918,6 +1920,7 @@ PS_TUNABLE g_use_halo = 1;     // window + halo staging for 3x3 stride-1 layers 
 PS_TUNABLE g_halo_tail = 1;   // halo kernel: a partial last round (<= half the CUs) as a second launch of 64-cout half tiles: 0 off, 1 on
 PS_TUNABLE g_halo_ring = 3;   // weight ring depth of the halo kernel (3 | 4 | 5 stages of 16 KiB; 256-pixel tiles: <= 4)
 PS_TUNABLE g_gemm256 = 1;      // 256 x 256 tile kernel for the plain GEMMs (1x1 stride-1, 16-bit): 0 off, 1 by shape, 2 whenever legal
+PS_TUNABLE g_gemm256_tail = 1; // gemm256: a partial last round of at most half the CUs goes to a second launch on the gathered-tile kernels: 0 off, 1 on
 PS_TUNABLE g_use_3stage = 0;  // experimental 256x128 three-stage kernel: correct but slower than two 128x128 blocks per CU (r01 measurements)
 PS_TUNABLE g_ablate = 0;
 PS_TUNABLE g_supertile = 4;  // measured best of {0,4,8,16} on the wide 28x28 layers (r01)
@@ -2048,16 +2051,42 @@ static bool use_gemm256(long long M, int Cd, int esize, int taps, int mul, int d
 }
 
 template <typename Tr>
-int dispatch_bn(const IgemmArgs& a, hipStream_t s) {
+int dispatch_bn(const IgemmArgs& a, hipStream_t s, bool allow_gemm256 = true) {
   if constexpr (sizeof(typename Tr::elem) == 2) {
     // (one tile per block, dispatched by the hardware: this kernel re-balances around CUs held by a communication kernel by itself, so
     // the tiles_per_block launch option of the persistent kernels does not apply to it)
-    if (use_gemm256(a.M, a.Cd, 2, a.taps, a.mul, a.div_shift, a.klines)) {
+    if (allow_gemm256 && use_gemm256(a.M, a.Cd, 2, a.taps, a.mul, a.div_shift, a.klines)) {
       IgemmArgs b = a;
       b.ntn = a.Cd / 256;
       b.ntm = (a.M + 255) / 256;
+      // The partial last round: T = ntm x ntn tiles on nb CUs leave R = T mod nb tiles that would keep R CUs busy for a whole tile time
+      // (1568 tiles of a 2048-channel layer at bs = 64: 6.125 rounds).  When R is at most half a round and a whole number of pixel
+      // tiles, those pixel rows go to a second launch on the gathered-tile kernels (256 x 128 or smaller tiles: <= 2 R <= nb blocks of
+      // about 0.6 tile times), with every tensor pointer advanced to the tail's first row.  Same MFMA chain per output element.
+      const int nb = ps_num_cus();
+      const long long T = (long long)b.ntm * b.ntn, R = T % nb;
+      int tail_ptiles = 0;
+      if (g_gemm256_tail && T > nb && R > 0 && 2 * R <= nb && R % b.ntn == 0 && a.epi_M == a.M) tail_ptiles = (int)(R / b.ntn);
+      b.ntm -= tail_ptiles;
       hipLaunchKernelGGL((conv_gemm256_kernel<Tr>), dim3((unsigned)(b.ntm * b.ntn)), dim3(512), 2 * (256 * 128 + 256 * 128), s, b);
       PS_CHECK_LAUNCH("conv_gemm256");
+      if (tail_ptiles > 0) {
+        IgemmArgs c = a;
+        const int es = (int)sizeof(typename Tr::elem);
+        const long long m_off = (long long)b.ntm * 256;
+        c.m_off = (int)m_off;
+        c.src = a.src + m_off * a.pix_bytes;
+        c.src_bytes = (unsigned)(a.src_bytes - m_off * a.pix_bytes);
+        c.M = a.M - (int)m_off;
+        c.epi_M = c.M;
+        auto adv = [&](const void* ptr, int ldc) { return ptr ? static_cast<const void*>(static_cast<const unsigned char*>(ptr) + m_off * ldc * es) : nullptr; };
+        c.epi.add0 = adv(a.epi.add0, a.epi.ldc_add0);
+        c.epi.out_raw = const_cast<void*>(adv(a.epi.out_raw, a.epi.ldc_raw));
+        c.epi.mask_src = adv(a.epi.mask_src, a.epi.ldc_mask);
+        c.epi.add1 = adv(a.epi.add1, a.epi.ldc_add1);
+        c.epi.out = const_cast<void*>(adv(a.epi.out, a.epi.ldc_out));
+        return dispatch_bn<Tr>(c, s, false);
+      }
       return PS_OK;
     }
   }
@@ -2197,6 +2226,7 @@ extern "C" void ps_debug_set_ws(int v) { g_use_ws = v; }
 extern "C" void ps_debug_set_ws2(int v) { g_use_ws2 = v; }
 extern "C" void ps_debug_set_halo(int v) { g_use_halo = v; }
 extern "C" void ps_debug_set_gemm256(int v) { g_gemm256 = v; }
+extern "C" void ps_debug_set_gemm256_tail(int v) { g_gemm256_tail = v; }
 #ifdef PS_HALO_STAMPS
 extern "C" int ps_debug_read_stamps(unsigned long long* host_out) {  // 256 x 4 x 4 values; synchronises the device
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_halo_stamps), sizeof(g_halo_stamps)) == hipSuccess ? 0 : -2;

@@ -935,6 +935,51 @@ def test_gemm256_kernel_forced_on_small_problems(case, dtype):
 
 
 @debug_only
+@pytest.mark.selfcheck
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(21, 28, 28, 2048, 2048), (11, 28, 28, 2048, 4096)])  # 520 = 2 x 256 + 8 tiles; 544 = 2 x 256 + 32 tiles
+def test_gemm256_tail_rows_on_the_gathered_tile_kernels(case, dtype):
+    """A conv_gemm256_kernel launch whose tile count leaves a partial last round of at most half the CUs hands those pixel rows to a second
+    launch on the gathered-tile kernels (every tensor pointer advanced, `m_off` for the dropout image index): same MFMA chain per output
+    element, so forward (raw) and masked data gradient are BIT-IDENTICAL to the single launch; the dropout output up to the fold rounding."""
+    from pistoseg_amd import _lib, ops
+
+    lib = _lib.load()
+    n, h, w, cin, cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    D = dev()
+    x = torch.randn(n, h, w, cin, generator=g).to(D, dtype)
+    wf = (torch.randn(cout, 1, 1, cin, generator=g) * (2.0 / cin) ** 0.5).to(D, dtype)
+    res = torch.randn(n, h, w, cout, generator=g).to(D, dtype)
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).to(D), (torch.randn(cout, generator=g) * 0.1).to(D)
+    drop = ((torch.rand(n, cout, generator=g) > 0.3).float() / 0.7).to(D)
+    gy = torch.randn(n, h, w, cin, generator=g).to(D, dtype)       # data gradient of a layer with `cout` inputs: produces cout channels
+    wd = (torch.randn(cout, 1, 1, cin, generator=g) * 0.05).to(D, dtype)
+    mask = torch.relu(torch.randn(n, h, w, cout, generator=g)).to(D, dtype)
+    sc2 = (torch.rand(cout, generator=g) + 0.5).to(D)
+    spec, spec_t = ops.ConvSpec(cin, cout, 1, 1, 1), ops.ConvSpec(cout, cin, 1, 1, 1)
+    assert conv_variant(spec, dtype, n, h, w, "fwd") == V_GEMM256 and conv_variant(spec_t, dtype, n, h, w, "dgrad") == V_GEMM256
+
+    def run():
+        raw = torch.full((n, h, w, cout), float("nan"), device=D, dtype=dtype)
+        act = torch.full((n, h, w, cout), float("nan"), device=D, dtype=dtype)
+        ops.conv2d_fwd(spec, x, wf, add0=res, out_raw=raw, bn_scale=scale, bn_shift=shift, drop=drop, out_act=act)
+        gx = torch.full((n, h, w, cout), float("nan"), device=D, dtype=dtype)
+        ops.conv2d_dgrad(spec_t, gy, wd, (h, w), mask_src=mask, bn_scale=sc2, out=gx)
+        return raw, act, gx
+
+    try:
+        lib.ps_debug_set_gemm256_tail(1)
+        split = run()
+        lib.ps_debug_set_gemm256_tail(0)
+        single = run()
+    finally:
+        lib.ps_debug_set_gemm256_tail(1)
+    assert torch.equal(split[0], single[0]) and torch.equal(split[2], single[2])
+    assert not torch.isnan(split[1].float()).any() and rel_err(split[1].float(), single[1].float()) < 2.0 ** -9
+
+
+@debug_only
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("bm", [112, 128, 224, 256])
 @pytest.mark.parametrize("case", [(128, 256, 3, 2, 1), (256, 256, 3, 1, 2), (512, 128, 1, 1, 1)])

@@ -74,6 +74,7 @@ def main():
                     lib.ps_debug_set_ws2(1)
                     lib.ps_debug_set_halo(1)
                     lib.ps_debug_set_gemm256(1)
+                    lib.ps_debug_set_gemm256_tail(1)
                     lib.ps_debug_set_halo_ring(args.halo_ring)
                     lib.ps_debug_set_halo_tail(1)
                     lib.ps_debug_set_ablate(0)
