@@ -206,8 +206,7 @@ def _wgrad_workspace(nbytes: int, device) -> Tensor:
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _WGRAD_WS.get(key)
     if ws is None or ws.numel() < nbytes:
-        with torch.cuda.stream(torch.cuda.current_stream(device)):
-            ws = torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)
+        ws = torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)  # allocated on (= owned by) the current stream
         _WGRAD_WS[key] = ws
     return ws
 
