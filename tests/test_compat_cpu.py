@@ -134,3 +134,48 @@ def test_rfm_net_checkpoint_contract_under_dataparallel_wrapper(tmp_path):
         fresh.load_state_dict(sd)
     with pytest.raises(RuntimeError):
         Net(num_classes=4, precision="fp32").load_state_dict(state)
+
+
+def test_deterministic_switch_follows_torch_unless_forced():
+    """`ops.DETERMINISTIC = None` means: do what the reference's own switches say -- `torch.use_deterministic_algorithms(True)`
+    (revise_pseudo_labels.py:140-146) / `pl.Trainer(deterministic=True)` (segmentation_train.py:153-160) both set torch's flag; True / False
+    force it, an explicit per-call override wins."""
+    import torch
+
+    from pistoseg_amd import ops
+
+    prev_flag, prev = torch.are_deterministic_algorithms_enabled(), ops.DETERMINISTIC
+    try:
+        ops.DETERMINISTIC = None
+        torch.use_deterministic_algorithms(False)
+        assert ops.deterministic_enabled() is False
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        assert ops.deterministic_enabled() is True and ops.deterministic_enabled(False) is False
+        ops.DETERMINISTIC = False
+        assert ops.deterministic_enabled() is False and ops.deterministic_enabled(True) is True
+        ops.DETERMINISTIC = True
+        torch.use_deterministic_algorithms(False)
+        assert ops.deterministic_enabled() is True
+    finally:
+        ops.DETERMINISTIC = prev
+        torch.use_deterministic_algorithms(prev_flag)
+
+
+def test_gpu_suite_order_puts_parity_before_selfchecks_before_control_flow():
+    """conftest's collection order (the driver runs `pytest -x`): oracle / golden parity files first, `selfcheck` tests next, bench /
+    launcher / DDP control flow last."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "--collect-only", "-q", "-m", "gpu"], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT)
+    ids = [ln for ln in r.stdout.splitlines() if "::" in ln]
+    assert len(ids) > 400, r.stdout[-2000:]
+    files = [i.split("::")[0].split("/")[-1] for i in ids]
+    first_control = min(k for k, f in enumerate(files) if f in ("test_bench_gpu.py", "test_bench_launch.py", "test_ddp_gpu.py"))
+    assert all(f in ("test_bench_gpu.py", "test_bench_launch.py", "test_ddp_gpu.py") for f in files[first_control:])
+    assert files[0] == "test_ops_gpu.py"
+    # the known self-comparison tests sit between the parity block and the control-flow block
+    k_side = next(k for k, i in enumerate(ids) if "side_stream_weight_gradients" in i)
+    k_last_parity = max(k for k, i in enumerate(ids) if "test_contract_gpu.py" in i)
+    assert k_last_parity < k_side < first_control
