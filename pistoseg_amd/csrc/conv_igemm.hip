@@ -1386,15 +1386,16 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const IgemmArgs a)
       const int cout = n0 + (rowq & ~63) + 4 * WI * (rho >> 2) + 4 * fi + (rho & 3);
       woff[h][p] = (unsigned)(cout * (int)a.wrow_bytes) + chunk_off;
     }
-  auto stage_a = [&](int buf, int h, int kt) {
+  // pc: which of the wave's two pieces of the quarter (-1: both)
+  auto stage_a = [&](int buf, int h, int kt, int pc = -1) {
     unsigned char* dst = smem + buf * BUF + ((grp + 2 * h) * 64 + 2 * wc * 8) * 128;
-    BLDS16(rsA, dst, aoff[h][0], kt * 128);
-    BLDS16(rsA, dst + 1024, aoff[h][1], kt * 128);
+    if (pc != 1) BLDS16(rsA, dst, aoff[h][0], kt * 128);
+    if (pc != 0) BLDS16(rsA, dst + 1024, aoff[h][1], kt * 128);
   };
-  auto stage_b = [&](int buf, int h, int kt) {
+  auto stage_b = [&](int buf, int h, int kt, int pc = -1) {
     unsigned char* dst = smem + buf * BUF + A_BYTES + ((grp + 2 * h) * 64 + 2 * wc * 8) * 128;
-    BLDS16(rsB, dst, woff[h][0], kt * 128);
-    BLDS16(rsB, dst + 1024, woff[h][1], kt * 128);
+    if (pc != 1) BLDS16(rsB, dst, woff[h][0], kt * 128);
+    if (pc != 0) BLDS16(rsB, dst + 1024, woff[h][1], kt * 128);
   };
 
   // ---- fragments
@@ -1424,15 +1425,25 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const IgemmArgs a)
 #ifndef PS_GEMM256_PRIO
 #define PS_GEMM256_PRIO 1  // A/B builds: 0 = no priority change, 1 = the MFMA phase at priority 1 (default), 2 = the LOAD phase at priority 1
 #endif
-  auto mma_quadrant = [&](int msub, int nsub, const u32x4 (&w)[2][2]) {  // 16 MFMAs; the same accumulator recurs every 8th
+#ifndef PS_GEMM256_SPLIT_DMA
+#define PS_GEMM256_SPLIT_DMA 0  // A/B: 1 = a load phase issues ONE of the quarter's two LDS-DMA pieces, the compute phase the other (between its K-halves)
+#endif
+  // 16 MFMAs; the same accumulator recurs every 8th.  mid(): issued between the two K-halves (PS_GEMM256_SPLIT_DMA: the quarter's second piece)
+  auto mma_quadrant = [&](int msub, int nsub, const u32x4 (&w)[2][2], auto mid) {
     if constexpr (PS_GEMM256_PRIO == 1) __builtin_amdgcn_s_setprio(1);
     if constexpr (PS_GEMM256_PRIO == 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
+    for (int kh = 0; kh < 2; ++kh) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 2; ++i) Tr::mma(w[i][kh], xf[j][kh], acc[4 * msub + j][2 * nsub + i]);
+      if (kh == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        mid();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     if constexpr (PS_GEMM256_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     if constexpr (PS_GEMM256_PRIO == 2) __builtin_amdgcn_s_setprio(1);
   };
@@ -1441,8 +1452,13 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const IgemmArgs a)
   // overlaps the barrier -- except where the NEXT interval already re-stages what was just read: G1's B1 reads of L(q1) (interval
   // 8t + 3) and G0's LDS-DMA of L(q2) (interval 8t + 4) into the same rows; there the reads are drained before the barrier.
   auto end_load = [&](bool staged, bool drain_reads) {
-    if (staged) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (split DMA: the pieces of this load phase, of the previous compute phase and of the previous load phase may stay in flight)
+    if (staged) {
+      if constexpr (PS_GEMM256_SPLIT_DMA) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     if (drain_reads) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -1453,6 +1469,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const IgemmArgs a)
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
   };
+  constexpr int LP = PS_GEMM256_SPLIT_DMA ? 0 : -1;  // piece(s) issued by a load phase
 
   // ---- prologue: A(0), B(0), B(1)
   stage_a(0, 0, 0);
@@ -1474,27 +1491,27 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const IgemmArgs a)
     const bool s1 = t + 1 < NT, s2 = t + 2 < NT;
     // L(q0): A0
     read_x(cb, 0);
-    if (s1) stage_a(P ^ 1, 0, t + 1);
+    if (s1) stage_a(P ^ 1, 0, t + 1, LP);
     end_load(s1, false);
-    mma_quadrant(0, 0, wf0[P]);
+    mma_quadrant(0, 0, wf0[P], [&]() { if (PS_GEMM256_SPLIT_DMA && s1) stage_a(P ^ 1, 0, t + 1, 1); });
     end_compute();
     // L(q1): B1
     read_w(cb, 1, wf1);
-    if (s1) stage_a(P ^ 1, 1, t + 1);
+    if (s1) stage_a(P ^ 1, 1, t + 1, LP);
     end_load(s1, grp == 1);
-    mma_quadrant(0, 1, wf1);
+    mma_quadrant(0, 1, wf1, [&]() { if (PS_GEMM256_SPLIT_DMA && s1) stage_a(P ^ 1, 1, t + 1, 1); });
     end_compute();
     // L(q2): A1
     read_x(cb, 1);
-    if (s2) stage_b(P, 0, t + 2);
+    if (s2) stage_b(P, 0, t + 2, LP);
     end_load(s2, false);
-    mma_quadrant(1, 1, wf1);
+    mma_quadrant(1, 1, wf1, [&]() { if (PS_GEMM256_SPLIT_DMA && s2) stage_b(P, 0, t + 2, 1); });
     end_compute();
     // L(q3): B0 of the NEXT K-tile (resident since two K-tiles ago)
     if (s1) read_w(smem + (P ^ 1) * BUF, 0, wf0[P ^ 1]);
-    if (s2) stage_b(P, 1, t + 2);
+    if (s2) stage_b(P, 1, t + 2, LP);
     end_load(s2, false);
-    mma_quadrant(1, 0, wf0[P]);
+    mma_quadrant(1, 0, wf0[P], [&]() { if (PS_GEMM256_SPLIT_DMA && s2) stage_b(P, 1, t + 2, 1); });
     end_compute();
   };
   int t = 0;
