@@ -1514,12 +1514,79 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const IgemmArgs a)
     mma_quadrant(1, 0, wf0[P], [&]() { if (PS_GEMM256_SPLIT_DMA && s2) stage_b(P, 1, t + 2, 1); });
     end_compute();
   };
+#ifndef PS_GEMM256_PHASES
+#define PS_GEMM256_PHASES 8  // A/B: 4 = two load + two compute phases per K-tile (half tiles of 32 MFMAs) instead of four + four (quadrants of 16):
+                             // bit-identical results, EQUAL speed within 0.5 % on every layer (profiles/r03_gemm256_vs_ws2.txt) -- the barriers are not what a K-tile costs
+#endif
+  // Four-phase form: G0's intervals for K-tile t are 4t (L: B1, A0 + its two quarters of A(t+1)), 4t + 1 (C: A0 x B0, A0 x B1),
+  // 4t + 2 (L: A1, B0 of t + 1 + its two quarters of B(t+2)), 4t + 3 (C: A1 x B1, A1 x B0); G1 one interval later.  vmcnt(4) at the end
+  // of a load phase = only that phase's four pieces in flight, i.e. a piece has landed by the end of its wave's NEXT load phase and is
+  // visible one barrier later: A(t+1) quarters {0, 2} (issued 4t, visible 4t + 3, read from 4t + 4), {1, 3} (4t + 1 -> 4t + 4, read
+  // from 4t + 6); B(t+2) quarters {0, 2} (4t + 2 -> 4t + 5), {1, 3} (4t + 3 -> 4t + 6, B0(t+2) read from 4t + 6).  WAR: A(t-1)'s quarters
+  // were last read in 4t - 4 .. 4t - 1 (quarter 3 by G1 in 4t - 1, re-staged by G1 itself in 4t + 1); B(t) is last read by G1's B1 reads in
+  // 4t + 1 and re-staged by G0 in 4t + 2: G1 retires those four reads (issued FIRST: lgkmcnt(8)) before its barrier.
+  auto mma_half = [&](int msub, const u32x4 (&w0)[2][2], const u32x4 (&w1)[2][2]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) Tr::mma(w0[i][kh], xf[j][kh], acc[4 * msub + j][i]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) Tr::mma(w1[i][kh], xf[j][kh], acc[4 * msub + j][2 + i]);
+      }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto end_load4 = [&](bool staged, bool drain_first4) {
+    if (staged) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (drain_first4) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto ktile4 = [&](auto parity, int t) {
+    constexpr int P = decltype(parity)::value;
+    const unsigned char* cb = smem + P * BUF;
+    const bool s1 = t + 1 < NT, s2 = t + 2 < NT;
+    // L(h0): B1 (first: G1 retires these before the barrier), A0
+    read_w(cb, 1, wf1);
+    __builtin_amdgcn_sched_barrier(0);
+    read_x(cb, 0);
+    if (s1) {
+      stage_a(P ^ 1, 0, t + 1);
+      stage_a(P ^ 1, 1, t + 1);
+    }
+    end_load4(s1, grp == 1);
+    mma_half(0, wf0[P], wf1);
+    end_compute();
+    // L(h1): A1, B0 of the next K-tile
+    read_x(cb, 1);
+    if (s1) read_w(smem + (P ^ 1) * BUF, 0, wf0[P ^ 1]);
+    if (s2) {
+      stage_b(P, 0, t + 2);
+      stage_b(P, 1, t + 2);
+    }
+    end_load4(s2, false);
+    mma_half(1, wf0[P], wf1);
+    end_compute();
+  };
   int t = 0;
-  for (; t + 1 < NT; t += 2) {
-    ktile(std::integral_constant<int, 0>{}, t);
-    ktile(std::integral_constant<int, 1>{}, t + 1);
+  if constexpr (PS_GEMM256_PHASES == 4) {
+    for (; t + 1 < NT; t += 2) {
+      ktile4(std::integral_constant<int, 0>{}, t);
+      ktile4(std::integral_constant<int, 1>{}, t + 1);
+    }
+    if (t < NT) ktile4(std::integral_constant<int, 0>{}, t);
+  } else {
+    for (; t + 1 < NT; t += 2) {
+      ktile(std::integral_constant<int, 0>{}, t);
+      ktile(std::integral_constant<int, 1>{}, t + 1);
+    }
+    if (t < NT) ktile(std::integral_constant<int, 0>{}, t);
   }
-  if (t < NT) ktile(std::integral_constant<int, 0>{}, t);
   if (grp == 0) __builtin_amdgcn_s_barrier();
   if constexpr (HEAD) conv_head_epilogue<T, MI, WI>(a, acc, m0 + grp * 128, n0 + wc * 64, lane, tn * 4 + wc);
   else conv_epilogue<T, MI, WI, 0>(a, acc, m0 + grp * 128, n0 + wc * 64, lane);
