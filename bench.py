@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="skip the extra untimed pass that samples board power / shader clock (one GPU only)")
     ap.add_argument("--deterministic", action="store_true",
                     help="weight gradients without atomics (ps_conv2d_wgrad_det): the reference's Trainer(deterministic=True) / use_deterministic_algorithms(True)")
     ap.add_argument("--no-overlap", action="store_true", help="weight gradients on the launch stream instead of a second stream")
@@ -132,6 +133,69 @@ def pmc_traffic(kernel_label):
         if k == kernel_label or kernel_label.split("<")[0] in k:
             return {"bytes_per_launch": round(v["hbm_bytes_per_launch_corrected"]), "source": os.path.basename(files[-1])}
     return None
+
+
+def power_leg(run_step, seconds=1.5):
+    """Board power and shader clock while the SAME step keeps running, in an extra UNTIMED pass after the measurement (world 1 only): the MFMA
+    peak the roofline divides by assumes the 2.4 GHz boost clock, which the 1400 W package cap does not sustain on dense 16-bit MFMA work
+    (DESIGN 7.28, profiles/r03_power_probe.txt) -- this records where the run sat.  `rocm-smi` runs as a child process from a sampler thread;
+    None when it is missing or its output does not parse."""
+    import shutil
+    import subprocess
+    import threading
+
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return None
+
+    def query(*flags):
+        try:
+            r = subprocess.run([smi, *flags, "--json"], capture_output=True, text=True, timeout=10)
+            return next(iter(json.loads(r.stdout).values()))
+        except Exception:
+            return {}
+
+    def number(card, key_part, after_paren=False):
+        for k, v in card.items():
+            if key_part in k.lower():
+                txt = str(v).split("(")[-1] if after_paren else str(v)
+                digits = "".join(ch for ch in txt if ch.isdigit() or ch == ".")
+                try:
+                    return float(digits)
+                except ValueError:
+                    return None
+        return None
+
+    try:
+        cap = number(query("--showmaxpower"), "power")
+        got, stop = [], threading.Event()
+
+        def sampler():
+            time.sleep(0.3 * seconds)  # the governor settles within a few hundred ms
+            while not stop.is_set():
+                card = query("--showpower", "--showclocks")
+                got.append((number(card, "power"), number(card, "sclk", after_paren=True)))
+
+        th = threading.Thread(target=sampler, daemon=True)
+        th.start()
+        t0 = time.perf_counter()
+        steps = 0
+        while time.perf_counter() - t0 < seconds:
+            run_step()
+            steps += 1
+            if steps % 8 == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        stop.set()
+        th.join(timeout=15)
+        ps = [p for p, _ in got if p]
+        cs = [c for _, c in got if c]
+        if not ps:
+            return None
+        return {"mean_w": round(sum(ps) / len(ps)), "max_w": round(max(ps)), "cap_w": cap, "sclk_mhz_mean": round(sum(cs) / len(cs)) if cs else None,
+                "samples": len(ps), "source": "rocm-smi during an extra untimed pass of the same step"}
+    except Exception:
+        return None
 
 
 def roofline_leg(run_step, precision):
@@ -568,6 +632,8 @@ def main():
         out["roofline"] = roofline_leg(serial_step, args.precision)
     else:
         serial_step()  # keep ranks in lockstep through the instrumented step (it contains collectives)
+    if rank == 0 and world == 1 and not args.no_power:
+        out["power"] = power_leg(train_step)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_tiles, args.tile, args.classes)
     if dist_on:

@@ -32,6 +32,9 @@ def test_bench_json_contract_small_config():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r and "kernel" in r
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["unit"] == "tiles/s" and c["value"] > 0 and c["cores"] >= 1 and isinstance(c["sample"], str)
+    assert "power" in d  # board power / shader clock of an extra untimed pass; None where rocm-smi is unavailable
+    if d["power"] is not None:
+        assert 50 < d["power"]["mean_w"] <= d["power"]["max_w"] <= 1.05 * (d["power"]["cap_w"] or 2000) and d["power"]["samples"] >= 1
 
 
 def test_bench_rfm_workload_carries_roofline_and_cpu_baseline():

@@ -7,9 +7,9 @@
 set -o pipefail
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-PMC_ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-infer --no-overlap"
+PMC_ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-infer --no-overlap --no-power"
 # --- BASELINE configs[1]: bs=64 bf16 (the headline)
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-overlap > gpurun_out/${tag}_bench_train_bs64_bf16.json 2> gpurun_out/${tag}_bench_profiled.err &&
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-overlap --no-power > gpurun_out/${tag}_bench_train_bs64_bf16.json 2> gpurun_out/${tag}_bench_profiled.err &&
 cp $(find gpurun_out/prof_${tag} -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_bench_train_bs64_bf16_kernel_stats.csv &&
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_${tag}_fetch -- python bench.py $PMC_ARGS > /dev/null 2>&1 &&
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_${tag}_write -- python bench.py $PMC_ARGS > /dev/null 2>&1 &&
@@ -19,7 +19,7 @@ python tools/pmc_mfma_report.py gpurun_out/pmc_${tag}_mfma_1 > gpurun_out/${tag}
 python bench.py > gpurun_out/${tag}_bench_unprofiled.json 2> gpurun_out/${tag}_bench_unprofiled.err &&
 python tools/step_profile.py > gpurun_out/${tag}_step_profile_per_launch.txt 2>&1 &&
 # --- the PARITY path: fp32 storage, exact-f32 MFMA (157 TFLOP/s matrix peak)
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_fp32 -- python bench.py --precision fp32 --steps 3 --warmup 1 --no-cpu-baseline --no-overlap > gpurun_out/${tag}_bench_fp32_parity_path.json 2>> gpurun_out/${tag}_bench_profiled.err &&
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_fp32 -- python bench.py --precision fp32 --steps 3 --warmup 1 --no-cpu-baseline --no-overlap --no-power > gpurun_out/${tag}_bench_fp32_parity_path.json 2>> gpurun_out/${tag}_bench_profiled.err &&
 cp $(find gpurun_out/prof_${tag}_fp32 -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_bench_fp32_parity_path_kernel_stats.csv &&
 # --- BASELINE configs[4]: BCSS 4-class, fp16 MFMA path, bs=128 -- bench line + HBM / MFMA counters
 CFG5="--precision fp16 --classes 4 --batch 128"
