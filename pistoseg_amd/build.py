@@ -76,11 +76,14 @@ def build(force: bool = False, verbose: bool = True, debug: bool = True) -> str:
     return path
 
 
-def build_variant(tag: str, defines, verbose: bool = True) -> str:
-    """An A/B build of the debug library with extra -D defines: pistoseg_amd/libpistoseg_hip_debug_<tag>.so (load it with
-    PISTOSEG_HIP_DEBUG_LIB=<path>).  Optimisation harness only."""
-    lib = os.path.join(HERE, f"libpistoseg_hip_debug_{tag}.so")
+def build_variant(tag: str, defines, verbose: bool = True, product: bool = False) -> str:
+    """An A/B build with extra -D defines.  Debug library (default): pistoseg_amd/libpistoseg_hip_debug_<tag>.so, load it with
+    PISTOSEG_HIP_DEBUG_LIB=<path>.  product=True: the product library's flags, pistoseg_amd/libpistoseg_hip_<tag>.so, load it with
+    PISTOSEG_HIP_LIB=<path> (whole-step A/Bs through bench.py).  Optimisation harness only."""
     extra = [d if d.startswith("-") else f"-D{d}" for d in defines]  # NAME=VALUE -> -DNAME=VALUE; anything starting with '-' is a raw compiler flag
+    if product:
+        return _build_one(os.path.join(HERE, f"libpistoseg_hip_{tag}.so"), os.path.join(HERE, "build", "abp_" + tag), extra, False, verbose)
+    lib = os.path.join(HERE, f"libpistoseg_hip_debug_{tag}.so")
     return _build_one(lib, os.path.join(HERE, "build", "ab_" + tag), ["-DPS_DEBUG_HOOKS", *extra], False, verbose)
 
 

@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--variants", default="3stage=0,3stage=1")
     ap.add_argument("--layers", default="")
     ap.add_argument("--halo-ring", type=int, default=3)
+    ap.add_argument("--data", default="randn", choices=["randn", "relu", "zeros"],
+                    help="operand values: dense random | max(randn, 0) activations | all zeros.  The big kernels sit at the 1400 W package cap on random data "
+                         "(DESIGN 7.28): a sustained loop then measures energy per FLOP; --data zeros (2.4 GHz, ~950 W) measures CYCLES per FLOP")
     ap.add_argument("--epi", default="raw", help="raw: store only | full: fwd = +residual -> raw + BN/ReLU out, dgrad = ReLU mask + add1 -> out")
     args = ap.parse_args()
     lib = _lib.use_debug_library()  # the ps_debug_* switches live in libpistoseg_hip_debug.so only
@@ -42,10 +45,13 @@ def main():
         n = args.batch
         spec = ops.ConvSpec(cin, cout, k, s, d)
         ho, wo = spec.out_hw(H, H)
-        x = torch.randn(n, H, H, cin, device=D).to(dt)
-        wf = (torch.randn(cout, k, k, cin, device=D) * 0.02).to(dt)
-        wd = (torch.randn(cin, k, k, cout, device=D) * 0.02).to(dt)
-        gy = torch.randn(n, ho, wo, cout, device=D).to(dt)
+        rnd = {"randn": lambda *sh: torch.randn(*sh, device=D), "relu": lambda *sh: torch.randn(*sh, device=D).relu(),
+               "zeros": lambda *sh: torch.zeros(*sh, device=D)}[args.data]
+        wscale = 0.0 if args.data == "zeros" else 0.02
+        x = rnd(n, H, H, cin).to(dt)
+        wf = (torch.randn(cout, k, k, cin, device=D) * wscale).to(dt)
+        wd = (torch.randn(cin, k, k, cout, device=D) * wscale).to(dt)
+        gy = (torch.randn(n, ho, wo, cout, device=D) * (0.0 if args.data == "zeros" else 1.0)).to(dt)
         y = torch.empty(n, ho, wo, cout, device=D, dtype=dt)
         gx = torch.empty(n, H, H, cin, device=D, dtype=dt)
         dw = torch.zeros(cout, k, k, cin, device=D)
