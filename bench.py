@@ -151,7 +151,8 @@ def power_leg(run_step, seconds=1.5):
     def query(*flags):
         try:
             r = subprocess.run([smi, *flags, "--json"], capture_output=True, text=True, timeout=10)
-            return next(iter(json.loads(r.stdout).values()))
+            doc = [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")][-1]  # (a low-power-state warning line may precede the JSON)
+            return next(iter(json.loads(doc).values()))
         except Exception:
             return {}
 

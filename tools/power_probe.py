@@ -23,7 +23,7 @@ def sample():
     """(power W, sclk MHz) from rocm-smi's JSON; None where the field is missing."""
     r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True)
     try:
-        card = next(iter(json.loads(r.stdout).values()))
+        card = next(iter(json.loads([ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")][-1]).values()))
     except Exception:
         return None, None
     p = c = None
