@@ -14,7 +14,7 @@ model = ResNet38dSeg(3, "bf16"); init_weights_he(model, seed=42); model = model.
 tr = SegTrainer(model)
 x = torch.randn(64, 3, 224, 224, device=D); y = torch.randint(0, 4, (64, 224, 224), device=D)
 variants = sys.argv[1:] or ["base"]
-RESET = {"wgrad_raster": -1, "halo_tail": 1}
+RESET = {"wgrad_raster": -1, "halo_tail": 1, "supertile": 4, "wgrad_ovh": 16, "gemm256": 1, "gemm256_tail": 1, "wgrad256": 0}
 def apply(v):
     for k, d in RESET.items(): getattr(lib, "ps_debug_set_" + k)(d)
     if v != "base":
