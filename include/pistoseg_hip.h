@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PS_VERSION 210 /* major*10000 + minor*100 + patch */
+#define PS_VERSION 211 /* major*10000 + minor*100 + patch */
 
 typedef enum ps_status {
   PS_OK = 0,
@@ -66,6 +66,10 @@ typedef struct ps_conv_geom {
                             * GPU runs nothing else); n > 0 = blocks are dispatched in batches and take n work items each, so the
                             * hardware re-balances when another kernel (an RCCL all-reduce overlapping the backward) holds some CUs.
                             * Results are bit-identical for every value. */
+  int32_t gpu_shared;     /* launch option: 1 = another stream of this process keeps the GPU busy beside this launch (the weight gradients
+                            * of the two-stream backward): the partial last round of a launch is then NOT re-issued as a second launch of
+                            * smaller tiles -- the co-running kernel's blocks fill those CUs, and the split costs 2 % of a training step
+                            * (profiles/r03_tail_split_two_streams.txt).  0 = the launch has the GPU to itself.  Bit-identical results. */
 } ps_conv_geom;
 
 /* Epilogue applied to the f32 accumulator `acc` of every produced element (pixel m, channel c):

@@ -41,6 +41,7 @@ struct IgemmArgs {
   unsigned wgt_bytes;
   int ablate;                 // timing experiments only (results WRONG): 1 = stage the first two K-steps only; 2 = also no per-step barriers (ws kernel)
   int nb, tpb;                // persistent kernels: blocks per batch (#CUs), tiles per block (0 = one batch), see ps_block_items
+  int shared;                 // host side only (ps_conv_geom.gpu_shared): another stream fills this launch's partial last round -- no tail launch
   // stride-2 data gradient, one launch per output parity class (conv_igemm_ws2_kernel<.., SPLIT>): the produced grid Ho x Wo is the
   // class's sub-grid, pixel (p', q') of it is pixel (oy + 2p', ox + 2q') of the full Hf x Wf gradient, and only the taps in tap_mask
   // (those that hit dy at integer positions for this parity) are staged and multiplied.  epi_M = rows of the full tensor.
@@ -2043,6 +2044,7 @@ int check_geom(const ps_conv_geom* g) {
   PS_REQUIRE(g->dilation >= 1 && g->dilation <= 64, "conv: dilation %d unsupported", g->dilation);
   PS_REQUIRE(g->n > 0 && g->h > 0 && g->w > 0, "conv: empty input %dx%dx%d", g->n, g->h, g->w);
   PS_REQUIRE(g->tiles_per_block >= 0 && g->tiles_per_block <= 4096, "conv: tiles_per_block %d out of range", g->tiles_per_block);
+  PS_REQUIRE(g->gpu_shared == 0 || g->gpu_shared == 1, "conv: gpu_shared %d (0 or 1)", g->gpu_shared);
   const int es = ps_esize(g->dtype);
   PS_REQUIRE((g->cin * es) % 128 == 0 && (g->cout * es) % 128 == 0,
              "conv: cin=%d cout=%d must be multiples of %d channels", g->cin, g->cout, 128 / es);
@@ -2150,7 +2152,7 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s, bool allow_gemm256 = true) {
       const int nb = ps_num_cus();
       const long long T = (long long)b.ntm * b.ntn, R = T % nb;
       int tail_ptiles = 0;
-      if (g_gemm256_tail && T > nb && R > 0 && 2 * R <= nb && R % b.ntn == 0 && a.epi_M == a.M) tail_ptiles = (int)(R / b.ntn);
+      if (g_gemm256_tail && !a.shared && T > nb && R > 0 && 2 * R <= nb && R % b.ntn == 0 && a.epi_M == a.M) tail_ptiles = (int)(R / b.ntn);
       b.ntm -= tail_ptiles;
       hipLaunchKernelGGL((conv_gemm256_kernel<Tr>), dim3((unsigned)(b.ntm * b.ntn)), dim3(512), 2 * (256 * 128 + 256 * 128), s, b);
       PS_CHECK_LAUNCH("conv_gemm256");
@@ -2220,10 +2222,12 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s, bool allow_gemm256 = true) {
       // The partial last round.  With T = ntm x ntn tiles on nb CUs, R = T mod nb <= nb / 2 tiles would keep R CUs busy for a whole round
       // (512-channel layers at bs=64: 896 tiles = 3.5 rounds).  Those R tiles -- whole pixel tiles, R % ntn == 0 -- go to a second launch
       // as 2 R half tiles of 64 couts (half the MFMAs, 8 instead of 16 KiB of weights per K-step: ~0.6 of a round on every CU).
+      // Not while another stream of the process shares the GPU (gpu_shared: the two-stream backward): its blocks take the idle CUs, and the
+      // split then COSTS 2 % of a training step (profiles/r03_tail_split_two_streams.txt).
       int tail_ptiles = 0;
       if constexpr (sizeof(typename Tr::elem) == 2) {
         const long long T = (long long)b.ntm * b.ntn, R = T % b.nb;
-        if (g_halo_tail && a.tpb == 0 && T > b.nb && R > 0 && 2 * R <= b.nb && R % b.ntn == 0 && a.Cd % 64 == 0) tail_ptiles = (int)(R / b.ntn);
+        if (g_halo_tail && a.tpb == 0 && !a.shared && T > b.nb && R > 0 && 2 * R <= b.nb && R % b.ntn == 0 && a.Cd % 64 == 0) tail_ptiles = (int)(R / b.ntn);
       }
       b.ntm -= tail_ptiles;
       const dim3 hgrid(ps_persistent_grid((long long)b.ntm * b.ntn, b.nb, b.tpb));
@@ -2414,6 +2418,7 @@ extern "C" int ps_conv2d_fwd(const ps_conv_geom* g, const void* x, const void* w
   a.Cd = g->cout;
   a.epi = *epi;
   a.tpb = g->tiles_per_block;
+  a.shared = g->gpu_shared;
   if (int rc = set_extents(a, (long long)g->n * g->h * g->w * a.pix_bytes, (long long)g->cout * a.wrow_bytes, es)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (g->dtype == PS_BF16) return dispatch_bn<TraitsBF16>(a, s);
@@ -2484,6 +2489,7 @@ extern "C" int ps_conv2d_dgrad(const ps_conv_geom* g, const void* dy, const void
   a.Cd = g->cin;
   a.epi = *epi;
   a.tpb = g->tiles_per_block;
+  a.shared = g->gpu_shared;
   if (int rc = set_extents(a, (long long)g->n * a.Hs * a.Ws * a.pix_bytes, (long long)g->cin * a.wrow_bytes, es)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dgrad_s2_split_ok(g, epi)) return g->dtype == PS_BF16 ? dgrad_s2_split<TraitsBF16>(a, s) : dgrad_s2_split<TraitsF16>(a, s);

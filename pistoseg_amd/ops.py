@@ -99,10 +99,14 @@ class ConvSpec:
 # per CU lives for the whole launch; n > 0 while a communication kernel shares the GPU (set by dist.BucketedAllReduce between its first
 # bucket launch and finish()).  It is read when a launch is ENQUEUED, by the one host thread that enqueues this process's work.
 TILES_PER_BLOCK = 0
+# Launch option ps_conv_geom.gpu_shared: 1 while another stream of this process runs kernels beside the launch stream (set by the backbone's
+# two-stream backward between its first side-stream launch and the join): a launch's partial last round is then left to the co-running
+# kernel's blocks instead of being re-issued as smaller tiles.  Read when a launch is enqueued, like TILES_PER_BLOCK.
+GPU_SHARED = 0
 
 
 def _geom(spec: ConvSpec, dtype: int, n: int, h: int, w: int, ldc_x: int, ldc_y: int) -> ConvGeom:
-    return ConvGeom(dtype, n, h, w, spec.cin, spec.cout, spec.ksize, spec.stride, spec.dilation, ldc_x, ldc_y, TILES_PER_BLOCK)
+    return ConvGeom(dtype, n, h, w, spec.cin, spec.cout, spec.ksize, spec.stride, spec.dilation, ldc_x, ldc_y, TILES_PER_BLOCK, GPU_SHARED)
 
 
 def _epilogue(mode=PS_EPI_NONE, add0=None, out_raw=None, scale=None, shift=None, drop=None, mask_src=None, add1=None, out=None) -> Epilogue:

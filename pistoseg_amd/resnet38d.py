@@ -446,6 +446,17 @@ class Net(nn.Module):
         self.refresh_dgrad_weights()
         self._out_grad_buf = {k: v for k, v in self._out_grad_buf.items() if k == self.units[-1][0]}  # drop stale buffers of aborted steps
         dt, dev, n = G.dtype, G.device, saved.n
+        shared_before = ops.GPU_SHARED
+        if wgrad_stream is not None:
+            ops.GPU_SHARED = 1  # the data gradients' partial last rounds are filled by the side stream's weight-gradient blocks (ps_conv_geom.gpu_shared)
+        try:
+            self._backward_units(saved, G, grads, g_taps, after_unit, wgrad_stream, first, dt, dev, n)
+        finally:
+            ops.GPU_SHARED = shared_before
+        if wgrad_stream is not None:
+            torch.cuda.current_stream().wait_stream(wgrad_stream)
+
+    def _backward_units(self, saved, G, grads, g_taps, after_unit, wgrad_stream, first, dt, dev, n) -> None:
         for i in range(len(self.units) - 1, -1, -1):
             name, kind, cin, cmid, cout, stride, fdil, dil, _p = self.units[i]
             if i < first:
@@ -535,8 +546,6 @@ class Net(nn.Module):
                 else:
                     with torch.cuda.stream(wgrad_stream):
                         after_unit(name)
-        if wgrad_stream is not None:
-            torch.cuda.current_stream().wait_stream(wgrad_stream)
 
     def register_shadow(self, name: str, param: nn.Parameter, view: Tensor) -> None:
         """`view`: 16-bit [cout][kh][kw][cin] storage that a trainer keeps equal to `param` (cast by its fused optimiser)."""

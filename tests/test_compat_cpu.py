@@ -161,6 +161,46 @@ def test_deterministic_switch_follows_torch_unless_forced():
         torch.use_deterministic_algorithms(prev_flag)
 
 
+def test_gpu_shared_launch_option_reaches_the_geometry_and_is_restored(monkeypatch):
+    """`ops.GPU_SHARED` is the `gpu_shared` field of every `ps_conv_geom` built while it is set (include/pistoseg_hip.h), and the backbone's
+    two-stream backward sets it only for its own duration -- also when a launch raises."""
+    import torch
+
+    from pistoseg_amd import ops
+    from pistoseg_amd.resnet38d import Net
+
+    spec = ops.ConvSpec(512, 512, 3, 1, 1)
+    assert ops._geom(spec, 1, 2, 28, 28, 512, 512).gpu_shared == 0
+    monkeypatch.setattr(ops, "GPU_SHARED", 1)
+    g = ops._geom(spec, 1, 2, 28, 28, 512, 512)
+    assert g.gpu_shared == 1 and g.tiles_per_block == ops.TILES_PER_BLOCK
+    monkeypatch.setattr(ops, "GPU_SHARED", 0)
+
+    net = Net()
+    seen = []
+
+    def fake_units(self, saved, G, grads, g_taps, after_unit, wgrad_stream, first, dt, dev, n):
+        seen.append(ops.GPU_SHARED)
+        raise RuntimeError("launch failed")
+
+    monkeypatch.setattr(Net, "_backward_units", fake_units)
+    monkeypatch.setattr(Net, "refresh_dgrad_weights", lambda self: None)
+
+    class Saved:
+        n = 1
+
+    class FakeStream:  # stands for the side stream; never used because the unit loop is replaced
+        pass
+
+    G = torch.zeros(1, 4, 4, 8)
+    for stream, expect in ((None, 0), (FakeStream(), 1)):
+        try:
+            net.backward_backbone(Saved(), G, {}, wgrad_stream=stream)
+        except RuntimeError as e:
+            assert "launch failed" in str(e)
+        assert seen[-1] == expect and ops.GPU_SHARED == 0
+
+
 def test_gpu_suite_order_puts_parity_before_selfchecks_before_control_flow():
     """conftest's collection order (the driver runs `pytest -x`): oracle / golden parity files first, `selfcheck` tests next, bench /
     launcher / DDP control flow last."""

@@ -977,6 +977,12 @@ def test_gemm256_tail_rows_on_the_gathered_tile_kernels(case, dtype):
         lib.ps_debug_set_gemm256_tail(1)
     assert torch.equal(split[0], single[0]) and torch.equal(split[2], single[2])
     assert not torch.isnan(split[1].float()).any() and rel_err(split[1].float(), single[1].float()) < 2.0 ** -9
+    try:  # ps_conv_geom.gpu_shared = 1: the single-launch schedule through the launch option (what the two-stream backward asks for)
+        ops.GPU_SHARED = 1
+        shared = run()
+    finally:
+        ops.GPU_SHARED = 0
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(shared, single))
 
 
 @debug_only
@@ -1201,6 +1207,14 @@ def test_conv_halo_tail_as_half_tiles(case, dtype, library):
     else:
         split = [run() for _ in range(2)]
     assert all(torch.equal(a_, b_) for a_, b_ in zip(split[0], split[1]))
+    # the launch option ps_conv_geom.gpu_shared (another stream fills the partial last round: no tail launch) -- on the PRODUCT library this
+    # is the single-launch schedule, so the product's own split is checked bit for bit as well
+    try:
+        ops.GPU_SHARED = 1
+        shared = run()
+    finally:
+        ops.GPU_SHARED = 0
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(split[0], shared))
     tol = TOL[dtype]
     for a_, r_ in zip(split[0], (nhwc((y + res).detach()), nhwc(act.detach()), nhwc(gx_ref))):
         assert rel_err(a_.float().cpu(), r_) < tol

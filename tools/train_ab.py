@@ -1,6 +1,7 @@
 """Same-box A/B of debug-library switches on the whole training step:  python tools/train_ab.py name=value[,name=value] ...
 Each argument is one variant (comma-separated ps_debug_set_<name>(value) calls; the word `base` = no switch); the variants are run
-interleaved, 3 rounds x 10 steps each, and the best round per variant is printed.  bs = 64, 224 x 224, bf16, two-stream backward."""
+interleaved, 3 rounds x 10 steps each, and the best round per variant is printed.  bs = 64, 224 x 224, bf16, two-stream backward.
+--infer as the first argument: the no-grad forward (eval mode) instead of the training step; --serial: weight gradients on the launch stream."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,21 +14,42 @@ D = torch.device("cuda:0")
 model = ResNet38dSeg(3, "bf16"); init_weights_he(model, seed=42); model = model.to(D)
 tr = SegTrainer(model)
 x = torch.randn(64, 3, 224, 224, device=D); y = torch.randint(0, 4, (64, 224, 224), device=D)
-variants = sys.argv[1:] or ["base"]
+argv = sys.argv[1:]
+INFER = "--infer" in argv
+SERIAL = "--serial" in argv
+argv = [a for a in argv if a not in ("--infer", "--serial")]
+variants = argv or ["base"]
+if SERIAL:
+    tr.wgrad_stream = None
+if INFER:
+    model.eval()
+    def one():
+        with torch.no_grad(): model(x)
+else:
+    def one(): tr.train_step(x, y)
 RESET = {"wgrad_raster": -1, "halo_tail": 1, "supertile": 4, "wgrad_ovh": 16, "gemm256": 1, "gemm256_tail": 1, "wgrad256": 0}
+from pistoseg_amd import ops
+_geom = ops._geom
+def _geom_unshared(*a):  # A/B of the gpu_shared launch option: the pseudo-switch `gpu_shared=0` hides the two-stream backward's hint from the library
+    g = _geom(*a); g.gpu_shared = 0; return g
 def apply(v):
     for k, d in RESET.items(): getattr(lib, "ps_debug_set_" + k)(d)
+    ops._geom = _geom
     if v != "base":
         for kv in v.split(","):
-            k, val = kv.split("="); getattr(lib, "ps_debug_set_" + k)(int(val))
-for _ in range(5): tr.train_step(x, y)
+            k, val = kv.split("=")
+            if k == "gpu_shared":
+                ops._geom = _geom if int(val) else _geom_unshared
+            else:
+                getattr(lib, "ps_debug_set_" + k)(int(val))
+for _ in range(5): one()
 best = {v: 1e9 for v in variants}
 for r in range(3):
     for v in variants:
         apply(v)
-        tr.train_step(x, y); torch.cuda.synchronize()
+        one(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(10): tr.train_step(x, y)
+        for _ in range(10): one()
         torch.cuda.synchronize()
         best[v] = min(best[v], (time.perf_counter() - t0) / 10)
 apply("base")
