@@ -27,7 +27,7 @@ if INFER:
         with torch.no_grad(): model(x)
 else:
     def one(): tr.train_step(x, y)
-RESET = {"wgrad_raster": -1, "halo_tail": 1, "supertile": 4, "wgrad_ovh": 16, "gemm256": 1, "gemm256_tail": 1, "wgrad256": 0}
+RESET = {"wgrad_raster": -1, "halo_tail": 1, "supertile": 4, "wgrad_ovh": 16, "gemm256": 1, "gemm256_tail": 1, "wgrad256": 0, "gemm256_rule": 32 * 10000 + 1024}
 from pistoseg_amd import ops
 _geom = ops._geom
 def _geom_unshared(*a):  # A/B of the gpu_shared launch option: the pseudo-switch `gpu_shared=0` hides the two-stream backward's hint from the library
