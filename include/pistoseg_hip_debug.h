@@ -46,6 +46,7 @@ void ps_debug_set_gemm256(int v);
 /* Testing hook: gemm256's partial last round as a second launch on the gathered-tile kernels: 0 off, 1 (default) on. */
 void ps_debug_set_gemm256_tail(int v);
 void ps_debug_set_gemm256_rule(int code); /* the by-shape rule's thresholds: code = min K-lines (K / 64) * 10000 + min produced channels; default 32 * 10000 + 1024 */
+void ps_debug_set_gemm256_min_tiles(int v); /* the by-shape rule's minimum number of 256 x 256 tiles in a launch (default 384 = 1.5 rounds of the 256 CUs) */
 /* Tuning hook: weight ring depth of the halo kernel: 3, 4 or 5 stages of 16 KiB (256-pixel tiles: at most 4). */
 void ps_debug_set_halo_ring(int v);
 /* Testing hook: halo kernel, partial last round as a second launch of 64-cout half tiles: 0 off, 1 (default) on. */

@@ -157,6 +157,7 @@ DEBUG_PROTOTYPES = {
     "ps_debug_set_gemm256": (None, [C.c_int]),
     "ps_debug_set_gemm256_tail": (None, [C.c_int]),
     "ps_debug_set_gemm256_rule": (None, [C.c_int]),
+    "ps_debug_set_gemm256_min_tiles": (None, [C.c_int]),
     "ps_debug_set_halo_ring": (None, [C.c_int]),
     "ps_debug_set_halo_tail": (None, [C.c_int]),
     "ps_debug_set_s2split": (None, [C.c_int]),

@@ -2005,7 +2005,7 @@ PS_TUNABLE g_use_halo = 1;     // window + halo staging for 3x3 stride-1 layers 
 PS_TUNABLE g_halo_tail = 1;   // halo kernel: a partial last round (<= half the CUs) as a second launch of 64-cout half tiles: 0 off, 1 on
 PS_TUNABLE g_halo_ring = 3;   // weight ring depth of the halo kernel (3 | 4 | 5 stages of 16 KiB; 256-pixel tiles: <= 4)
 PS_TUNABLE g_gemm256 = 1;      // 256 x 256 tile kernel for the plain GEMMs (1x1 stride-1, 16-bit): 0 off, 1 by shape, 2 whenever legal
-PS_TUNABLE g_gemm256_min_klines = 32, g_gemm256_min_cd = 1024;  // the by-shape rule's thresholds: K / 64 and produced channels
+PS_TUNABLE g_gemm256_min_klines = 32, g_gemm256_min_cd = 1024, g_gemm256_min_tiles = 384;  // the by-shape rule's thresholds: K / 64 and produced channels
 PS_TUNABLE g_gemm256_tail = 1; // gemm256: a partial last round of at most half the CUs goes to a second launch on the gathered-tile kernels: 0 off, 1 on
 PS_TUNABLE g_use_3stage = 0;  // experimental 256x128 three-stage kernel: correct but slower than two 128x128 blocks per CU (r01 measurements)
 PS_TUNABLE g_ablate = 0;
@@ -2129,14 +2129,15 @@ static int pick_ws_variant(long long M, int Cd, int esize, bool halo_ok) {
 }
 
 // The 256 x 256 tile kernel serves plain GEMMs: one tap, no gather arithmetic, 16-bit operands, whole 256-cout tiles, K >= 256.
-// By shape (g_gemm256 == 1): K >= 2048 and >= 1024 produced channels (>= 512 tiles).  Measured r03 on sustained single-kernel loops
+// By shape (g_gemm256 == 1): K >= 2048, >= 1024 produced channels and >= 384 tiles (1.5 rounds of the 256 CUs; first 512: at bs = 32 the
+// 1024-channel layers have 392 tiles, and taking them is +1.0-1.2 % of a stage-3 step, profiles/r03_train_ab_gemm256_rule.txt).  Measured r03 on sustained single-kernel loops
 // (profiles/r03_gemm256_vs_ws2.txt): +13..27 % on the >= 2048-channel layers, +-5 % on the K = 1024 / 1024-channel ones; on the WHOLE step
 // (profiles/r03_train_ab_gemm256_rule.txt) the 1024-channel layers with K >= 2048 -- the data gradients 1024 <- 2048 / 2560 and the forward
 // 2048 -> 1024 -- are worth another +0.8-1.0 % of a training step, +0.3 % of an inference pass; K = 1024 layers stay on ws2 (no change).
 static bool use_gemm256(long long M, int Cd, int esize, int taps, int mul, int div_shift, int klines) {
   if (!g_gemm256 || g_use_glds != 2 || esize != 2 || taps != 1 || mul != 1 || div_shift != 0 || Cd % 256 != 0 || klines < 4) return false;
   if (g_gemm256 == 2) return true;
-  return ((M + 255) / 256) * (Cd / 256) >= 512 && klines >= g_gemm256_min_klines && Cd >= g_gemm256_min_cd;
+  return ((M + 255) / 256) * (Cd / 256) >= g_gemm256_min_tiles && klines >= g_gemm256_min_klines && Cd >= g_gemm256_min_cd;
 }
 
 template <typename Tr>
@@ -2319,6 +2320,7 @@ extern "C" void ps_debug_set_halo(int v) { g_use_halo = v; }
 extern "C" void ps_debug_set_gemm256(int v) { g_gemm256 = v; }
 extern "C" void ps_debug_set_gemm256_tail(int v) { g_gemm256_tail = v; }
 extern "C" void ps_debug_set_gemm256_rule(int code) { g_gemm256_min_klines = code / 10000; g_gemm256_min_cd = code % 10000; }
+extern "C" void ps_debug_set_gemm256_min_tiles(int v) { g_gemm256_min_tiles = v; }
 #ifdef PS_HALO_STAMPS
 extern "C" int ps_debug_read_stamps(unsigned long long* host_out) {  // 256 x 4 x 4 values; synchronises the device
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_halo_stamps), sizeof(g_halo_stamps)) == hipSuccess ? 0 : -2;

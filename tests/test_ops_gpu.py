@@ -700,7 +700,8 @@ def test_wgrad_deterministic_mode(case, dtype, library):
     ((17, 32, 32, 64, 512, 3, 1, 4), "halo"),     # 256-pixel tiles (the maps of 256 x 256 inputs), dilation 4
     ((11, 28, 28, 2048, 4096, 1, 1, 1), "gemm256"), # b7's 1x1 shape: the 256 x 256 tile GEMM kernel, 33.7 pixel tiles (ragged)
     ((21, 28, 28, 2048, 2048, 1, 1, 1), "gemm256"), # odd image count: ragged last pixel tile (64.3 tiles of 256 pixels)
-    ((42, 28, 28, 2048, 1024, 1, 1, 1), "gemm256"), # 1024 produced channels, K = 2048: 129 x 4 = 516 tiles, the rule's lower edge
+    ((32, 28, 28, 2048, 1024, 1, 1, 1), "gemm256"), # 1024 produced channels, K = 2048 at the stage-3 batch: 98 x 4 = 392 tiles, the rule's lower edge (384)
+    ((31, 28, 28, 2048, 1024, 1, 1, 1), "ws2"),     # ... and one image fewer: 95 x 4 = 380 tiles -> the large-tile persistent kernel
     ((37, 28, 28, 512, 1024, 1, 1, 1), "ws2"),      # K = 512: below the 256 x 256 kernel's range -> ws2, ragged last pixel tile
     ((21, 56, 56, 256, 512, 3, 2, 1), "ws2"),       # stride-2 3x3 (b4's first conv)
 ])
