@@ -42,7 +42,8 @@ GFLOP_TRAIN_PER_TILE = 556.28  # fwd + dgrad + wgrad, frozen conv1a/b2* skipped
 # launch, barriers, MAX-over-ranks timing, lockstep instrumented step, teardown) is exercised by tests/test_bench_launch.py.  Such a run's
 # numbers mean nothing and its JSON line says so ("test_backend").
 TEST_BACKEND = os.environ.get("PISTOSEG_BENCH_TEST_BACKEND") or None
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}  # /opt/skills/guides/MI355X_MICROARCH.md, dense
+# /opt/skills/guides/MI355X_MICROARCH.md, dense.  bf16x3 (split bf16: three 16-bit MFMAs per algorithmic product) is priced at a third of the bf16 peak
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3.0}
 
 
 def parse():
@@ -53,7 +54,13 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="tiles per GPU per step")
     ap.add_argument("--tile", type=int, default=224)
     ap.add_argument("--classes", type=int, default=3)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--dataset", default=None, choices=["wsss4luad", "bcss"],
+                    help="CE variant of SegmentationModule (models/segmentation_module.py:63-66): wsss4luad = CrossEntropyLoss(ignore_index=3) with "
+                         "targets 0..3 (3 = white background, ignored); bcss = CrossEntropyLoss() without an ignore index, targets 0..classes-1.  "
+                         "Default: wsss4luad for 3 classes, bcss otherwise (BASELINE configs[4])")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32", "bf16x3"],
+                    help="bf16 / fp16: 16-bit storage, f32 accumulate (throughput); fp32: exact-f32 MFMA; bf16x3: split bf16 (hi + lo planes, three MFMAs per "
+                         "product) -- the two last meet the reference's fp32 results to 1e-4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
     ap.add_argument("--no-power", action="store_true", help="skip the extra untimed pass that samples board power / shader clock (one GPU only)")
@@ -147,10 +154,16 @@ def power_leg(run_step, seconds=1.5):
     smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
     if not os.path.exists(smi):
         return None
+    # Under a profiler (rocprofv3 preloads its library and sets ROCP_* / ROCPROFILER_*) the extra untimed steps would land in the trace and
+    # the sampler's child processes would inherit the preload: skip the leg there, whatever the command line says.
+    env = os.environ
+    if "rocprof" in env.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCP_", "ROCPROFILER_", "ROCPROF_")) for k in env):
+        return {"skipped": "profiler preload detected"}
+    child_env = {k: v for k, v in env.items() if k != "LD_PRELOAD"}
 
     def query(*flags):
         try:
-            r = subprocess.run([smi, *flags, "--json"], capture_output=True, text=True, timeout=10)
+            r = subprocess.run([smi, *flags, "--json"], capture_output=True, text=True, timeout=10, env=child_env)
             doc = [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")][-1]  # (a low-power-state warning line may precede the JSON)
             return next(iter(json.loads(doc).values()))
         except Exception:
@@ -220,7 +233,7 @@ def roofline_leg(run_step, precision):
     kernels = {k: {"launches": v["launches"], "avg_us": round(1e3 * v["ms"] / v["launches"], 1),
                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in per.items()}
     return {
-        "bound": "mfma", "kernel": name, "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
+        "bound": "mfma", "kernel": name, "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": pmc_traffic(name),
         "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / d["launches"], 1),
         "launch_note": "a launch = one C-ABI call; a halo conv launch is one main dispatch (128-cout tiles) plus, for layers whose tile count leaves a "
@@ -229,7 +242,13 @@ def roofline_leg(run_step, precision):
     }
 
 
-def cpu_baseline(tiles, tile, classes):
+def ce_variant(args):
+    """(ignore_index, exclusive upper bound of the synthetic targets) of the reference's CE for this dataset branch."""
+    ds = args.dataset or ("wsss4luad" if args.classes == 3 else "bcss")
+    return (args.classes, args.classes + 1) if ds == "wsss4luad" else (None, args.classes)
+
+
+def cpu_baseline(tiles, tile, classes, ignore_index, target_hi):
     """The CPU oracle's training step (fwd + CE + bwd + AdamW) on a bounded sample; oracle = checker, timed beside:
     bs = `tiles` (8), one warm-up step then three timed steps with all host threads (the `value` = tiles / median step), the forward
     alone timed the same way; then the same on two threads -- the setting the reference's own entry scripts pin
@@ -243,12 +262,12 @@ def cpu_baseline(tiles, tile, classes):
     opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=0.05)
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(tiles, 3, tile, tile, generator=g)
-    y = torch.randint(0, classes + 1, (tiles, tile, tile), generator=g)
+    y = torch.randint(0, target_hi, (tiles, tile, tile), generator=g)
 
     def step(xb, yb):
         t0 = time.perf_counter()
         opt.zero_grad(set_to_none=True)
-        loss = ref_cpu.seg_ce_loss(ref_cpu.seg_forward(sd, xb), yb, classes)
+        loss = ref_cpu.seg_ce_loss(ref_cpu.seg_forward(sd, xb), yb, ignore_index)
         loss.backward()
         opt.step()
         return time.perf_counter() - t0
@@ -335,12 +354,15 @@ def rfm_bench(args, world, rank, dev, dist_on):
         step()
     dt = timed(step, args.steps, dist_on)
 
-    def serial_step():  # the instrumented step runs the weight gradients on the launch stream: per-kernel times are exclusive
+    def serial_step():  # weight gradients on the launch stream (exclusive per-kernel times), launch schedule of the timed two-stream step (gpu_shared)
+        from pistoseg_amd import ops
+
         ws, tr.wgrad_stream = tr.wgrad_stream, None
+        shared, ops.GPU_SHARED = ops.GPU_SHARED, (1 if ws is not None else ops.GPU_SHARED)
         try:
             step()
         finally:
-            tr.wgrad_stream = ws
+            tr.wgrad_stream, ops.GPU_SHARED = ws, shared
 
     roof = None
     if rank == 0:
@@ -577,12 +599,13 @@ def main():
     model = ResNet38dSeg(classes=args.classes, precision=args.precision)
     init_weights_he(model, seed=42)
     model = model.to(dev)
-    trainer = SegTrainer(model, lr=1e-3, weight_decay=0.05, ignore_index=args.classes,
+    ignore_index, target_hi = ce_variant(args)
+    trainer = SegTrainer(model, lr=1e-3, weight_decay=0.05, ignore_index=ignore_index,
                          process_group=torch.distributed.group.WORLD if dist_on else None, overlap_wgrad=not args.no_overlap,
                          deterministic=args.deterministic)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     x = torch.randn(args.batch, 3, args.tile, args.tile, generator=g).to(dev)
-    y = torch.randint(0, args.classes + 1, (args.batch, args.tile, args.tile), generator=g).to(dev)
+    y = torch.randint(0, target_hi, (args.batch, args.tile, args.tile), generator=g).to(dev)
 
     def train_step():
         trainer.train_step(x, y)
@@ -599,7 +622,7 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "ms_per_step_median_hip_events": round(timed.median_ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{1 if (args.classes, args.precision, args.batch) == (3, 'bf16', 64) else 4}]: segmentation_train.py step, "
-                               f"ResNet38-d seg model, {args.classes}-class CE(ignore={args.classes}), AdamW, random-init",
+                               f"ResNet38-d seg model, {args.classes}-class CE(ignore_index={ignore_index}), targets 0..{target_hi - 1}, AdamW, random-init",
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "tile": args.tile, "parallelism": f"dp{world}",
                    "deterministic": bool(args.deterministic)},
         "train_conv_tflops_per_gpu": round(value / world * GFLOP_TRAIN_PER_TILE * (args.tile / 224.0) ** 2 / 1e3, 1),
@@ -622,12 +645,18 @@ def main():
         out["infer_ms_per_step_median_hip_events"] = round(timed.median_ms, 3)
         model.train()
 
-    def serial_step():  # the instrumented step runs the weight gradients on the launch stream: per-kernel times are exclusive
+    def serial_step():
+        """The instrumented step runs the weight gradients on the launch stream (per-kernel times are exclusive) but keeps the launch
+        schedule of the timed two-stream step: `gpu_shared` stays set, so the halo / gemm256 partial last rounds are NOT re-issued as tail
+        launches -- the roofline table describes the same dispatches as the headline tiles/s."""
+        from pistoseg_amd import ops
+
         ws, trainer.wgrad_stream = trainer.wgrad_stream, None
+        shared, ops.GPU_SHARED = ops.GPU_SHARED, (1 if ws is not None else ops.GPU_SHARED)
         try:
             train_step()
         finally:
-            trainer.wgrad_stream = ws
+            trainer.wgrad_stream, ops.GPU_SHARED = ws, shared
 
     if rank == 0:
         out["roofline"] = roofline_leg(serial_step, args.precision)
@@ -636,7 +665,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_power:
         out["power"] = power_leg(train_step)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_tiles, args.tile, args.classes)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_tiles, args.tile, args.classes, ignore_index, target_hi)
     if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

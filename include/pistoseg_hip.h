@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PS_VERSION 211 /* major*10000 + minor*100 + patch */
+#define PS_VERSION 220 /* major*10000 + minor*100 + patch */
 
 typedef enum ps_status {
   PS_OK = 0,
@@ -39,7 +39,17 @@ typedef enum ps_status {
   PS_ERR_NOGPU = -3    /* no gfx950 device visible */
 } ps_status;
 
-typedef enum ps_dtype { PS_F32 = 0, PS_BF16 = 1, PS_F16 = 2 } ps_dtype;
+typedef enum ps_dtype {
+  PS_F32 = 0, PS_BF16 = 1, PS_F16 = 2,
+  /* Split-bf16 ("bf16x3") -- convolutions only (ps_conv2d_fwd / ps_conv2d_dgrad; the weight gradient runs as three PS_BF16 launches on
+   * plane slices).  A tensor of C logical channels stores 3 C bf16 channels per pixel: planes [hi | lo | hi], hi = bf16(v),
+   * lo = bf16(v - hi), value = hi + lo (16 mantissa bits); channel strides count bf16 elements (>= 3 C).  Weights: W_fwd[cout][tap][3 cin]
+   * as [hi | hi | lo] per tap (ps_split_f32, pattern 1), likewise W_dgrad[cin][tap][3 cout].  The kernels contract the 3 C channels as ONE
+   * bf16 GEMM with f32 accumulation, i.e. every product is x_hi w_hi + x_lo w_hi + x_hi w_lo (relative error ~2^-16 instead of bf16's
+   * 2^-8 at 3 MFMAs per product): the path that meets the reference's fp32 results to 1e-4 (models/resnet38d.py:156-188 computes in fp32)
+   * at 16-bit MFMA speed / 3.  Epilogue tensors (add0, out_raw, mask_src, add1, out) are split tensors of `produced channels` planes. */
+  PS_BF16X3 = 3
+} ps_dtype;
 
 int ps_version(void);
 const char* ps_last_error(void);
@@ -148,6 +158,14 @@ typedef struct ps_wt_item {
   int32_t cout, taps, cin, dst_ld;
 } ps_wt_item;
 int ps_weight_transpose_batched(int32_t src_dtype, int32_t dst_dtype, int32_t n_items, const ps_wt_item* items, void* stream);
+/* Row-wise conversion between f32 and a storage format (exactly one side is PS_F32): rows of c logical channels (c % 8 == 0), pitches
+ * ld_src / ld_dst in ELEMENTS of the respective side (channel slices of wider buffers are fine).  f32 -> PS_BF16 / PS_F16 (RNE cast),
+ * f32 -> PS_BF16X3 (three bf16 planes of c channels: pattern 0 = [hi | lo | hi], the activation layout; pattern 1 = [hi | hi | lo], the weight
+ * layout; hi = bf16(v), lo = bf16(v - hi)) and back (16-bit -> f32 exactly; split -> hi + lo).
+ * replaces: nothing in the reference (it computes in fp32 throughout, models/resnet38d.py:156-188); this is the edge between the split /
+ * 16-bit conv stack and the f32 head, loss and RFM kernels (models/revise_net.py:50-75), and the weight layout maker of the split path. */
+int ps_convert_rows(const void* src, int32_t src_fmt, int64_t ld_src, void* dst, int32_t dst_fmt, int64_t ld_dst, int64_t rows, int32_t c,
+                    int32_t pattern, void* stream);
 /* Strided row copy: dst[r][0..row_bytes) = src[r][0..row_bytes), r < rows (pitches in bytes; everything a multiple of 16).  Used to lay
  * two weight matrices side by side along K, so that a bottleneck unit's shortcut conv and its last 1x1 conv (and their data gradients)
  * run as ONE GEMM over concatenated channels (models/resnet38d.py:76-97: `branch1 + branch2`). */

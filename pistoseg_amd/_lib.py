@@ -17,7 +17,7 @@ import torch  # noqa: F401  (side effect: loads the HIP runtime torch uses)
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PISTOSEG_HIP_LIB") or os.path.join(HERE, "libpistoseg_hip.so")  # override: A/B-testing another build
 
-PS_F32, PS_BF16, PS_F16 = 0, 1, 2
+PS_F32, PS_BF16, PS_F16, PS_BF16X3 = 0, 1, 2, 3  # PS_BF16X3: split-bf16 conv format (planes [hi | lo | hi]; include/pistoseg_hip.h)
 PS_EPI_NONE, PS_EPI_BNRELU, PS_EPI_RELUBWD = 0, 1, 2
 PS_MASK_PLAIN, PS_MASK_MUL, PS_MASK_FILL = 0, 1, 2
 
@@ -89,6 +89,7 @@ PROTOTYPES = {
     "ps_conv2d_wgrad_det": (C.c_int, [C.POINTER(ConvGeom), _P, _P, _P, _P, _L, _P]),
     "ps_weight_transpose": (C.c_int, [_I, _I, _P, _P, _I, _I, _I, _P]),
     "ps_weight_transpose_batched": (C.c_int, [_I, _I, _I, C.POINTER(WtItem), _P]),
+    "ps_convert_rows": (C.c_int, [_P, _I, _L, _P, _I, _L, _L, _I, _I, _P]),
     "ps_copy_rows": (C.c_int, [_P, _L, _P, _L, _L, _L, _P]),
     "ps_cast_f32_bf16": (C.c_int, [_P, _P, _L, _P]),
     "ps_cast_f32_lowp": (C.c_int, [_P, _P, _I, _L, _P]),

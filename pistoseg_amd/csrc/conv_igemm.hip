@@ -72,20 +72,34 @@ __device__ __forceinline__ void ps_tile_of_block(int bid, int ntn, int ntm, int&
   }
 }
 
+// Epilogue storage tag of the split-bf16 path (PS_BF16X3): a tensor of C logical channels is three planes of C bf16 channels per pixel,
+// [hi | lo | hi] with hi = bf16(v), lo = bf16(v - hi) (the value is hi + lo, 16 mantissa bits); the duplicated hi plane is what lets the
+// unmodified K loop of every kernel compute x_hi w_hi + x_lo w_hi + x_hi w_lo as ONE bf16 contraction over 3 C channels against weights
+// laid out [hi | hi | lo] per tap (f32 accumulate).  sizeof == 1 so that the `sizeof(T) == 2` 16-bit fast paths do not take it.
+struct bf16x3_t {};
+
 struct TraitsBF16 {
   typedef __bf16 elem;
+  typedef __bf16 epi;
   static __device__ __forceinline__ void mma(const u32x4& w, const u32x4& x, f32x4& acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
   }
 };
+struct TraitsBF16X3 {  // K loop of TraitsBF16 over 3 x the channels, split epilogue
+  typedef __bf16 elem;
+  typedef bf16x3_t epi;
+  static __device__ __forceinline__ void mma(const u32x4& w, const u32x4& x, f32x4& acc) { TraitsBF16::mma(w, x, acc); }
+};
 struct TraitsF16 {
   typedef _Float16 elem;
+  typedef _Float16 epi;
   static __device__ __forceinline__ void mma(const u32x4& w, const u32x4& x, f32x4& acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
   }
 };
 struct TraitsF32 {
   typedef float elem;
+  typedef float epi;
   // a 16-byte chunk holds 4 consecutive k of this lane's row; MFMA j consumes element j of both operands,
   // i.e. k = 4*(chunk) + j for lane group (lane>>4): every k of the K-line is visited exactly once.
   static __device__ __forceinline__ void mma(const u32x4& w, const u32x4& x, f32x4& acc) {
@@ -123,14 +137,28 @@ constexpr unsigned PAD_ROW = 0x80000000u;
 // Eight consecutive tensor elements as loaded through a buffer descriptor (no conversion until they are needed).
 template <typename T>
 struct Raw8 {
-  static constexpr int NQ = sizeof(T) / 2;  // 16-byte quads
+  static constexpr bool X3 = std::is_same<T, bf16x3_t>::value;
+  static constexpr int NQ = X3 ? 2 : sizeof(T) / 2;  // 16-byte quads (split: the hi and the lo plane's)
   u32x4 q[NQ];
-  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int voff) {
+  // plane: byte distance between the planes of a split tensor (ignored by the plain types), wave-uniform.  It travels in the buffer
+  // instruction's scalar offset, which takes no part in the range check: a row past the end is dropped through its lane offset alone.
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int voff, int plane = 0) {
+    if constexpr (X3) {
+      q[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+      q[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, plane, 0);  // plane distance as the instruction's SCALAR offset: no second address register
+    } else {
 #pragma unroll
-    for (int k = 0; k < NQ; ++k) q[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16 * k, 0, 0);
+      for (int k = 0; k < NQ; ++k) q[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16 * k, 0, 0);
+    }
   }
   __device__ __forceinline__ void unpack(float* v) const {
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (X3) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(q[0][i] << 16) + __uint_as_float(q[1][i] << 16);
+        v[2 * i + 1] = __uint_as_float(q[0][i] & 0xffff0000u) + __uint_as_float(q[1][i] & 0xffff0000u);
+      }
+    } else if constexpr (sizeof(T) == 4) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = __uint_as_float(q[i >> 2][i & 3]);
     } else if constexpr (std::is_same<T, __bf16>::value) {
@@ -145,8 +173,20 @@ struct Raw8 {
       for (int i = 0; i < 8; ++i) v[i] = static_cast<float>(h[i]);
     }
   }
-  static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rs, int voff, const float* v) {
-    if constexpr (sizeof(T) == 4) {
+  static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rs, int voff, const float* v, int plane = 0) {
+    if constexpr (X3) {
+      u32x4 hi, lo;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t h0 = ps_f32_to_bf16(v[2 * i]), h1 = ps_f32_to_bf16(v[2 * i + 1]);
+        const uint32_t l0 = ps_f32_to_bf16(v[2 * i] - __uint_as_float(h0 << 16)), l1 = ps_f32_to_bf16(v[2 * i + 1] - __uint_as_float(h1 << 16));
+        hi[i] = h0 | (h1 << 16);
+        lo[i] = l0 | (l1 << 16);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(hi, rs, voff, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(lo, rs, voff, plane, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(hi, rs, voff, 2 * plane, 0);
+    } else if constexpr (sizeof(T) == 4) {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const u32x4 d = {__float_as_uint(v[4 * k]), __float_as_uint(v[4 * k + 1]), __float_as_uint(v[4 * k + 2]), __float_as_uint(v[4 * k + 3])};
@@ -178,10 +218,12 @@ template <typename T, int MI, int WI, int MAP = 0, int CW = (sizeof(T) == 2 ? 4 
 __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[MI][WI], int mbase, int cbase, int lane) {
   constexpr bool COLMAP = MAP == 1;
   constexpr int CH = 4 * WI;  // 16 or 8 channels per lane, handled CW at a time
-  constexpr int NO = CW / 8, ES = (int)sizeof(T);
+  constexpr bool X3 = std::is_same<T, bf16x3_t>::value;  // split tensors: planes [hi | lo | hi], a.Cd channels apart (see bf16x3_t)
+  constexpr int NO = CW / 8, ES = X3 ? 2 : (int)sizeof(T);
   static_assert(CW % 8 == 0 && CH % CW == 0, "channel chunk");
   const int frow = lane & 15, g = lane >> 4;
   const ps_epilogue& e = a.epi;
+  const int plane = a.Cd * ES;
   const int row0 = COLMAP ? mbase + (frow & 7) * a.Wo + (frow >> 3) : mbase + frow;  // row of fragment mi: row0 + mi * RSTEP
   constexpr int RSTEP = COLMAP ? 2 : 16;
   // MAP 2: fragment row mi is pixel m = row0 + 16 mi of the class's sub-grid -> row rrow[mi] of the full tensor (epi_M = dropped)
@@ -231,14 +273,14 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
     }
     // Row loads run LW rows ahead of their use (a row's registers are refilled with row + LW as soon as it has been consumed):
     // every load still precedes every store, with LW instead of MI rows of operands live.
-    constexpr int LW = MI < 4 ? MI : 4;
+    constexpr int LW = X3 ? (MI < 2 ? MI : 2) : (MI < 4 ? MI : 4);  // (split tensors: two quads per row and hi / lo temporaries at the stores)
     auto add_rows = [&](const void* base, int ldc) {  // acc += tensor rows
       const __amdgpu_buffer_rsrc_t rs = rsrc(base, ldc);
       Raw8<T> t[LW][NO];
 #pragma unroll
       for (int mi = 0; mi < LW; ++mi)
 #pragma unroll
-        for (int o = 0; o < NO; ++o) t[mi][o].load(rs, roff(mi, ldc, cb) + 8 * o * ES);
+        for (int o = 0; o < NO; ++o) t[mi][o].load(rs, roff(mi, ldc, cb) + 8 * o * ES, plane);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -247,7 +289,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
           t[mi % LW][o].unpack(f);
 #pragma unroll
           for (int i = 0; i < 8; ++i) acc[mi][(c0 + 8 * o + i) / 4][i & 3] += f[i];
-          if (mi + LW < MI) t[mi % LW][o].load(rs, roff(mi + LW, ldc, cb) + 8 * o * ES);
+          if (mi + LW < MI) t[mi % LW][o].load(rs, roff(mi + LW, ldc, cb) + 8 * o * ES, plane);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -265,7 +307,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
             const float y = fmaxf(x * sc[8 * o + i] + sh[8 * o + i], 0.f);
             f[i] = bnrelu ? y : x;
           }
-          Raw8<T>::store(rs, roff(mi, ldc, cb) + 8 * o * ES, f);
+          Raw8<T>::store(rs, roff(mi, ldc, cb) + 8 * o * ES, f, plane);
         }
     };
     if (e.add0) add_rows(e.add0, e.ldc_add0);
@@ -283,6 +325,34 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
     if (e.drop && !fold) {
       // dropout, rows of more than one image: per-row multipliers, row by row
       const int hw = a.Ho * a.Wo;
+      auto ld8 = [&](const void* base, int ldc, int m, int c, float* v) {  // 8 channels c.. of row m
+        if constexpr (X3) {
+          const __bf16* p = reinterpret_cast<const __bf16*>(base) + (long long)m * ldc + c;
+          float lo[8];
+          ps_load8<__bf16>(p, v);
+          ps_load8<__bf16>(p + a.Cd, lo);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] += lo[i];
+        } else {
+          ps_load8<T>(reinterpret_cast<const T*>(base) + (long long)m * ldc + c, v);
+        }
+      };
+      auto st8 = [&](void* base, int ldc, int m, int c, const float* v) {
+        if constexpr (X3) {
+          __bf16* p = reinterpret_cast<__bf16*>(base) + (long long)m * ldc + c;
+          float hi[8], lo[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            hi[i] = ps_bf16_to_f32(ps_f32_to_bf16(v[i]));
+            lo[i] = v[i] - hi[i];
+          }
+          ps_store8<__bf16>(p, hi);
+          ps_store8<__bf16>(p + a.Cd, lo);
+          ps_store8<__bf16>(p + 2 * a.Cd, hi);
+        } else {
+          ps_store8<T>(reinterpret_cast<T*>(base) + (long long)m * ldc + c, v);
+        }
+      };
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const int m = row0 + mi * RSTEP;  // (MAP 2 never comes with dropout: the host keeps such launches on the plain path)
@@ -297,19 +367,19 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
         } else {
           float ms[CW];
 #pragma unroll
-          for (int o = 0; o < NO; ++o) ps_load8<T>(reinterpret_cast<const T*>(e.mask_src) + (long long)m * e.ldc_mask + cb + 8 * o, ms + 8 * o);
+          for (int o = 0; o < NO; ++o) ld8(e.mask_src, e.ldc_mask, m, cb + 8 * o, ms + 8 * o);
 #pragma unroll
           for (int i = 0; i < CW; ++i) v[i] = ms[i] > 0.f ? v[i] * sc[i] * d[i] : 0.f;
           if (e.add1) {
             float t[CW];
 #pragma unroll
-            for (int o = 0; o < NO; ++o) ps_load8<T>(reinterpret_cast<const T*>(e.add1) + (long long)m * e.ldc_add1 + cb + 8 * o, t + 8 * o);
+            for (int o = 0; o < NO; ++o) ld8(e.add1, e.ldc_add1, m, cb + 8 * o, t + 8 * o);
 #pragma unroll
             for (int i = 0; i < CW; ++i) v[i] += t[i];
           }
         }
 #pragma unroll
-        for (int o = 0; o < NO; ++o) ps_store8<T>(reinterpret_cast<T*>(e.out) + (long long)m * e.ldc_out + cb + 8 * o, v + 8 * o);
+        for (int o = 0; o < NO; ++o) st8(e.out, e.ldc_out, m, cb + 8 * o, v + 8 * o);
       }
       continue;
     }
@@ -319,7 +389,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
 #pragma unroll
       for (int mi = 0; mi < LW; ++mi)
 #pragma unroll
-        for (int o = 0; o < NO; ++o) t[mi][o].load(rs, roff(mi, e.ldc_mask, cb) + 8 * o * ES);
+        for (int o = 0; o < NO; ++o) t[mi][o].load(rs, roff(mi, e.ldc_mask, cb) + 8 * o * ES, plane);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -331,7 +401,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
             const float x = acc[mi][(c0 + 8 * o + i) / 4][i & 3] * sc[8 * o + i];
             acc[mi][(c0 + 8 * o + i) / 4][i & 3] = ms[i] > 0.f ? x : 0.f;
           }
-          if (mi + LW < MI) t[mi % LW][o].load(rs, roff(mi + LW, e.ldc_mask, cb) + 8 * o * ES);
+          if (mi + LW < MI) t[mi % LW][o].load(rs, roff(mi + LW, e.ldc_mask, cb) + 8 * o * ES, plane);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -353,7 +423,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
 // STG: 0 registers, 1 global_load_lds, 2 buffer_load ... lds (default)
 template <typename Tr, int BM, int BN, int WMW, int WNW, int STG>
 __global__ __launch_bounds__(64 * WMW * WNW) void conv_igemm_kernel(const IgemmArgs a) {
-  typedef typename Tr::elem T;
+  typedef typename Tr::elem T [[maybe_unused]];
   constexpr int NW = WMW * WNW;  // waves per block (4 or 8)
   constexpr int MI = BM / (16 * WMW);        // pixel fragments per wave
   constexpr int WI = BN / (16 * WNW);        // cout fragments per wave
@@ -508,7 +578,7 @@ __global__ __launch_bounds__(64 * WMW * WNW) void conv_igemm_kernel(const IgemmA
     __syncthreads();
   }
 
-  conv_epilogue<T, MI, WI>(a, acc, m0 + wm * WM, n0 + wn * WN, lane);
+  conv_epilogue<typename Tr::epi, MI, WI>(a, acc, m0 + wm * WM, n0 + wn * WN, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -518,7 +588,7 @@ __global__ __launch_bounds__(64 * WMW * WNW) void conv_igemm_kernel(const IgemmA
 // ------------------------------------------------------------------------------------------------
 template <typename Tr>
 __global__ __launch_bounds__(512) void conv_igemm3_kernel(const IgemmArgs a) {
-  typedef typename Tr::elem T;
+  typedef typename Tr::elem T [[maybe_unused]];
   constexpr int BM = 256, BN = 128, WM = 64, MI = 4;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -638,7 +708,7 @@ __global__ __launch_bounds__(512) void conv_igemm3_kernel(const IgemmArgs a) {
     cur = (cur == 2) ? 0 : cur + 1;
     nxt2 = (nxt2 == 2) ? 0 : nxt2 + 1;
   }
-  conv_epilogue<T, MI, 4>(a, acc, m0 + wm * WM, n0 + wn * 64, lane);
+  conv_epilogue<typename Tr::epi, MI, 4>(a, acc, m0 + wm * WM, n0 + wn * 64, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -653,7 +723,7 @@ __global__ __launch_bounds__(512) void conv_igemm3_kernel(const IgemmArgs a) {
 // ------------------------------------------------------------------------------------------------
 template <typename Tr, int GM>
 __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const IgemmArgs a) {
-  typedef typename Tr::elem T;
+  typedef typename Tr::elem T [[maybe_unused]];
   constexpr int BM = 2 * GM, BN = 128;
   constexpr int WMW = (GM == 128) ? 2 : 1, WNW = 4 / WMW;
   constexpr int MI = GM / (16 * WMW), WI = BN / (16 * WNW);
@@ -811,7 +881,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const IgemmArgs a) {
     nx2 = (nx2 == 2) ? 0 : nx2 + 1;
   }
   if (grp == 1) mma_all();
-  conv_epilogue<T, MI, WI>(a, acc, m0 + grp * GM + wm * WM, n0 + wn * WN, lane);
+  conv_epilogue<typename Tr::epi, MI, WI>(a, acc, m0 + grp * GM + wm * WM, n0 + wn * WN, lane);
 }
 
 // Epilogue of the wave-specialised kernel (bf16): the per-channel scale/shift and the tile-shaped operands (residual
@@ -894,7 +964,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const IgemmArgs& a, f32x4 (&ac
 // ------------------------------------------------------------------------------------------------
 template <typename Tr, int BM>  // BM = 128: consumers 2x2 of 64x64; BM = 112: consumers 1x4 of 112x32 (balanced tiling, see above)
 __global__ __launch_bounds__(512, 4) void conv_igemm_ws_kernel(const IgemmArgs a) {
-  typedef typename Tr::elem T;
+  typedef typename Tr::elem T [[maybe_unused]];
   constexpr int BN = 128, WMW = (BM == 128) ? 2 : 1, WNW = 4 / WMW;
   constexpr int MI = BM / (16 * WMW), WI = BN / (16 * WNW), WM = 16 * MI, WN = 16 * WI;
   constexpr int AINS = BM / 8;
@@ -909,7 +979,7 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_ws_kernel(const IgemmArgs a
   const int m0 = tm * BM, n0 = tn * BN;
   const int nsteps = a.taps * a.klines;
   // bf16: epilogue operands travel through LDS (see conv_epilogue_lds); which tensor goes to which tile:
-  constexpr bool LDS_EPI = sizeof(T) == 2;
+  constexpr bool LDS_EPI = sizeof(T) == 2 && std::is_same<T, typename Tr::epi>::value;  // (not for split tensors)
   const ps_epilogue& ep = a.epi;
   const bool ep_bwd = ep.mode == PS_EPI_RELUBWD;
   const void* tile1_src = ep_bwd ? ep.mask_src : ep.add0;
@@ -1048,7 +1118,7 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_ws_kernel(const IgemmArgs a
     conv_epilogue_lds<T, MI, WI>(a, acc, m0 + wm * WM, wm * WM, n0 + wn * WN, wn * WN, lane, prm, smem + (nsteps & 1) * STAGE,
                               smem + ((nsteps - 1) & 1) * STAGE);
   } else {
-    conv_epilogue<T, MI, WI>(a, acc, m0 + wm * WM, n0 + wn * WN, lane);
+    conv_epilogue<typename Tr::epi, MI, WI>(a, acc, m0 + wm * WM, n0 + wn * WN, lane);
   }
 }
 
@@ -1067,7 +1137,7 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_ws_kernel(const IgemmArgs a
 // ------------------------------------------------------------------------------------------------
 template <typename Tr, int BM, bool SPLIT = false>  // SPLIT: one parity class of a stride-2 data gradient (IgemmArgs::tap_mask ...)
 __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs a) {
-  typedef typename Tr::elem T;
+  typedef typename Tr::elem T [[maybe_unused]];
   constexpr int BN = 128, MI = BM / 32, WI = 4, WM = 16 * MI, WN = 64;
   constexpr int AINS = BM / 8, AJ = AINS / 4, BJ = 4, NLD = AJ + BJ;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -1269,7 +1339,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
       for (int i = 0; i < WI; ++i) Tr::mma(wf1[i], xf1[mi], acc[mi][i]);
     int tm, tn;
     ps_tile_of_block(tile, a.ntn, a.ntm, tm, tn, a.supertile);
-    conv_epilogue<T, MI, WI, SPLIT ? 2 : 0>(a, acc, tm * BM + wm * WM, tn * BN + wn * WN, lane);
+    conv_epilogue<typename Tr::epi, MI, WI, SPLIT ? 2 : 0>(a, acc, tm * BM + wm * WM, tn * BN + wn * WN, lane);
   }
 }
 
@@ -1356,7 +1426,7 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------
 template <typename Tr, bool HEAD = false>
 __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const IgemmArgs a) {
-  typedef typename Tr::elem T;
+  typedef typename Tr::elem T [[maybe_unused]];
   static_assert(sizeof(T) == 2, "16-bit operands");
   constexpr int BM = 256, BN = 256, MI = 8, WI = 4;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;  // 64 KiB per K-tile
@@ -1590,7 +1660,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const IgemmArgs a)
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
   if constexpr (HEAD) conv_head_epilogue<T, MI, WI>(a, acc, m0 + grp * 128, n0 + wc * 64, lane, tn * 4 + wc);
-  else conv_epilogue<T, MI, WI, 0>(a, acc, m0 + grp * 128, n0 + wc * 64, lane);
+  else conv_epilogue<typename Tr::epi, MI, WI, 0>(a, acc, m0 + grp * 128, n0 + wc * 64, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1641,7 +1711,7 @@ __device__ unsigned long long g_halo_stamps[256 * 4 * 6];  // [block][consumer w
 // half the chip idle for a whole round; as half tiles the same work occupies every CU for ~0.6 of a round).
 template <typename Tr, int TW, int NW = 3, int WI = 4>  // TW = 28 (maps of 224-pixel tiles: 28 / 56 / 112 wide) or 32 (256-pixel tiles: 32 / 64 / 128 wide); NW = weight ring depth
 __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs a) {
-  typedef typename Tr::elem T;
+  typedef typename Tr::elem T [[maybe_unused]];
   static_assert(TW == 28 || TW == 32, "tile width");
   static_assert(WI == 4 || WI == 2, "cout fragments per wave");
   constexpr int BN = 32 * WI, MI = TW / 4, WN = 16 * WI, TR = 8;  // tile = 8 rows x TW columns = 224 | 256 pixels, BN = 128 | 64 couts
@@ -1978,7 +2048,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
     ps_tile_of_block(tile, a.ntn, a.ntm, tm, tn, a.supertile);
       tm += a.tm0;
     const int rb = tm / ncb;
-    conv_epilogue<T, MI, WI, 1>(a, acc, rb * TR * W + (tm - rb * ncb) * TW + wm * (TW / 2), tn * BN + wn * WN, lane);
+    conv_epilogue<typename Tr::epi, MI, WI, 1>(a, acc, rb * TR * W + (tm - rb * ncb) * TW + wm * (TW / 2), tn * BN + wn * WN, lane);
 #ifdef PS_HALO_STAMPS
     PS_STAMP(st_prev);  // the epilogue is not part of segment 0 of the next tile's first step
 #endif
@@ -2039,7 +2109,7 @@ int launch_igemm(const IgemmArgs& a0, hipStream_t stream) {
 
 int check_geom(const ps_conv_geom* g) {
   PS_REQUIRE(g != nullptr, "conv: null geometry");
-  PS_REQUIRE(ps_dtype_ok(g->dtype), "conv: dtype %d unsupported", g->dtype);
+  PS_REQUIRE(ps_conv_dtype_ok(g->dtype), "conv: dtype %d unsupported", g->dtype);
   PS_REQUIRE(g->ksize == 1 || g->ksize == 3, "conv: ksize %d unsupported (1 or 3)", g->ksize);
   PS_REQUIRE(g->stride == 1 || g->stride == 2, "conv: stride %d unsupported (1 or 2)", g->stride);
   PS_REQUIRE(g->dilation >= 1 && g->dilation <= 64, "conv: dilation %d unsupported", g->dilation);
@@ -2050,14 +2120,14 @@ int check_geom(const ps_conv_geom* g) {
   PS_REQUIRE((g->cin * es) % 128 == 0 && (g->cout * es) % 128 == 0,
              "conv: cin=%d cout=%d must be multiples of %d channels", g->cin, g->cout, 128 / es);
   PS_REQUIRE(g->cin % 64 == 0 && g->cout % 64 == 0, "conv: cin=%d cout=%d must be multiples of 64", g->cin, g->cout);
-  PS_REQUIRE(g->ldc_x >= g->cin && g->ldc_y >= g->cout, "conv: channel strides smaller than channel counts");
+  PS_REQUIRE(g->ldc_x >= ps_planes(g->dtype) * g->cin && g->ldc_y >= ps_planes(g->dtype) * g->cout, "conv: channel strides smaller than channel counts");
   PS_REQUIRE((g->ldc_x * es) % 16 == 0 && (g->ldc_y * es) % 16 == 0, "conv: channel strides must be 16-byte multiples");
   const long long ho = (g->h - 1) / g->stride + 1, wo = (g->w - 1) / g->stride + 1;
   PS_REQUIRE((long long)g->n * g->h * g->w < (1LL << 31) && (long long)g->n * ho * wo < (1LL << 31), "conv: too many pixels");
   return PS_OK;
 }
 
-int check_epilogue(const ps_epilogue* e, int dtype, const char* who) {
+int check_epilogue(const ps_epilogue* e, int dtype, const char* who, int cd) {
   PS_REQUIRE(e != nullptr, "%s: null epilogue", who);
   PS_REQUIRE(e->mode >= PS_EPI_NONE && e->mode <= PS_EPI_RELUBWD, "%s: bad epilogue mode %d", who, e->mode);
   PS_REQUIRE(e->out_raw || e->mode != PS_EPI_NONE, "%s: epilogue produces no output", who);
@@ -2070,6 +2140,7 @@ int check_epilogue(const ps_epilogue* e, int dtype, const char* who) {
   for (const auto& x : t) {
     if (!x.p) continue;
     PS_REQUIRE(ps_aligned16(x.p) && (x.ldc * es) % 16 == 0 && x.ldc > 0, "%s: epilogue tensor %s misaligned (ptr %p ldc %d)", who, x.nm, x.p, x.ldc);
+    PS_REQUIRE(x.ldc >= ps_planes(dtype) * cd, "%s: epilogue tensor %s has channel stride %d < %d produced channels x %d planes", who, x.nm, x.ldc, cd, ps_planes(dtype));
   }
   return PS_OK;
 }
@@ -2339,7 +2410,7 @@ extern "C" int ps_conv_variant(const ps_conv_geom* g, int32_t dgrad) {
   const long long M = dgrad ? (long long)g->n * g->h * g->w : (long long)g->n * ho * wo;
   if (g_use_3stage + g_use_pp != 0) return PS_CONV_OTHER;
   if (use_gemm256(M, dgrad ? g->cin : g->cout, ps_esize(g->dtype), g->ksize * g->ksize, dgrad ? 1 : g->stride,
-                                              dgrad && g->stride == 2 ? 1 : 0, (dgrad ? g->cout : g->cin) * ps_esize(g->dtype) / 128))
+                                              dgrad && g->stride == 2 ? 1 : 0, ps_planes(g->dtype) * (dgrad ? g->cout : g->cin) * ps_esize(g->dtype) / 128))
     return PS_CONV_GEMM256;
   // both directions of a stride-1 3x3 layer gather on the input grid h x w
   const bool halo_ok = g->ksize == 3 && g->stride == 1 && halo_tile_width(g->w) != 0 && g->dilation <= 4;
@@ -2407,7 +2478,7 @@ extern "C" int ps_conv1x1_head_fwd(const ps_conv_geom* g, const void* x, const v
 
 extern "C" int ps_conv2d_fwd(const ps_conv_geom* g, const void* x, const void* w_fwd, const ps_epilogue* epi, void* stream) {
   if (int rc = check_geom(g)) return rc;
-  if (int rc = check_epilogue(epi, g->dtype, "conv2d_fwd")) return rc;
+  if (int rc = check_epilogue(epi, g->dtype, "conv2d_fwd", g->cout)) return rc;
   PS_REQUIRE(x && w_fwd && ps_aligned16(x) && ps_aligned16(w_fwd), "conv2d_fwd: null or misaligned x/w");
   const int es = ps_esize(g->dtype);
   IgemmArgs a{};
@@ -2418,15 +2489,17 @@ extern "C" int ps_conv2d_fwd(const ps_conv_geom* g, const void* x, const void* w
   a.M = g->n * a.Ho * a.Wo;
   a.mul = g->stride; a.dstep = g->dilation; a.div_shift = 0;
   a.taps = g->ksize * g->ksize; a.ctr = g->ksize / 2;
-  a.klines = g->cin * es / 128;
+  const int kc = ps_planes(g->dtype) * g->cin;  // contracted channels per tap (split format: [hi | lo | hi] against [hi | hi | lo])
+  a.klines = kc * es / 128;
   a.pix_bytes = (long long)g->ldc_x * es;
-  a.wrow_bytes = (long long)a.taps * g->cin * es;
+  a.wrow_bytes = (long long)a.taps * kc * es;
   a.Cd = g->cout;
   a.epi = *epi;
   a.tpb = g->tiles_per_block;
   a.shared = g->gpu_shared;
   if (int rc = set_extents(a, (long long)g->n * g->h * g->w * a.pix_bytes, (long long)g->cout * a.wrow_bytes, es)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (g->dtype == PS_BF16X3) return dispatch_bn<TraitsBF16X3>(a, s);
   if (g->dtype == PS_BF16) return dispatch_bn<TraitsBF16>(a, s);
   if (g->dtype == PS_F16) return dispatch_bn<TraitsF16>(a, s);
   return dispatch_bn<TraitsF32>(a, s);
@@ -2478,7 +2551,7 @@ static bool dgrad_s2_split_ok(const ps_conv_geom* g, const ps_epilogue* epi) {
 
 extern "C" int ps_conv2d_dgrad(const ps_conv_geom* g, const void* dy, const void* w_dgrad, const ps_epilogue* epi, void* stream) {
   if (int rc = check_geom(g)) return rc;
-  if (int rc = check_epilogue(epi, g->dtype, "conv2d_dgrad")) return rc;
+  if (int rc = check_epilogue(epi, g->dtype, "conv2d_dgrad", g->cin)) return rc;
   PS_REQUIRE(dy && w_dgrad && ps_aligned16(dy) && ps_aligned16(w_dgrad), "conv2d_dgrad: null or misaligned dy/w");
   const int es = ps_esize(g->dtype);
   IgemmArgs a{};
@@ -2489,16 +2562,19 @@ extern "C" int ps_conv2d_dgrad(const ps_conv_geom* g, const void* dy, const void
   a.M = g->n * g->h * g->w;
   a.mul = 1; a.dstep = -g->dilation; a.div_shift = g->stride == 2 ? 1 : 0;
   a.taps = g->ksize * g->ksize; a.ctr = g->ksize / 2;
-  a.klines = g->cout * es / 128;
+  const int kc = ps_planes(g->dtype) * g->cout;
+  a.klines = kc * es / 128;
   a.pix_bytes = (long long)g->ldc_y * es;
-  a.wrow_bytes = (long long)a.taps * g->cout * es;
+  a.wrow_bytes = (long long)a.taps * kc * es;
   a.Cd = g->cin;
   a.epi = *epi;
   a.tpb = g->tiles_per_block;
   a.shared = g->gpu_shared;
   if (int rc = set_extents(a, (long long)g->n * a.Hs * a.Ws * a.pix_bytes, (long long)g->cin * a.wrow_bytes, es)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (dgrad_s2_split_ok(g, epi)) return g->dtype == PS_BF16 ? dgrad_s2_split<TraitsBF16>(a, s) : dgrad_s2_split<TraitsF16>(a, s);
+  if (dgrad_s2_split_ok(g, epi))
+    return g->dtype == PS_BF16X3 ? dgrad_s2_split<TraitsBF16X3>(a, s) : g->dtype == PS_BF16 ? dgrad_s2_split<TraitsBF16>(a, s) : dgrad_s2_split<TraitsF16>(a, s);
+  if (g->dtype == PS_BF16X3) return dispatch_bn<TraitsBF16X3>(a, s);
   if (g->dtype == PS_BF16) return dispatch_bn<TraitsBF16>(a, s);
   if (g->dtype == PS_F16) return dispatch_bn<TraitsF16>(a, s);
   return dispatch_bn<TraitsF32>(a, s);

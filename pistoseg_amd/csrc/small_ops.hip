@@ -958,6 +958,84 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const unsigned char* __r
 }
 }  // namespace
 
+namespace {
+// ------------------------------------------------------------------------------------------------
+// Row-wise format conversion between f32 and the activation / weight storage formats: rows of c logical channels, 8 per thread,
+// arbitrary row pitches (channel slices of wider buffers).  f32 -> {bf16, f16, split}; {bf16, f16, split} -> f32.
+// Split (PS_BF16X3): three bf16 planes of c channels per row; pattern 0 = [hi | lo | hi] (activations), 1 = [hi | hi | lo] (weights);
+// hi = bf16(v) RNE, lo = bf16(v - hi); reading back: hi + lo (the lo plane is plane 1 or 2 by pattern).
+// ------------------------------------------------------------------------------------------------
+template <int SRC, int DST>
+__global__ __launch_bounds__(256) void convert_rows_kernel(const unsigned char* __restrict__ src, long long ld_src, unsigned char* __restrict__ dst,
+                                                            long long ld_dst, long long rows, int c8, int pattern) {
+  const long long total = rows * c8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / c8;
+    const int c = (int)(i - r * c8) * 8, cch = c8 * 8;
+    float v[8];
+    if constexpr (SRC == PS_F32) {
+      ps_load8<float>(reinterpret_cast<const float*>(src) + r * ld_src + c, v);
+    } else if constexpr (SRC == PS_BF16) {
+      ps_load8<__bf16>(reinterpret_cast<const __bf16*>(src) + r * ld_src + c, v);
+    } else if constexpr (SRC == PS_F16) {
+      ps_load8<_Float16>(reinterpret_cast<const _Float16*>(src) + r * ld_src + c, v);
+    } else {
+      const __bf16* p = reinterpret_cast<const __bf16*>(src) + r * ld_src + c;
+      float lo[8];
+      ps_load8<__bf16>(p, v);
+      ps_load8<__bf16>(p + (pattern ? 2 : 1) * cch, lo);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += lo[k];
+    }
+    if constexpr (DST == PS_F32) {
+      ps_store8<float>(reinterpret_cast<float*>(dst) + r * ld_dst + c, v);
+    } else if constexpr (DST == PS_BF16) {
+      ps_store8<__bf16>(reinterpret_cast<__bf16*>(dst) + r * ld_dst + c, v);
+    } else if constexpr (DST == PS_F16) {
+      ps_store8<_Float16>(reinterpret_cast<_Float16*>(dst) + r * ld_dst + c, v);
+    } else {
+      __bf16* p = reinterpret_cast<__bf16*>(dst) + r * ld_dst + c;
+      float hi[8], lo[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        hi[k] = ps_bf16_to_f32(ps_f32_to_bf16(v[k]));
+        lo[k] = v[k] - hi[k];
+      }
+      ps_store8<__bf16>(p, hi);
+      ps_store8<__bf16>(p + cch, pattern ? hi : lo);
+      ps_store8<__bf16>(p + 2 * cch, pattern ? lo : hi);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int ps_convert_rows(const void* src, int32_t src_fmt, int64_t ld_src, void* dst, int32_t dst_fmt, int64_t ld_dst, int64_t rows, int32_t c,
+                               int32_t pattern, void* stream) {
+  PS_REQUIRE(src && dst && rows >= 0 && c > 0, "convert_rows: bad argument");
+  PS_REQUIRE((src_fmt == PS_F32) != (dst_fmt == PS_F32), "convert_rows: exactly one side must be f32 (got %d -> %d)", src_fmt, dst_fmt);
+  PS_REQUIRE(ps_conv_dtype_ok(src_fmt) && ps_conv_dtype_ok(dst_fmt) && (pattern == 0 || pattern == 1), "convert_rows: bad format / pattern");
+  PS_REQUIRE(c % 8 == 0 && ld_src >= ps_planes(src_fmt) * (int64_t)c && ld_dst >= ps_planes(dst_fmt) * (int64_t)c, "convert_rows: c=%d must be a multiple of 8 and fit the pitches", c);
+  PS_REQUIRE(ps_aligned16(src) && ps_aligned16(dst) && (ld_src * ps_esize(src_fmt)) % 16 == 0 && (ld_dst * ps_esize(dst_fmt)) % 16 == 0, "convert_rows: misaligned");
+  if (rows == 0) return PS_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(grid_for(rows * (c / 8), 256)), block(256);
+  const unsigned char* sp = static_cast<const unsigned char*>(src);
+  unsigned char* dp = static_cast<unsigned char*>(dst);
+#define PS_CVT(S, D) hipLaunchKernelGGL((convert_rows_kernel<S, D>), grid, block, 0, s, sp, (long long)ld_src, dp, (long long)ld_dst, (long long)rows, c / 8, pattern)
+  if (src_fmt == PS_F32) {
+    if (dst_fmt == PS_BF16) PS_CVT(PS_F32, PS_BF16);
+    else if (dst_fmt == PS_F16) PS_CVT(PS_F32, PS_F16);
+    else PS_CVT(PS_F32, PS_BF16X3);
+  } else {
+    if (src_fmt == PS_BF16) PS_CVT(PS_BF16, PS_F32);
+    else if (src_fmt == PS_F16) PS_CVT(PS_F16, PS_F32);
+    else PS_CVT(PS_BF16X3, PS_F32);
+  }
+#undef PS_CVT
+  PS_CHECK_LAUNCH("convert_rows");
+  return PS_OK;
+}
+
 extern "C" int ps_copy_rows(const void* src, int64_t src_ld_bytes, void* dst, int64_t dst_ld_bytes, int64_t rows, int64_t row_bytes, void* stream) {
   PS_REQUIRE(src && dst && rows > 0 && row_bytes > 0, "copy_rows: bad argument");
   PS_REQUIRE(row_bytes % 16 == 0 && src_ld_bytes % 16 == 0 && dst_ld_bytes % 16 == 0 && ps_aligned16(src) && ps_aligned16(dst),

@@ -4,7 +4,11 @@ The reference has no distributed code (its `nn.DataParallel` wrappers degenerate
 tile batches are independent (BN is frozen, resnet38d.py:206-211), so
   * training = batch-dim data parallel with ONE exchange per step: a SUM all-reduce of the flat f32 gradient
     arena, cut into buckets that are contiguous in the order the reverse plan finalises them and launched on
-    a side stream as soon as their last unit is done (overlap with the remaining dgrad/wgrad);
+    a side stream as soon as their last unit is done (overlap with the remaining dgrad/wgrad).  Two wire
+    formats, chosen per trainer: "fp32" (the arena slices themselves: 417.8 MB per step and GPU)
+    and "bf16" (each bucket cast to bf16, all-reduced, widened back into the arena: 208.9 MB -- xGMI is
+    point-to-point, a ring moves 2 (p-1)/p x payload per GPU at one link's ~153 GB/s, so halving the payload
+    halves the exposed tail of the last bucket; the sum then carries bf16 rounding, 2^-9 relative per addition);
   * inference = contiguous index ranges per rank, no collective on the data path, optional gather of uint8
     masks / all-reduce of the confusion matrix.
 Everything here is device-agnostic so the N > 1 logic is covered by world_size-2 gloo tests on CPU.
@@ -45,33 +49,58 @@ class BucketedAllReduce:
     `finish()` the conv launches are told to cut their work into `shared_tiles_per_block`-tile blocks that the hardware
     dispatcher re-balances (the `tiles_per_block` launch option of ps_conv_geom); forward passes and single-GPU runs keep the fully persistent schedule."""
 
-    def __init__(self, flat: Tensor, buckets: List[Tuple[str, int, int]], group=None, shared_tiles_per_block: int = 1):
+    def __init__(self, flat: Tensor, buckets: List[Tuple[str, int, int]], group=None, shared_tiles_per_block: int = 1, launch_opts=None,
+                 payload: str = "fp32"):
+        """launch_opts: the `ops.LaunchOpts` of the model whose backward runs beside the buckets (its `tiles_per_block` is what `_share_gpu`
+        switches: state of THAT model's launches, not of the process).  payload: "fp32" | "bf16" (see the module docstring)."""
+        assert payload in ("fp32", "bf16")
         self.flat, self.buckets, self.group = flat, buckets, group
         self.comm_stream = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None
         self.shared_tiles_per_block = shared_tiles_per_block
+        self.launch_opts = launch_opts
+        self.payload = payload
+        # bf16 wire format: one staging arena the size of the gradient arena (buckets are disjoint slices of it)
+        self.stage = torch.empty(flat.numel(), device=flat.device, dtype=torch.bfloat16) if payload == "bf16" else None
         self._next = 0
         self._pending = []
         self._sharing = False
 
     def _share_gpu(self, on: bool) -> None:
-        if self.comm_stream is None or on == self._sharing:
+        if self.comm_stream is None or on == self._sharing or self.launch_opts is None:
             return
-        from . import ops  # device path only: the CPU (gloo) tests never load the HIP library
-
-        ops.TILES_PER_BLOCK = self.shared_tiles_per_block if on else 0  # a per-launch argument of the C-ABI (ps_conv_geom)
+        self.launch_opts.tiles_per_block = self.shared_tiles_per_block if on else None  # a per-launch argument of the C-ABI (ps_conv_geom)
         self._sharing = on
 
     def begin_step(self) -> None:
         self._next, self._pending = 0, []
+
+    def _exchange(self, start: int, end: int):
+        """Enqueue one bucket's exchange on the current stream; returns the collective's work handle."""
+        if self.stage is None:
+            return dist.all_reduce(self.flat[start:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        src, st = self.flat[start:end], self.stage[start:end]
+        if src.is_cuda:
+            from . import ops  # device path only: the CPU (gloo) tests never load the HIP library
+
+            ops.cast_f32_lowp(src, st)
+        else:
+            st.copy_(src)
+        w = dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        w.wait()  # RCCL: a stream dependency (the host does not block); gloo: the host waits, the tests' ranks are CPU processes
+        if src.is_cuda:
+            ops.convert_rows(st, src, end - start)
+        else:
+            src.copy_(st)
+        return w
 
     def _launch(self, start: int, end: int) -> None:
         self._share_gpu(True)
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
-                w = dist.all_reduce(self.flat[start:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                w = self._exchange(start, end)
         else:
-            w = dist.all_reduce(self.flat[start:end], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w = self._exchange(start, end)
         self._pending.append(w)
 
     def on_unit_done(self, unit: str) -> None:

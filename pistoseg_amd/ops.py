@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import PS_BF16, PS_EPI_BNRELU, PS_EPI_NONE, PS_EPI_RELUBWD, PS_F16, PS_F32, ConvGeom, Epilogue, Tensor4
+from ._lib import PS_BF16, PS_BF16X3, PS_EPI_BNRELU, PS_EPI_NONE, PS_EPI_RELUBWD, PS_F16, PS_F32, ConvGeom, Epilogue, Tensor4
 
 Tensor = torch.Tensor
 
@@ -29,7 +29,7 @@ _VARIANT_NAMES = {1: "conv_igemm_kernel", 2: "conv_igemm_ws_kernel", 3: "conv_ig
 
 def _conv_label(kind: str, g: ConvGeom) -> str:
     """Kernel family serving this launch (asked of the library: ps_conv_variant mirrors the dispatcher)."""
-    dt = {PS_BF16: "bf16", PS_F16: "f16"}.get(g.dtype, "f32")
+    dt = {PS_BF16: "bf16", PS_F16: "f16", PS_BF16X3: "bf16x3"}.get(g.dtype, "f32")
     if kind == "wgrad":
         v = int(_lib.load().ps_conv_wgrad_variant(C.byref(g)))
         return f"{ {2: 'conv_wgrad256_kernel', 1: 'conv_wgrad_ws2_kernel'}.get(v, 'conv_wgrad_kernel') }<{dt}>"
@@ -95,18 +95,39 @@ class ConvSpec:
         return (h - 1) // self.stride + 1, (w - 1) // self.stride + 1
 
 
-# Launch option of the persistent conv kernels, passed to the C-ABI with every launch (ps_conv_geom.tiles_per_block): 0 = one block
-# per CU lives for the whole launch; n > 0 while a communication kernel shares the GPU (set by dist.BucketedAllReduce between its first
-# bucket launch and finish()).  It is read when a launch is ENQUEUED, by the one host thread that enqueues this process's work.
-TILES_PER_BLOCK = 0
-# Launch option ps_conv_geom.gpu_shared: 1 while another stream of this process runs kernels beside the launch stream (set by the backbone's
-# two-stream backward between its first side-stream launch and the join): a launch's partial last round is then left to the co-running
-# kernel's blocks instead of being re-issued as smaller tiles.  Read when a launch is enqueued, like TILES_PER_BLOCK.
+# Launch options of the conv kernels.  They are arguments of every C-ABI launch (ps_conv_geom.tiles_per_block / .gpu_shared, and the
+# choice between ps_conv2d_wgrad and ps_conv2d_wgrad_det), and on the host side they are STATE OF THE CALLER: every model owns a
+# `LaunchOpts` (resnet38d.Net.launch) that its plans pass to each launch, its trainer sets `deterministic` on it and its gradient
+# reducer `tiles_per_block` -- two trainers in one process do not see each other's switches.  A field left at None falls back to the
+# module-level default below, which only direct callers of this module (the op tests, the probes under tools/) ever change.
+@dataclass
+class LaunchOpts:
+    # 0 = one block per CU lives for the whole launch; n > 0 while a communication kernel shares the GPU (dist.BucketedAllReduce sets it on
+    # its model's options between its first bucket launch and finish())
+    tiles_per_block: Optional[int] = None
+    # 1 while another stream of the caller runs kernels beside the launch stream (the backbone's two-stream backward, for its own duration): a
+    # launch's partial last round is then left to the co-running kernel's blocks instead of being re-issued as smaller tiles
+    gpu_shared: Optional[int] = None
+    # weight gradients without atomics / top-k ties in index order (see DETERMINISTIC below); None = the module default = torch's switch
+    deterministic: Optional[bool] = None
+
+
+TILES_PER_BLOCK = 0  # module defaults (see LaunchOpts): read when a launch is ENQUEUED
 GPU_SHARED = 0
 
 
-def _geom(spec: ConvSpec, dtype: int, n: int, h: int, w: int, ldc_x: int, ldc_y: int) -> ConvGeom:
-    return ConvGeom(dtype, n, h, w, spec.cin, spec.cout, spec.ksize, spec.stride, spec.dilation, ldc_x, ldc_y, TILES_PER_BLOCK, GPU_SHARED)
+def _geom(spec: ConvSpec, dtype: int, n: int, h: int, w: int, ldc_x: int, ldc_y: int, opts: Optional[LaunchOpts] = None) -> ConvGeom:
+    tpb = TILES_PER_BLOCK if opts is None or opts.tiles_per_block is None else opts.tiles_per_block
+    shared = GPU_SHARED if opts is None or opts.gpu_shared is None else opts.gpu_shared
+    return ConvGeom(dtype, n, h, w, spec.cin, spec.cout, spec.ksize, spec.stride, spec.dilation, ldc_x, ldc_y, int(tpb), int(shared))
+
+
+def _conv_dt(t: Tensor, split: bool) -> int:
+    """C-ABI dtype of a conv launch on activation tensor t: `split` marks bf16 tensors holding the three planes [hi | lo | hi] (PS_BF16X3)."""
+    if split:
+        assert t.dtype == torch.bfloat16, "split tensors are bf16 planes"
+        return PS_BF16X3
+    return _dt(t)
 
 
 def _epilogue(mode=PS_EPI_NONE, add0=None, out_raw=None, scale=None, shift=None, drop=None, mask_src=None, add1=None, out=None) -> Epilogue:
@@ -127,32 +148,34 @@ def _epilogue(mode=PS_EPI_NONE, add0=None, out_raw=None, scale=None, shift=None,
 
 
 def conv2d_fwd(spec: ConvSpec, x: Tensor, w_fwd: Tensor, *, add0=None, out_raw=None, bn_scale=None, bn_shift=None, drop=None,
-               out_act=None, relu=False) -> None:
-    """y = conv(x, W) [+ add0]; out_raw <- y; out_act <- max(y*scale+shift, 0)*drop (if out_act given)."""
+               out_act=None, relu=False, split: bool = False, opts: Optional[LaunchOpts] = None) -> None:
+    """y = conv(x, W) [+ add0]; out_raw <- y; out_act <- max(y*scale+shift, 0)*drop (if out_act given).
+    split: every activation tensor holds three bf16 planes per logical channel and w_fwd is [cout][taps][3 cin] (PS_BF16X3)."""
     _require_gpu(x, w_fwd)
     n, h, w, c = x.shape
-    assert c == spec.cin and w_fwd.numel() == spec.cout * spec.cin * spec.ksize**2 and w_fwd.dtype == x.dtype
+    pl = 3 if split else 1
+    assert c == pl * spec.cin and w_fwd.numel() == pl * spec.cout * spec.cin * spec.ksize**2 and w_fwd.dtype == x.dtype
     mode = PS_EPI_BNRELU if out_act is not None else PS_EPI_NONE
     ref = out_act if out_act is not None else out_raw
-    g = _geom(spec, _dt(x), n, h, w, _ldc(x), _ldc(ref))
+    g = _geom(spec, _conv_dt(x, split), n, h, w, _ldc(x), _ldc(ref), opts)
     e = _epilogue(mode, add0=add0, out_raw=out_raw, scale=bn_scale, shift=bn_shift, drop=drop, out=out_act)
     lib = _lib.load()
     ho, wo = spec.out_hw(h, w)
     m = n * ho * wo
-    _launch(_conv_label("fwd", g) if PROFILE is not None else "", 2.0 * m * spec.cout * spec.cin * spec.ksize**2,
+    _launch(_conv_label("fwd", g) if PROFILE is not None else "", 2.0 * m * spec.cout * spec.cin * spec.ksize**2,  # (algorithmic FLOPs: a split launch spends three MFMAs per product)
             lambda: _lib.check(lib.ps_conv2d_fwd(C.byref(g), x.data_ptr(), w_fwd.data_ptr(), C.byref(e), _stream()), "ps_conv2d_fwd"))
 
 
 def conv2d_dgrad(spec: ConvSpec, dy: Tensor, w_dgrad: Tensor, x_hw, *, add0=None, out_raw=None, mask_src=None, bn_scale=None,
-                 drop=None, add1=None, out=None) -> None:
-    """dx = conv^T(dy, W) [+ add0]; out_raw <- dx; out <- (mask_src>0 ? dx*scale*drop : 0) [+ add1]."""
+                 drop=None, add1=None, out=None, split: bool = False, opts: Optional[LaunchOpts] = None) -> None:
+    """dx = conv^T(dy, W) [+ add0]; out_raw <- dx; out <- (mask_src>0 ? dx*scale*drop : 0) [+ add1].  split: as conv2d_fwd."""
     _require_gpu(dy, w_dgrad)
     n = dy.shape[0]
     h, w = x_hw
-    assert dy.shape[3] == spec.cout and tuple(dy.shape[1:3]) == spec.out_hw(h, w) and w_dgrad.dtype == dy.dtype
+    assert dy.shape[3] == (3 if split else 1) * spec.cout and tuple(dy.shape[1:3]) == spec.out_hw(h, w) and w_dgrad.dtype == dy.dtype
     mode = PS_EPI_RELUBWD if out is not None else PS_EPI_NONE
     ref = out if out is not None else out_raw
-    g = _geom(spec, _dt(dy), n, h, w, _ldc(ref), _ldc(dy))
+    g = _geom(spec, _conv_dt(dy, split), n, h, w, _ldc(ref), _ldc(dy), opts)
     e = _epilogue(mode, add0=add0, out_raw=out_raw, scale=bn_scale, drop=drop, mask_src=mask_src, add1=add1, out=out)
     lib = _lib.load()
     mo = n * dy.shape[1] * dy.shape[2]
@@ -169,6 +192,9 @@ def conv1x1_head_supported(spec: ConvSpec, x: Tensor, classes: int) -> int:
     return int(_lib.load().ps_conv1x1_head_workspace_floats(C.byref(g), classes))
 
 
+_HEAD_WS: dict = {}
+
+
 def conv1x1_head_fwd(spec: ConvSpec, x: Tensor, w_fwd: Tensor, bn_scale: Tensor, bn_shift: Tensor, w_head: Tensor, cam: Tensor) -> None:
     """cam[n,h,w,C] (f32) = head(T(relu(bn(conv1x1(x))))) in one launch + an ordered reduction: the activated tensor is never written
     (inference: b7's last conv + bn7 + ReLU + fc8, resnet38d.py:186 / revise_net.py:50).  w_head: [C, cout] f32."""
@@ -182,7 +208,10 @@ def conv1x1_head_fwd(spec: ConvSpec, x: Tensor, w_fwd: Tensor, bn_scale: Tensor,
     need = int(lib.ps_conv1x1_head_workspace_floats(C.byref(g), classes))
     if need <= 0:
         raise _lib.PsError("conv1x1_head_fwd: geometry not served by the fused kernel")
-    ws = torch.empty(need, device=x.device, dtype=torch.float32)
+    key = (x.device, _stream())  # grow-only, one per (device, stream): launches of one stream run in order and may share it
+    ws = _HEAD_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _HEAD_WS[key] = torch.empty(need, device=x.device, dtype=torch.float32)
     _launch(f"conv_gemm256_kernel<{ {PS_BF16: 'bf16', PS_F16: 'f16'}.get(g.dtype, 'f32') }>" if PROFILE is not None else "",
             2.0 * n * h * w * spec.cout * spec.cin,
             lambda: _lib.check(lib.ps_conv1x1_head_fwd(C.byref(g), x.data_ptr(), w_fwd.data_ptr(), bn_scale.data_ptr(), bn_shift.data_ptr(),
@@ -206,8 +235,9 @@ def deterministic_enabled(override: Optional[bool] = None) -> bool:
     return torch.are_deterministic_algorithms_enabled() if DETERMINISTIC is None else DETERMINISTIC
 
 
-def _wgrad_workspace(nbytes: int, device) -> Tensor:
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+def _wgrad_workspace(nbytes: int, device, stream: int) -> Tensor:
+    """`stream`: the raw handle the launch is enqueued on (the same lookup as the launch itself: ops._stream())."""
+    key = (device, stream)
     ws = _WGRAD_WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), device=device, dtype=torch.uint8)  # allocated on (= owned by) the current stream
@@ -215,24 +245,44 @@ def _wgrad_workspace(nbytes: int, device) -> Tensor:
     return ws
 
 
-def conv2d_wgrad(spec: ConvSpec, x: Tensor, dy: Tensor, dw: Tensor, deterministic: Optional[bool] = None) -> None:
-    """dw[cout][kh][kw][cin] (f32, channels-last OIHW storage) += sum_pixels dy * x@tap.  deterministic (default: the module switch
-    DETERMINISTIC): no atomics, bit-identical from run to run."""
+def release_workspaces() -> None:
+    """Drop the grow-only scratch buffers of this module (deterministic weight-gradient slices, fc8 partial sums, the fused head's
+    partial sums): trainers call it on teardown; the next launch that needs one allocates it again."""
+    _WGRAD_WS.clear()
+    _fc8_ws.clear()
+    _HEAD_WS.clear()
+
+
+def conv2d_wgrad(spec: ConvSpec, x: Tensor, dy: Tensor, dw: Tensor, deterministic: Optional[bool] = None, split: bool = False,
+                 opts: Optional[LaunchOpts] = None, _flops_share: float = 1.0) -> None:
+    """dw[cout][kh][kw][cin] (f32, channels-last OIHW storage) += sum_pixels dy * x@tap.  deterministic (default: opts.deterministic, then the
+    module switch DETERMINISTIC): no atomics, bit-identical from run to run.
+    split: x / dy hold the planes [hi | lo | hi]: dw += x_hi dy_hi + x_hi dy_lo + x_lo dy_hi as three bf16 launches on plane slices (the weight
+    gradient contracts over PIXELS, so the planes cannot ride along the K axis as they do in the forward / data-gradient kernels)."""
+    if split:
+        ci, co = spec.cin, spec.cout
+        assert x.shape[3] == 3 * ci and dy.shape[3] == 3 * co
+        for xs, ds in ((x[..., :ci], dy[..., :co]), (x[..., :ci], dy[..., co:2 * co]), (x[..., ci:2 * ci], dy[..., :co])):
+            conv2d_wgrad(spec, xs, ds, dw, deterministic, False, opts, _flops_share=1.0 / 3.0)  # (each carries a third of the algorithmic FLOPs)
+        return
     _require_gpu(x, dy, dw)
     n, h, w, c = x.shape
     assert c == spec.cin and dy.shape[3] == spec.cout and dw.dtype == torch.float32 and x.dtype == dy.dtype
     assert dw.numel() == spec.cout * spec.cin * spec.ksize**2
-    g = _geom(spec, _dt(x), n, h, w, _ldc(x), _ldc(dy))
+    g = _geom(spec, _dt(x), n, h, w, _ldc(x), _ldc(dy), opts)
     lib = _lib.load()
     mo = n * dy.shape[1] * dy.shape[2]
-    flops = 2.0 * mo * spec.cout * spec.cin * spec.ksize**2
+    flops = 2.0 * mo * spec.cout * spec.cin * spec.ksize**2 * _flops_share
+    if deterministic is None and opts is not None:
+        deterministic = opts.deterministic
     if deterministic_enabled(deterministic):
         need = int(lib.ps_conv2d_wgrad_det_workspace_bytes(C.byref(g)))
         if need < 0:
             _lib.check(-1, "ps_conv2d_wgrad_det_workspace_bytes")
-        ws = _wgrad_workspace(need, x.device) if need > 0 else None
+        stream = _stream()
+        ws = _wgrad_workspace(need, x.device, stream) if need > 0 else None
         _launch(_conv_label("wgrad", g) if PROFILE is not None else "", flops,
-                lambda: _lib.check(lib.ps_conv2d_wgrad_det(C.byref(g), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(ws), need, _stream()),
+                lambda: _lib.check(lib.ps_conv2d_wgrad_det(C.byref(g), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(ws), need, stream),
                                    "ps_conv2d_wgrad_det"))
         return
     _launch(_conv_label("wgrad", g) if PROFILE is not None else "", flops,
@@ -270,6 +320,32 @@ def copy_rows(src: Tensor, dst: Tensor) -> None:
     lib = _lib.load()
     _lib.check(lib.ps_copy_rows(src.data_ptr(), src.stride(0) * es, dst.data_ptr(), dst.stride(0) * es, src.shape[0], src.shape[1] * es, _stream()),
                "ps_copy_rows")
+
+
+def convert_rows(src: Tensor, dst: Tensor, c: int, *, src_split: bool = False, dst_split: bool = False, weights: bool = False) -> None:
+    """Row-wise conversion between f32 and a storage format (ps_convert_rows): src / dst are [..., C'] views with unit channel stride whose
+    leading dims are densely packed rows of pitch stride(-2); c = logical channels.  f32 -> bf16 / fp16 / split planes and back.
+    weights: the split layout is [hi | hi | lo] (weights) instead of [hi | lo | hi] (activations)."""
+    _require_gpu(src, dst)
+    assert src.stride(-1) == 1 and dst.stride(-1) == 1
+    rows = src.numel() // src.shape[-1]
+    assert rows == dst.numel() // dst.shape[-1]
+
+    def pitch(t):
+        if t.dim() == 1:
+            return t.shape[0]
+        ld = t.stride(-2)
+        exp = ld
+        for d in range(t.dim() - 2, -1, -1):  # rows must be equally spaced
+            assert t.stride(d) == exp or t.shape[d] == 1, "rows must be densely packed"
+            exp *= t.shape[d]
+        return ld
+
+    sf = PS_BF16X3 if src_split else _dt(src)
+    df = PS_BF16X3 if dst_split else _dt(dst)
+    assert src.shape[-1] == (3 if src_split else 1) * c and dst.shape[-1] == (3 if dst_split else 1) * c
+    lib = _lib.load()
+    _lib.check(lib.ps_convert_rows(src.data_ptr(), sf, pitch(src), dst.data_ptr(), df, pitch(dst), rows, c, int(weights), _stream()), "ps_convert_rows")
 
 
 def cast_f32_bf16(src: Tensor, dst: Tensor) -> None:
@@ -551,10 +627,10 @@ def ecr_tensor(ref: Tensor, rv: Tensor, label: Tensor, out: Tensor) -> None:
     _lib.check(lib.ps_ecr_tensor(ref.data_ptr(), rv.data_ptr(), label.data_ptr(), out.data_ptr(), n, c, h, w, _stream()), "ps_ecr_tensor")
 
 
-def ecr_bwd(ref, rv, label, t, thr, take, drv, grad_scale: float) -> None:
+def ecr_bwd(ref, rv, label, t, thr, take, drv, grad_scale: float, deterministic: Optional[bool] = None) -> None:
     n, c, h, w = rv.shape
     lib = _lib.load()
-    if deterministic_enabled():  # ties at the threshold taken in index order (ps_ecr_bwd_det) instead of first come, first served
+    if deterministic_enabled(deterministic):  # ties at the threshold taken in index order (ps_ecr_bwd_det) instead of first come, first served
         need = int(lib.ps_tie_workspace_ints(n, h, w))
         counts = torch.empty(need, device=rv.device, dtype=torch.int32)
         _lib.check(lib.ps_ecr_bwd_det(ref.data_ptr(), rv.data_ptr(), label.data_ptr(), t.data_ptr(), thr.data_ptr(), take.data_ptr(), counts.data_ptr(),
@@ -617,10 +693,10 @@ def chmax(x: Tensor, label: Tensor):
     return m, arg
 
 
-def minpool_bwd(m, arg, label, thr, take, dx, grad_scale: float) -> None:
+def minpool_bwd(m, arg, label, thr, take, dx, grad_scale: float, deterministic: Optional[bool] = None) -> None:
     n, c, h, w = dx.shape
     lib = _lib.load()
-    if deterministic_enabled():
+    if deterministic_enabled(deterministic):
         need = int(lib.ps_tie_workspace_ints(n, h, w))
         counts = torch.empty(need, device=dx.device, dtype=torch.int32)
         _lib.check(lib.ps_minpool_bwd_det(m.data_ptr(), arg.data_ptr(), label.data_ptr(), thr.data_ptr(), take.data_ptr(), counts.data_ptr(), need,

@@ -6,7 +6,10 @@ Same module tree / state-dict keys (`b{2..7}[_k].{bn_branch2a,conv_branch2a,bn_b
 nn.BatchNorm2d children are *parameter holders only*: the arithmetic runs as a fixed plan of fused HIP
 launches (pistoseg_amd/ops.py -> libpistoseg_hip.so):
 
-  * activations are channels-last [N,H,W,C] in the compute dtype (bf16, or f32 for the parity path);
+  * activations are channels-last [N,H,W,C] in the compute dtype (bf16 / fp16, or f32 for the exact parity path) -- or, with
+    precision="bf16x3", SPLIT bf16: three planes [hi | lo | hi] of C channels per pixel (value = hi + lo, 16 mantissa bits) against
+    weights split [hi | hi | lo], so that the same 16-bit MFMA kernels compute x_hi w_hi + x_lo w_hi + x_hi w_lo with f32 accumulation:
+    the reference's fp32 results (resnet38d.py:156-188) to 1e-4 at a third of the bf16 rate instead of a sixteenth (exact-f32 MFMA);
   * every conv writes, from its epilogue, the NEXT BatchNorm+ReLU(+Dropout2d) already applied, plus the raw
     residual stream only where an identity shortcut will read it (pre-activation net: BN/ReLU are
     frozen per-channel affines, resnet38d.py:206-211);
@@ -103,8 +106,11 @@ class Net(nn.Module):
 
     def __init__(self, precision: str = "bf16", units=None):
         super().__init__()
-        assert precision in ("bf16", "fp16", "fp32")
+        assert precision in ("bf16", "fp16", "fp32", "bf16x3")
         self.precision = precision
+        self.split = precision == "bf16x3"  # activations / gradients as bf16 planes [hi | lo | hi] (ops.conv2d_fwd(split=True), PS_BF16X3)
+        self.cm = 3 if self.split else 1    # stored channels per logical channel
+        self.launch = ops.LaunchOpts()      # this model's launch options (tiles_per_block / gpu_shared / deterministic), passed to every conv launch
         self.units = list(UNITS if units is None else units)  # the OEEM stage-0 net differs in b7's dilation only (oeem.py)
         self.conv1a = nn.Conv2d(3, 64, 3, padding=1, bias=False)
         for name, kind, cin, cmid, cout, stride, fdil, dil, p in self.units:
@@ -135,7 +141,7 @@ class Net(nn.Module):
     def forward_as_dict(self, x):
         """NCHW f32 feature dict {conv3, conv4, conv5, conv6} (resnet38d.py:159-188)."""
         feats, _ = self.run_backbone(x, save=False, drop=self.sample_dropout(x.shape[0], x.device) if self.training else None)
-        return {k: v.permute(0, 3, 1, 2).float() for k, v in feats.items()}
+        return {k: self.act_to_f32(v).permute(0, 3, 1, 2) for k, v in feats.items()}
 
     def train(self, mode=True):
         """Quirk kept from resnet38d.py:191-213: freezes `not_training` layers and every BatchNorm (which
@@ -160,7 +166,30 @@ class Net(nn.Module):
     # ------------------------------------------------------------------ device-side views of the parameters
     @property
     def compute_dtype(self):
-        return {"bf16": torch.bfloat16, "fp16": torch.float16}.get(self.precision, torch.float32)
+        return {"bf16": torch.bfloat16, "fp16": torch.float16, "bf16x3": torch.bfloat16}.get(self.precision, torch.float32)
+
+    def act_to_f32(self, t: Tensor) -> Tensor:
+        """An activation / gradient tensor of the plans ([N,H,W,cm*C], possibly a channel slice) as a contiguous f32 [N,H,W,C]: the edge
+        between the conv stack's storage format and the f32 head / loss kernels (f32 tensors pass through)."""
+        if t.dtype == torch.float32:
+            return t  # (possibly a channel slice: every kernel takes the channel stride)
+        c = t.shape[3] // self.cm
+        out = torch.empty(tuple(t.shape[:3]) + (c,), device=t.device, dtype=torch.float32)
+        ops.convert_rows(t, out, c, src_split=self.split)
+        return out
+
+    def act_from_f32(self, t: Tensor, out: Optional[Tensor] = None) -> Tensor:
+        """The inverse: f32 [N,H,W,C] -> the plans' storage format (into `out`, which may be a channel slice, or a new tensor)."""
+        c = t.shape[3]
+        if out is None:
+            if self.precision == "fp32":
+                return t
+            out = torch.empty(tuple(t.shape[:3]) + (self.cm * c,), device=t.device, dtype=self.compute_dtype)
+        if out.dtype == torch.float32:
+            out.copy_(t)
+        else:
+            ops.convert_rows(t, out, c, dst_split=self.split)
+        return out
 
     def _cached(self, key: str, deps: Tuple[Tensor, ...], make, raw_pointer_updates: bool = True):
         # raw_pointer_updates: the tensors may be rewritten behind torch's back by the fused optimiser (conv weights in the
@@ -174,16 +203,26 @@ class Net(nn.Module):
         self._cache[key] = (sig, val)
         return val
 
-    def w_fwd(self, conv: nn.Conv2d, key: str) -> Tensor:
-        """[cout][kh][kw][cin] in the compute dtype (the f32 parameter storage itself on the fp32 path)."""
+    def w_fwd(self, conv: nn.Conv2d, key: str, f32: bool = False) -> Tensor:
+        """[cout][kh][kw][cin] in the compute dtype (the f32 parameter storage itself on the fp32 path, or with f32=True: the heads that
+        compute in f32 inside the 16-bit models)."""
         w = conv.weight
         if not w.is_contiguous(memory_format=torch.channels_last) and w.shape[2] > 1:
             _channels_last_(conv)
             w = conv.weight
         flat = w.detach().permute(0, 2, 3, 1)
         assert flat.is_contiguous()
-        if self.precision == "fp32":
+        if self.precision == "fp32" or f32:
             return flat
+        if self.split:  # [cout][kh][kw][hi | hi | lo] of cin channels each, re-derived from the f32 master whenever it changed
+
+            def make_split():
+                cout, kh, kw, cin = flat.shape
+                out = torch.empty((cout, kh, kw, 3 * cin), device=w.device, dtype=torch.bfloat16)
+                ops.convert_rows(flat.reshape(cout * kh * kw, cin), out.view(cout * kh * kw, 3 * cin), cin, dst_split=True, weights=True)
+                return out
+
+            return self._cached("wf:" + key, (w,), make_split)
         shadow = self._bf16_shadow.get(key + ".weight")
         if shadow is not None:
             # The fused optimiser refreshes the shadow in the launch that updates the f32 master (raw pointers: no version bump).
@@ -201,10 +240,23 @@ class Net(nn.Module):
 
         return self._cached("wf:" + key, (w,), make)
 
-    def w_dgrad(self, conv: nn.Conv2d, key: str) -> Tensor:
-        """[cin][kh][kw][cout] in the compute dtype."""
+    def w_dgrad(self, conv: nn.Conv2d, key: str, f32: bool = False) -> Tensor:
+        """[cin][kh][kw][cout] in the compute dtype (f32=True: in f32, see w_fwd)."""
         w = conv.weight
         cout, cin, k, _ = w.shape
+        if (f32 and self.precision != "fp32") or self.split:
+            # transposed in f32, then (split path) cut into planes [hi | hi | lo] along cout; re-derived lazily when the master changes
+
+            def make_f32():
+                t = torch.empty((cin, k, k, cout), device=w.device, dtype=torch.float32)
+                ops.weight_transpose(self.w_fwd(conv, key, f32=True), t, cout, k * k, cin)
+                if f32:
+                    return t
+                out = torch.empty((cin, k, k, 3 * cout), device=w.device, dtype=torch.bfloat16)
+                ops.convert_rows(t.view(cin * k * k, cout), out.view(cin * k * k, 3 * cout), cout, dst_split=True, weights=True)
+                return out
+
+            return self._cached(("wd32:" if f32 else "wd:") + key, (w,), make_f32)
 
         def make():
             src = self.w_fwd(conv, key)
@@ -242,9 +294,10 @@ class Net(nn.Module):
         cout, cin, c2 = w1.shape[0], w1.shape[1], w2.shape[1]
 
         def make():
-            out = torch.empty((cout, cin + c2), device=w1.device, dtype=self.compute_dtype)
-            ops.copy_rows(self.w_fwd(unit.conv_branch1, name + ".conv_branch1").reshape(cout, cin), out[:, :cin])
-            ops.copy_rows(self.w_fwd(unit.conv_branch2b2, name + ".conv_branch2b2").reshape(cout, c2), out[:, cin:])
+            m = self.cm  # (split path: [hi | hi | lo] of conv_branch1, then [hi | hi | lo] of conv_branch2b2 -- the order of the activation planes)
+            out = torch.empty((cout, m * (cin + c2)), device=w1.device, dtype=self.compute_dtype)
+            ops.copy_rows(self.w_fwd(unit.conv_branch1, name + ".conv_branch1").reshape(cout, m * cin), out[:, :m * cin])
+            ops.copy_rows(self.w_fwd(unit.conv_branch2b2, name + ".conv_branch2b2").reshape(cout, m * c2), out[:, m * cin:])
             return out
 
         return self._cached("wfc:" + name, (w1, w2), make)
@@ -254,6 +307,17 @@ class Net(nn.Module):
         input): d/da = W1^T G + W2a^T g2 is one 1x1 data gradient over the concatenated gradient [G | g2]."""
         w1, w2 = unit.conv_branch1.weight, unit.conv_branch2a.weight
         cout, cin, c4 = w1.shape[0], w1.shape[1], w2.shape[0]
+
+        def make_split():
+            out = torch.empty((cin, 3 * (cout + c4)), device=w1.device, dtype=torch.bfloat16)
+            for conv, cname, lo, co in ((unit.conv_branch1, ".conv_branch1", 0, cout), (unit.conv_branch2a, ".conv_branch2a", 3 * cout, c4)):
+                t = torch.empty((cin, co), device=w1.device, dtype=torch.float32)
+                ops.weight_transpose(self.w_fwd(conv, name + cname, f32=True), t, co, 1, cin)
+                ops.convert_rows(t, out[:, lo:lo + 3 * co], co, dst_split=True, weights=True)
+            return out
+
+        if self.split:
+            return self._cached("wdc:" + name, (w1, w2), make_split)
 
         def make():
             out = torch.empty((cin, cout + c4), device=w1.device, dtype=self.compute_dtype)
@@ -271,11 +335,12 @@ class Net(nn.Module):
         as one GEMM (w_dgrad_cat).  Callers that produce the gradient of the LAST unit's output (head backward) should use this."""
         u = next(x for x in self.units if x[0] == name)
         cout = u[4]
+        m = self.cm
         if u[1] == "bot" and self.fuse_bottleneck:
-            buf = torch.empty((n, h, w, cout + cout // 4), device=device, dtype=dtype)
+            buf = torch.empty((n, h, w, m * (cout + cout // 4)), device=device, dtype=dtype)
             self._out_grad_buf[name] = buf
-            return buf[..., :cout]
-        return torch.empty((n, h, w, cout), device=device, dtype=dtype)
+            return buf[..., :m * cout]
+        return torch.empty((n, h, w, m * cout), device=device, dtype=dtype)
 
     def bn_affine(self, bn: nn.BatchNorm2d, key: str) -> Tuple[Tensor, Tensor]:
         """Eval-mode BN as y = x*scale + shift (f32 per-channel vectors; BN is frozen on this path)."""
@@ -336,22 +401,30 @@ class Net(nn.Module):
         saved = _Saved() if save else None
         feats: Dict[str, Tensor] = {}
 
-        def new(hh, ww, c):
-            return torch.empty((n, hh, ww, c), device=dev, dtype=dt)
+        cm, kw = self.cm, dict(split=self.split, opts=self.launch)
+
+        def new(hh, ww, c):  # c LOGICAL channels (split path: three bf16 planes each)
+            return torch.empty((n, hh, ww, cm * c), device=dev, dtype=dt)
 
         def new_unit_input(hh, ww, idx):
             """Activated input of unit idx; for a fused bottleneck unit it is the first cin channels of [a | a3]."""
             u = self.units[idx]
             if u[1] == "bot" and self.fuse_bottleneck:
                 wide = new(hh, ww, u[2] + u[4] // 2)
-                return wide[..., :u[2]], wide
+                return wide[..., :cm * u[2]], wide
             return new(hh, ww, u[2]), None
 
         first = getattr(self, self.units[0][0])
         sc0, sh0 = self.bn_affine(first.bn_branch2a, self.units[0][0] + ".bn_branch2a")
         a = new(h, w, 64)
         a_wide = None
-        ops.conv1a_fwd(x, self.conv1a.weight.detach().contiguous(), sc0, sh0, a)
+        if self.split:  # conv1a (3 -> 64) on the exact-f32 kernel, then cut into planes
+            a32 = torch.empty((n, h, w, 64), device=dev, dtype=torch.float32)
+            ops.conv1a_fwd(x, self.conv1a.weight.detach().contiguous(), sc0, sh0, a32)
+            ops.convert_rows(a32, a, 64, dst_split=True)
+            del a32
+        else:
+            ops.conv1a_fwd(x, self.conv1a.weight.detach().contiguous(), sc0, sh0, a)
         xraw = None
         for i, (name, kind, cin, cmid, cout, stride, fdil, dil, _p) in enumerate(self.units):
             unit = getattr(self, name)
@@ -375,18 +448,22 @@ class Net(nn.Module):
                 shortcut = xraw
             elif not fused:
                 shortcut = new(ho, wo, cout)
-                ops.conv2d_fwd(specs["conv_branch1"], a, self.w_fwd(unit.conv_branch1, name + ".conv_branch1"), out_raw=shortcut)
-            if i + 1 < len(self.units):
+                ops.conv2d_fwd(specs["conv_branch1"], a, self.w_fwd(unit.conv_branch1, name + ".conv_branch1"), out_raw=shortcut, **kw)
+            last = i + 1 == len(self.units)
+            # inference with the head folded into the last unit's final launch: conv6 is never written, so it is not even allocated
+            head_fused = (last and fused and head is not None and not save and head.shape[1] == cout and not self.split
+                          and ops.conv1x1_head_supported(ConvSpec(cin + cout // 2, cout, 1), a_wide, head.shape[0]) > 0)
+            if not last:
                 a_next, a_wide_next = new_unit_input(ho, wo, i + 1)
             else:
-                a_next, a_wide_next = new(ho, wo, cout), None
+                a_next, a_wide_next = (None if head_fused else new(ho, wo, cout)), None
             xraw_next = new(ho, wo, cout) if need_raw else None
             if kind == "res":
                 s1, b1 = self.bn_affine(unit.bn_branch2b1, name + ".bn_branch2b1")
                 a2 = new(ho, wo, cmid)
-                ops.conv2d_fwd(specs["conv_branch2a"], a, self.w_fwd(unit.conv_branch2a, name + ".conv_branch2a"), bn_scale=s1, bn_shift=b1, out_act=a2)
+                ops.conv2d_fwd(specs["conv_branch2a"], a, self.w_fwd(unit.conv_branch2a, name + ".conv_branch2a"), bn_scale=s1, bn_shift=b1, out_act=a2, **kw)
                 ops.conv2d_fwd(specs["conv_branch2b1"], a2, self.w_fwd(unit.conv_branch2b1, name + ".conv_branch2b1"), add0=shortcut,
-                               out_raw=xraw_next, bn_scale=nscale, bn_shift=nshift, out_act=a_next)
+                               out_raw=xraw_next, bn_scale=nscale, bn_shift=nshift, out_act=a_next, **kw)
                 if saved is not None:
                     saved.mid[name] = (a2,)
             else:
@@ -394,23 +471,20 @@ class Net(nn.Module):
                 s1, b1 = self.bn_affine(unit.bn_branch2b1, name + ".bn_branch2b1")
                 s2, b2 = self.bn_affine(unit.bn_branch2b2, name + ".bn_branch2b2")
                 a2 = new(ho, wo, cout // 4)
-                ops.conv2d_fwd(specs["conv_branch2a"], a, self.w_fwd(unit.conv_branch2a, name + ".conv_branch2a"), bn_scale=s1, bn_shift=b1, drop=d1, out_act=a2)
-                a3 = a_wide[..., cin:] if fused else new(ho, wo, cout // 2)
-                ops.conv2d_fwd(specs["conv_branch2b1"], a2, self.w_fwd(unit.conv_branch2b1, name + ".conv_branch2b1"), bn_scale=s2, bn_shift=b2, drop=d2, out_act=a3)
+                ops.conv2d_fwd(specs["conv_branch2a"], a, self.w_fwd(unit.conv_branch2a, name + ".conv_branch2a"), bn_scale=s1, bn_shift=b1, drop=d1, out_act=a2, **kw)
+                a3 = a_wide[..., cm * cin:] if fused else new(ho, wo, cout // 2)
+                ops.conv2d_fwd(specs["conv_branch2b1"], a2, self.w_fwd(unit.conv_branch2b1, name + ".conv_branch2b1"), bn_scale=s2, bn_shift=b2, drop=d2, out_act=a3, **kw)
                 if fused:  # branch1(a) + branch2b2(a3) = one 1x1 conv over [a | a3]: no shortcut tensor, no residual read
                     cat_spec = ConvSpec(cin + cout // 2, cout, 1)
-                    last = i + 1 == len(self.units)
-                    if (last and head is not None and not save and xraw_next is None and head.shape[1] == cout
-                            and ops.conv1x1_head_supported(cat_spec, a_wide, head.shape[0]) > 0):
+                    if head_fused:
                         cam = torch.empty((n, ho, wo, head.shape[0]), device=dev, dtype=torch.float32)
                         ops.conv1x1_head_fwd(cat_spec, a_wide, self.w_fwd_cat(unit, name), nscale, nshift, head, cam)
                         feats["cam"] = cam
-                        a_next = None
                     else:
-                        ops.conv2d_fwd(cat_spec, a_wide, self.w_fwd_cat(unit, name), out_raw=xraw_next, bn_scale=nscale, bn_shift=nshift, out_act=a_next)
+                        ops.conv2d_fwd(cat_spec, a_wide, self.w_fwd_cat(unit, name), out_raw=xraw_next, bn_scale=nscale, bn_shift=nshift, out_act=a_next, **kw)
                 else:
                     ops.conv2d_fwd(specs["conv_branch2b2"], a3, self.w_fwd(unit.conv_branch2b2, name + ".conv_branch2b2"), add0=shortcut,
-                                   out_raw=xraw_next, bn_scale=nscale, bn_shift=nshift, out_act=a_next)
+                                   out_raw=xraw_next, bn_scale=nscale, bn_shift=nshift, out_act=a_next, **kw)
                 if saved is not None:
                     saved.mid[name] = (a2, a3)
                     saved.drop[name + ".dropout_2b1"], saved.drop[name + ".dropout_2b2"] = d1, d2
@@ -446,17 +520,18 @@ class Net(nn.Module):
         self.refresh_dgrad_weights()
         self._out_grad_buf = {k: v for k, v in self._out_grad_buf.items() if k == self.units[-1][0]}  # drop stale buffers of aborted steps
         dt, dev, n = G.dtype, G.device, saved.n
-        shared_before = ops.GPU_SHARED
+        shared_before = self.launch.gpu_shared
         if wgrad_stream is not None:
-            ops.GPU_SHARED = 1  # the data gradients' partial last rounds are filled by the side stream's weight-gradient blocks (ps_conv_geom.gpu_shared)
+            self.launch.gpu_shared = 1  # the data gradients' partial last rounds are filled by the side stream's weight-gradient blocks (ps_conv_geom.gpu_shared)
         try:
             self._backward_units(saved, G, grads, g_taps, after_unit, wgrad_stream, first, dt, dev, n)
         finally:
-            ops.GPU_SHARED = shared_before
+            self.launch.gpu_shared = shared_before
         if wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(wgrad_stream)
 
     def _backward_units(self, saved, G, grads, g_taps, after_unit, wgrad_stream, first, dt, dev, n) -> None:
+        cm, kw = self.cm, dict(split=self.split, opts=self.launch)
         for i in range(len(self.units) - 1, -1, -1):
             name, kind, cin, cmid, cout, stride, fdil, dil, _p = self.units[i]
             if i < first:
@@ -476,16 +551,16 @@ class Net(nn.Module):
                 if not p.requires_grad:
                     return
                 if wgrad_stream is None:
-                    ops.conv2d_wgrad(specs[cname], x_act, dy, grads[f"{name}.{cname}.weight"])
+                    ops.conv2d_wgrad(specs[cname], x_act, dy, grads[f"{name}.{cname}.weight"], **kw)
                     return
                 wgrad_stream.wait_stream(torch.cuda.current_stream())  # dy (and the zeroed gradient arena) are ready
                 with torch.cuda.stream(wgrad_stream):
-                    ops.conv2d_wgrad(specs[cname], x_act, dy, grads[f"{name}.{cname}.weight"])
+                    ops.conv2d_wgrad(specs[cname], x_act, dy, grads[f"{name}.{cname}.weight"], **kw)
                 x_act.record_stream(wgrad_stream)  # keep the caching allocator from recycling them under the side stream
                 dy.record_stream(wgrad_stream)
 
             def new(hh, ww, c):
-                return torch.empty((n, hh, ww, c), device=dev, dtype=dt)
+                return torch.empty((n, hh, ww, cm * c), device=dev, dtype=dt)
 
             if kind == "res":
                 (a2,) = saved.mid[name]
@@ -493,7 +568,7 @@ class Net(nn.Module):
                 wgrad("conv_branch2b1", a2, G)
                 gh = new(ho, wo, cmid)
                 ops.conv2d_dgrad(specs["conv_branch2b1"], G, self.w_dgrad(unit.conv_branch2b1, name + ".conv_branch2b1"), (ho, wo),
-                                 mask_src=a2, bn_scale=s1, out=gh)
+                                 mask_src=a2, bn_scale=s1, out=gh, **kw)
                 wgrad("conv_branch2a", a, gh)
                 if not same:
                     wgrad("conv_branch1", a, G)
@@ -502,12 +577,12 @@ class Net(nn.Module):
                     if same:
                         assert tap is None
                         ops.conv2d_dgrad(specs["conv_branch2a"], gh, self.w_dgrad(unit.conv_branch2a, name + ".conv_branch2a"), (h, w),
-                                         mask_src=a, bn_scale=s_in, add1=G, out=Gp)
+                                         mask_src=a, bn_scale=s_in, add1=G, out=Gp, **kw)
                     else:
                         t = new(h, w, cin)
-                        ops.conv2d_dgrad(specs["conv_branch1"], G, self.w_dgrad(unit.conv_branch1, name + ".conv_branch1"), (h, w), add0=tap, out_raw=t)
+                        ops.conv2d_dgrad(specs["conv_branch1"], G, self.w_dgrad(unit.conv_branch1, name + ".conv_branch1"), (h, w), add0=tap, out_raw=t, **kw)
                         ops.conv2d_dgrad(specs["conv_branch2a"], gh, self.w_dgrad(unit.conv_branch2a, name + ".conv_branch2a"), (h, w),
-                                         add0=t, mask_src=a, bn_scale=s_in, out=Gp)
+                                         add0=t, mask_src=a, bn_scale=s_in, out=Gp, **kw)
                     G = Gp
             else:
                 a2, a3 = saved.mid[name]
@@ -521,11 +596,11 @@ class Net(nn.Module):
                 wgrad("conv_branch2b2", a3, G)
                 g3 = new(ho, wo, cout // 2)
                 ops.conv2d_dgrad(specs["conv_branch2b2"], G, self.w_dgrad(unit.conv_branch2b2, name + ".conv_branch2b2"), (ho, wo),
-                                 mask_src=a3, bn_scale=s2, drop=d2, out=g3)
+                                 mask_src=a3, bn_scale=s2, drop=d2, out=g3, **kw)
                 wgrad("conv_branch2b1", a2, g3)
-                g2 = GG[..., cout:] if fused else new(ho, wo, cout // 4)
+                g2 = GG[..., cm * cout:] if fused else new(ho, wo, cout // 4)
                 ops.conv2d_dgrad(specs["conv_branch2b1"], g3, self.w_dgrad(unit.conv_branch2b1, name + ".conv_branch2b1"), (ho, wo),
-                                 mask_src=a2, bn_scale=s1, drop=d1, out=g2)
+                                 mask_src=a2, bn_scale=s1, drop=d1, out=g2, **kw)
                 wgrad("conv_branch2a", a, g2)
                 wgrad("conv_branch1", a, G)
                 if need_dx:
@@ -533,12 +608,12 @@ class Net(nn.Module):
                     Gp = self.alloc_unit_out_grad(prev, n, h, w, dev, dt)
                     if fused:
                         ops.conv2d_dgrad(ConvSpec(cin, cout + cout // 4, 1), GG, self.w_dgrad_cat(unit, name), (h, w),
-                                         add0=tap, mask_src=a, bn_scale=s_in, out=Gp)
+                                         add0=tap, mask_src=a, bn_scale=s_in, out=Gp, **kw)
                     else:
                         t = new(h, w, cin)
-                        ops.conv2d_dgrad(specs["conv_branch1"], G, self.w_dgrad(unit.conv_branch1, name + ".conv_branch1"), (h, w), add0=tap, out_raw=t)
+                        ops.conv2d_dgrad(specs["conv_branch1"], G, self.w_dgrad(unit.conv_branch1, name + ".conv_branch1"), (h, w), add0=tap, out_raw=t, **kw)
                         ops.conv2d_dgrad(specs["conv_branch2a"], g2, self.w_dgrad(unit.conv_branch2a, name + ".conv_branch2a"), (h, w),
-                                         add0=t, mask_src=a, bn_scale=s_in, out=Gp)
+                                         add0=t, mask_src=a, bn_scale=s_in, out=Gp, **kw)
                     G = Gp
             if after_unit is not None:
                 if wgrad_stream is None:

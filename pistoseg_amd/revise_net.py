@@ -12,6 +12,13 @@ arithmetic is a fixed plan of HIP launches:
 
 `get_norm_cam_d` is no-grad in the reference (revise_net.py:32): cam_rv / pmask_rv / pcam_rv receive gradient
 only through A (-> f9 -> f8_3/f8_4 -> conv4/conv5 taps -> backbone); fc8 trains only through `cam`.
+
+The RFM heads compute in f32 whatever the backbone's precision: the concat feature F, q | k, the affinity matrix and
+their gradients are f32 tensors and `f8_3` / `f8_4` / `f9_1` / `f9_2` run on the exact-f32 MFMA kernels with the f32
+master weights (0.4 GF per tile of a 556 GF step).  The three `*_rv` outputs reach the loss ONLY through that matrix
+-- a 192-deep dot product of q and k into a softmax (revise_net.py:61-75) -- so 16-bit rounding of F / q / k was the
+stage-3 loss's whole signal path (round 3: `f8_4.weight` gradient 21 % off the CPU oracle in the bf16 model).  The
+16-bit / split taps conv4 / conv5 are widened on the way in and the tap gradients narrowed on the way out.
 """
 from __future__ import annotations
 
@@ -81,7 +88,7 @@ class Net(ResNet38dSeg):
                 for conv in (self.f9_1, self.f9_2):
                     w = conv.weight.detach().reshape(192, 195).float()
                     rows.append(torch.cat([w[:, 3:67], w[:, 67:195], w[:, 0:3], w.new_zeros(192, FCAT - 195)], dim=1))
-                return torch.cat(rows, dim=0).to(self.compute_dtype).contiguous()
+                return torch.cat(rows, dim=0).contiguous()  # f32: the heads compute in f32 in every precision
 
         wf = self._cached("w9f", (self.f9_1.weight, self.f9_2.weight), make_fwd)
         if not transposed:
@@ -113,20 +120,23 @@ class Net(ResNet38dSeg):
         conv4, conv5 = feats["conv4"], feats["conv5"]
         g1, g2 = conv5.shape[1:3]
         P = g1 * g2
-        dev, dt = x.device, self.compute_dtype
+        dev, dt, kw = x.device, torch.float32, dict(opts=self.launch)  # dt: the heads' dtype (module docstring)
         if "cam" in feats:
             cam_lr = feats["cam"]
         else:  # fc8 on dropout7(conv6)
             cam_lr = torch.empty((n, g1, g2, C), device=dev, dtype=torch.float32)
-            ops.fc8_fwd(feats["conv6"], self.fc8.weight.detach().reshape(C, 4096), drop.get("dropout7"), cam_lr)
-        # concat feature (revise_net.py:61-66)
+            conv6 = self.act_to_f32(feats["conv6"]) if self.split else feats["conv6"]
+            ops.fc8_fwd(conv6, self.fc8.weight.detach().reshape(C, 4096), drop.get("dropout7"), cam_lr)
+            del conv6
+        # concat feature (revise_net.py:61-66), in f32 from the widened taps
+        c4f, c5f = self.act_to_f32(conv4), self.act_to_f32(conv5)
         F = torch.zeros((n, g1, g2, FCAT), device=dev, dtype=dt)
-        ops.conv2d_fwd(ConvSpec(512, 64, 1), conv4, self.w_fwd(self.f8_3, "f8_3"), out_act=F[..., 0:64])
-        ops.conv2d_fwd(ConvSpec(1024, 128, 1), conv5, self.w_fwd(self.f8_4, "f8_4"), out_act=F[..., 64:192])
+        ops.conv2d_fwd(ConvSpec(512, 64, 1), c4f, self.w_fwd(self.f8_3, "f8_3", f32=True), out_act=F[..., 0:64], **kw)
+        ops.conv2d_fwd(ConvSpec(1024, 128, 1), c5f, self.w_fwd(self.f8_4, "f8_4", f32=True), out_act=F[..., 64:192], **kw)
         ops.bilinear_fwd(x, "nchw", F[..., 192:195], "nhwc", True)
         # q | k (revise_net.py:69-71)
         QK = torch.empty((n, g1, g2, 384), device=dev, dtype=dt)
-        ops.conv2d_fwd(ConvSpec(FCAT, 384, 1), F, self._w9(False), out_raw=QK)
+        ops.conv2d_fwd(ConvSpec(FCAT, 384, 1), F, self._w9(False), out_raw=QK, **kw)
         # transposed affinity: S[b][j][i] = sum_c k[b,j,c] * q[b,i,c]; softmax over i (= dim 1 of A)
         q, k = QK[..., :192], QK[..., 192:]
         Pm = torch.empty((n, P, P), device=dev, dtype=torch.float32)
@@ -152,7 +162,7 @@ class Net(ResNet38dSeg):
             outs.append(o)
         ctx = None
         if save:
-            ctx = dict(saved=saved, F=F, QK=QK, Pm=Pm, V=V, R=R, conv4=conv4, conv5=conv5, drop7=drop.get("dropout7"), hw=(H, W), g=(g1, g2))
+            ctx = dict(saved=saved, F=F, QK=QK, Pm=Pm, V=V, R=R, conv4=c4f, conv5=c5f, drop7=drop.get("dropout7"), hw=(H, W), g=(g1, g2))
         return tuple(outs), ctx
 
     # ------------------------------------------------------------------ reverse plan
@@ -165,7 +175,7 @@ class Net(ResNet38dSeg):
         n, C = saved.n, self.classes
         g1, g2 = ctx["g"]
         P = g1 * g2
-        dev, dt = F.device, F.dtype
+        dev, dt, kw = F.device, F.dtype, dict(opts=self.launch)  # (f32: see the module docstring)
         d_cam, d_rvs = d_outs[0], d_outs[1:]
         g_taps = {}
         if any(d is not None for d in d_rvs):
@@ -183,17 +193,17 @@ class Net(ResNet38dSeg):
             ops.bgemm(dS, q, dQK[..., 192:], n, P, 192, P, (P * P, P, 1), (P * 384, 384, 1), (P * 384, 384, 1))
             spec9 = ConvSpec(FCAT, 384, 1)
             if "f9" in grads:
-                ops.conv2d_wgrad(spec9, F, dQK, grads["f9"])
+                ops.conv2d_wgrad(spec9, F, dQK, grads["f9"], **kw)
             dFm = torch.empty_like(F)
-            ops.conv2d_dgrad(spec9, dQK, self._w9(True), (g1, g2), mask_src=F, out=dFm)
+            ops.conv2d_dgrad(spec9, dQK, self._w9(True), (g1, g2), mask_src=F, out=dFm, **kw)
             for name, conv, lo, hi, tapname, cin in (("f8_3", self.f8_3, 0, 64, "conv4", 512), ("f8_4", self.f8_4, 64, 192, "conv5", 1024)):
                 spec = ConvSpec(cin, hi - lo, 1)
                 dy = dFm[..., lo:hi]
                 if f"{name}.weight" in grads:
-                    ops.conv2d_wgrad(spec, ctx[tapname], dy, grads[f"{name}.weight"])
+                    ops.conv2d_wgrad(spec, ctx[tapname], dy, grads[f"{name}.weight"], **kw)
                 gt = torch.empty((n, g1, g2, cin), device=dev, dtype=dt)
-                ops.conv2d_dgrad(spec, dy, self.w_dgrad(conv, name), (g1, g2), out_raw=gt)
-                g_taps[tapname] = gt
+                ops.conv2d_dgrad(spec, dy, self.w_dgrad(conv, name, f32=True), (g1, g2), out_raw=gt, **kw)
+                g_taps[tapname] = self.act_from_f32(gt)  # narrowed to the backbone's storage format: the reverse plan adds it to the unit's input gradient
         dw8 = grads["fc8.weight"].view(C, 4096) if "fc8.weight" in grads else torch.zeros((C, 4096), device=dev)
         if d_cam is None:
             d_cam = torch.zeros((n, C) + tuple(ctx["hw"]), device=dev)

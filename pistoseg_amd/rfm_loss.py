@@ -27,10 +27,12 @@ def _ecr_reference(p: Tensor, label: Tensor, hw) -> Tensor:
     return up
 
 
-def rfm_losses(outputs, pmask: Tensor, pcam: Tensor, label: Tensor, want_grad: bool, grad_scale: float = 1.0):
+def rfm_losses(outputs, pmask: Tensor, pcam: Tensor, label: Tensor, want_grad: bool, grad_scale: float = 1.0, deterministic: Optional[bool] = None):
     """outputs = (cam, cam_rv, pmask_rv, pcam_rv), NCHW f32 on the device; pmask / pcam carry the zero background
     channel; label: [N, C] (or [N,C,1,1]) with label[:, 0] = 1.
-    Returns ((loss, loss_cls, loss_rfm, loss_ecr), grads or None) with grads = (d_cam, d_cam_rv, d_pmask_rv, d_pcam_rv)."""
+    Returns ((loss, loss_cls, loss_rfm, loss_ecr), grads or None) with grads = (d_cam, d_cam_rv, d_pmask_rv, d_pcam_rv).
+    deterministic: the top-k backwards take elements tied at the threshold in index order (the caller's setting; None = ops' default,
+    i.e. torch.use_deterministic_algorithms, revise_pseudo_labels.py:140-146)."""
     cam, cam_rv, pmask_rv, pcam_rv = [t.contiguous() for t in outputs]
     n, c, H, W = cam.shape
     dev = cam.device
@@ -53,7 +55,7 @@ def rfm_losses(outputs, pmask: Tensor, pcam: Tensor, label: Tensor, want_grad: b
     thr, take, sums = ops.topk_select(m, k, largest=False, relu=True)
     ops.sum_scaled(sums, 1.0 / (k * n), l_cls, accumulate=True)
     if want_grad:
-        ops.minpool_bwd(m, arg, label, thr, take, d_cam_rv, grad_scale / (k * n))
+        ops.minpool_bwd(m, arg, label, thr, take, d_cam_rv, grad_scale / (k * n), deterministic=deterministic)
 
     # ---- loss_rfm = mean |pmask_rv*label - pcam_rv*label| over the foreground channels
     ops.l1_masked(pmask_rv, pcam_rv, label, l_rfm, accumulate=False, da=d_pm, db=d_pc, grad_scale=grad_scale)
@@ -68,7 +70,7 @@ def rfm_losses(outputs, pmask: Tensor, pcam: Tensor, label: Tensor, want_grad: b
         thr, take, sums = ops.topk_select(t.view(n, -1), k2, largest=True)
         ops.sum_scaled(sums, 1.0 / (k2 * n), l_ecr, accumulate=True)
         if want_grad:
-            ops.ecr_bwd(ref, rv, label, t, thr, take, drv, grad_scale / (k2 * n))
+            ops.ecr_bwd(ref, rv, label, t, thr, take, drv, grad_scale / (k2 * n), deterministic=deterministic)
     total = l_cls + l_rfm + l_ecr
     grads = (d_cam, d_cam_rv, d_pm, d_pc) if want_grad else None
     return (total, l_cls, l_rfm, l_ecr), grads

@@ -36,6 +36,8 @@ class ResNet38dSeg(resnet38d.Net):
 
     # ------------------------------------------------------------------ head
     def head_forward(self, conv6: Tensor, drop7: Optional[Tensor], out_hw) -> (Tensor, Tensor):
+        if self.split:
+            conv6 = self.act_to_f32(conv6)  # the head reads conv6 = hi + lo in f32 (the narrow-head kernels take f32 / 16-bit tensors)
         n, g1, g2, _ = conv6.shape
         cam = torch.empty((n, g1, g2, self.classes), device=conv6.device, dtype=torch.float32)
         ops.fc8_fwd(conv6, self.fc8.weight.detach().reshape(self.classes, 4096), drop7, cam)
@@ -50,6 +52,11 @@ class ResNet38dSeg(resnet38d.Net):
         ops.bilinear_bwd(dlogits.contiguous(), "nchw", dcam, "nhwc", True)
         scale7, _ = self.bn_affine(self.bn7, "bn7")
         g_x7 = self.alloc_unit_out_grad(self.units[-1][0], n, g1, g2, conv6.device, conv6.dtype)  # [G | g2] buffer of the last unit
+        if self.split:  # f32 head backward on conv6 = hi + lo, its f32 result cut into planes
+            g32 = torch.empty((n, g1, g2, 4096), device=conv6.device, dtype=torch.float32)
+            ops.fc8_bwd(self.act_to_f32(conv6), self.fc8.weight.detach().reshape(self.classes, 4096), drop7, scale7, dcam, g32, dw8)
+            self.act_from_f32(g32, g_x7)
+            return g_x7
         ops.fc8_bwd(conv6, self.fc8.weight.detach().reshape(self.classes, 4096), drop7, scale7, dcam, g_x7, dw8)
         return g_x7
 
@@ -77,7 +84,7 @@ class ResNet38dSeg(resnet38d.Net):
     def max_tiles_per_launch(self, h: int, w: int) -> int:
         """Largest batch one forward plan can take: its biggest tensor (conv1a's 64-channel output at full resolution) must stay
         below 2 GiB, the range of the kernels' buffer descriptors (ps_conv2d_fwd rejects larger problems)."""
-        esize = 4 if self.precision == "fp32" else 2
+        esize = {"fp32": 4, "bf16x3": 6}.get(self.precision, 2)
         return max(1, ((1 << 31) - 1) // (h * w * 64 * esize))
 
     def new_grad_buffers(self, device) -> Dict[str, Tensor]:

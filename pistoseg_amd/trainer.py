@@ -91,12 +91,16 @@ class _ArenaMixin:
 class SegTrainer(_ArenaMixin):
     def __init__(self, model: ResNet38dSeg, lr: float = 1e-3, weight_decay: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8,
                  ignore_index: Optional[int] = 3, process_group=None, bucket_mb: float = 48.0, track_iou: bool = True,
-                 loss_scale: Optional[float] = None, overlap_wgrad: bool = True, deterministic: Optional[bool] = None):
+                 loss_scale: Optional[float] = None, overlap_wgrad: bool = True, deterministic: Optional[bool] = None, grad_payload: str = "fp32"):
+        """grad_payload: what the N > 1 gradient exchange puts on the wire -- "fp32" (SUM all-reduce of the f32 arena slices) or "bf16" (each
+        bucket cast to bf16, all-reduced, widened back: half the xGMI bytes; see dist.BucketedAllReduce)."""
         assert next(model.parameters()).is_cuda, "move the model to the GPU first"
         self.model = model
         # `pl.Trainer(deterministic=True)` (segmentation_train.py:153-160): weight gradients without atomics (ps_conv2d_wgrad_det), so two
         # identical runs are bit-identical.  None = follow torch.are_deterministic_algorithms_enabled(), the switch that call site sets.
+        # Per-trainer state: it lives in this model's launch options (ops.LaunchOpts), not in a process-wide switch.
         self.deterministic = deterministic
+        model.launch.deterministic = deterministic
         # weight gradients on a second stream (see Net.backward_backbone)
         self.wgrad_stream = torch.cuda.Stream(device=next(model.parameters()).device) if overlap_wgrad else None
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, betas, eps
@@ -114,7 +118,8 @@ class SegTrainer(_ArenaMixin):
         self.g_flat = torch.zeros(total, device=dev, dtype=torch.float32)
         self.m_flat = torch.zeros(total, device=dev, dtype=torch.float32)
         self.v_flat = torch.zeros(total, device=dev, dtype=torch.float32)
-        self.pb_flat = torch.empty(total, device=dev, dtype=model.compute_dtype) if model.precision != "fp32" else None
+        # 16-bit shadow of the weights, refreshed by the fused optimiser (the split path re-derives its [hi | hi | lo] planes from the master instead)
+        self.pb_flat = torch.empty(total, device=dev, dtype=model.compute_dtype) if model.precision in ("bf16", "fp16") else None
         # fp16 activations gradients underflow without a loss scale (a CE gradient is ~1/(N*H*W) = 3e-7 per pixel):
         # dynamic scaling a la torch.cuda.amp.GradScaler (x0.5 and skip on overflow, x2 every 200 clean steps).
         self.dynamic_scale = model.precision == "fp16" and loss_scale is None
@@ -139,7 +144,7 @@ class SegTrainer(_ArenaMixin):
         self.reducer: Optional[BucketedAllReduce] = None
         if self.world > 1:
             buckets = plan_buckets([(name, p.numel()) for name, p in self.entries], int(bucket_mb * (1 << 20) / 4))
-            self.reducer = BucketedAllReduce(self.g_flat, buckets, process_group)
+            self.reducer = BucketedAllReduce(self.g_flat, buckets, process_group, launch_opts=model.launch, payload=grad_payload)
         self.cm = torch.zeros(model.classes * model.classes, device=dev, dtype=torch.int64)  # train_iou confusion
 
     # ------------------------------------------------------------------
@@ -161,12 +166,8 @@ class SegTrainer(_ArenaMixin):
         if self.reducer is not None:
             self.reducer.begin_step()
             self.reducer.on_unit_done("fc8")
-        prev, ops.DETERMINISTIC = ops.DETERMINISTIC, (self.deterministic if self.deterministic is not None else ops.DETERMINISTIC)
-        try:
-            model.backward_backbone(saved, g_x7, self.grads, after_unit=self.reducer.on_unit_done if self.reducer is not None else None,
-                                    wgrad_stream=self.wgrad_stream)
-        finally:
-            ops.DETERMINISTIC = prev
+        model.backward_backbone(saved, g_x7, self.grads, after_unit=self.reducer.on_unit_done if self.reducer is not None else None,
+                                wgrad_stream=self.wgrad_stream)
         if self.reducer is not None:
             self.reducer.finish()
         if self.dynamic_scale:
@@ -198,12 +199,14 @@ class RFMTrainer(_ArenaMixin):
     """
 
     def __init__(self, model, lr: float = 0.01, wt_dec: float = 5e-4, max_step: int = 1000, power: float = 0.9, process_group=None,
-                 bucket_mb: float = 48.0, loss_scale: Optional[float] = None, overlap_wgrad: bool = True, deterministic: Optional[bool] = None):
+                 bucket_mb: float = 48.0, loss_scale: Optional[float] = None, overlap_wgrad: bool = True, deterministic: Optional[bool] = None,
+                 grad_payload: str = "fp32"):
         from .revise_net import FCAT, Net
 
         assert isinstance(model, Net) and next(model.parameters()).is_cuda
         self.model, self.FCAT = model, FCAT
         self.deterministic = deterministic  # torch.use_deterministic_algorithms(True) of revise_pseudo_labels.py:140-146; None = follow that switch
+        model.launch.deterministic = deterministic  # per-trainer state, carried by this model's launch options
         self.wgrad_stream = torch.cuda.Stream(device=next(model.parameters()).device) if overlap_wgrad else None  # see backward_backbone
         self.lr0, self.wt_dec, self.max_step, self.power = lr, wt_dec, max_step, power
         self.global_step = 0
@@ -216,7 +219,8 @@ class RFMTrainer(_ArenaMixin):
         self.p_flat = torch.empty(total, device=dev, dtype=torch.float32)
         self.g_flat = torch.zeros(total, device=dev, dtype=torch.float32)
         self.buf_flat = torch.zeros(total, device=dev, dtype=torch.float32)
-        self.pb_flat = torch.empty(total, device=dev, dtype=model.compute_dtype) if model.precision != "fp32" else None
+        # 16-bit shadow of the weights, refreshed by the fused optimiser (the split path re-derives its [hi | hi | lo] planes from the master instead)
+        self.pb_flat = torch.empty(total, device=dev, dtype=model.compute_dtype) if model.precision in ("bf16", "fp16") else None
         self.dynamic_scale = model.precision == "fp16" and loss_scale is None
         self.loss_scale = float(loss_scale) if loss_scale is not None else (1024.0 if model.precision == "fp16" else 1.0)
         self.clean_steps, self.skipped_steps = 0, 0
@@ -245,7 +249,7 @@ class RFMTrainer(_ArenaMixin):
         self.reducer: Optional[BucketedAllReduce] = None
         if self.world > 1:
             buckets = plan_buckets([(name, p.numel()) for name, p in self.entries], int(bucket_mb * (1 << 20) / 4))
-            self.reducer = BucketedAllReduce(self.g_flat, buckets, process_group)
+            self.reducer = BucketedAllReduce(self.g_flat, buckets, process_group, launch_opts=model.launch, payload=grad_payload)
 
     def train_step(self, x: Tensor, pmask: Tensor, pcam: Tensor, label: Tensor):
         """x [N,3,H,W]; pmask/pcam [N,C,32,32] with the zero background channel; label [N,C] with label[:,0] = 1.
@@ -257,11 +261,8 @@ class RFMTrainer(_ArenaMixin):
         self.f9_packed.zero_()
         drop = model.sample_dropout(x.shape[0], x.device)
         outs, ctx = model.rfm_forward(x, pmask, pcam, save=True, drop=drop)
-        prev, ops.DETERMINISTIC = ops.DETERMINISTIC, (self.deterministic if self.deterministic is not None else ops.DETERMINISTIC)
-        try:  # (the loss block's top-k backward chooses among exact ties: deterministic mode takes them in index order)
-            losses, d_outs = rfm_losses(outs, pmask, pcam, label, want_grad=True, grad_scale=self.loss_scale / self.world)
-        finally:
-            ops.DETERMINISTIC = prev
+        # (the loss block's top-k backward chooses among exact ties: deterministic mode takes them in index order)
+        losses, d_outs = rfm_losses(outs, pmask, pcam, label, want_grad=True, grad_scale=self.loss_scale / self.world, deterministic=self.deterministic)
         if self.reducer is not None:
             self.reducer.begin_step()
 
@@ -277,11 +278,7 @@ class RFMTrainer(_ArenaMixin):
             elif self.reducer is not None:
                 self.reducer.on_unit_done(name)
 
-        prev, ops.DETERMINISTIC = ops.DETERMINISTIC, (self.deterministic if self.deterministic is not None else ops.DETERMINISTIC)
-        try:
-            model.rfm_backward(ctx, list(d_outs), self.grads, after_unit=after, wgrad_stream=self.wgrad_stream)
-        finally:
-            ops.DETERMINISTIC = prev
+        model.rfm_backward(ctx, list(d_outs), self.grads, after_unit=after, wgrad_stream=self.wgrad_stream)
         if self.reducer is not None:
             self.reducer.finish()
         if self.dynamic_scale:

@@ -161,26 +161,32 @@ def test_deterministic_switch_follows_torch_unless_forced():
         torch.use_deterministic_algorithms(prev_flag)
 
 
-def test_gpu_shared_launch_option_reaches_the_geometry_and_is_restored(monkeypatch):
-    """`ops.GPU_SHARED` is the `gpu_shared` field of every `ps_conv_geom` built while it is set (include/pistoseg_hip.h), and the backbone's
-    two-stream backward sets it only for its own duration -- also when a launch raises."""
+def test_launch_options_are_per_model_state_and_reach_the_geometry(monkeypatch):
+    """`tiles_per_block` / `gpu_shared` are fields of every `ps_conv_geom` (include/pistoseg_hip.h).  On the host they are state of the CALLER:
+    each model owns an `ops.LaunchOpts` that its plans pass to every launch (a field left at None falls back to the module default, which only
+    direct users of `ops` -- op tests, probes -- change); the backbone's two-stream backward sets `gpu_shared` on ITS model for its own duration
+    only (also when a launch raises), the gradient reducer `tiles_per_block` on ITS model -- a second model in the process sees neither."""
     import torch
 
     from pistoseg_amd import ops
+    from pistoseg_amd.dist import BucketedAllReduce
     from pistoseg_amd.resnet38d import Net
 
     spec = ops.ConvSpec(512, 512, 3, 1, 1)
     assert ops._geom(spec, 1, 2, 28, 28, 512, 512).gpu_shared == 0
-    monkeypatch.setattr(ops, "GPU_SHARED", 1)
-    g = ops._geom(spec, 1, 2, 28, 28, 512, 512)
+    monkeypatch.setattr(ops, "GPU_SHARED", 1)  # module default: what a None field means
+    g = ops._geom(spec, 1, 2, 28, 28, 512, 512, ops.LaunchOpts())
     assert g.gpu_shared == 1 and g.tiles_per_block == ops.TILES_PER_BLOCK
+    g = ops._geom(spec, 1, 2, 28, 28, 512, 512, ops.LaunchOpts(tiles_per_block=3, gpu_shared=0))
+    assert g.gpu_shared == 0 and g.tiles_per_block == 3
     monkeypatch.setattr(ops, "GPU_SHARED", 0)
 
-    net = Net()
+    net, other = Net(), Net()
+    assert net.launch is not other.launch
     seen = []
 
     def fake_units(self, saved, G, grads, g_taps, after_unit, wgrad_stream, first, dt, dev, n):
-        seen.append(ops.GPU_SHARED)
+        seen.append((self.launch.gpu_shared, other.launch.gpu_shared))
         raise RuntimeError("launch failed")
 
     monkeypatch.setattr(Net, "_backward_units", fake_units)
@@ -193,12 +199,20 @@ def test_gpu_shared_launch_option_reaches_the_geometry_and_is_restored(monkeypat
         pass
 
     G = torch.zeros(1, 4, 4, 8)
-    for stream, expect in ((None, 0), (FakeStream(), 1)):
+    for stream, expect in ((None, None), (FakeStream(), 1)):
         try:
             net.backward_backbone(Saved(), G, {}, wgrad_stream=stream)
         except RuntimeError as e:
             assert "launch failed" in str(e)
-        assert seen[-1] == expect and ops.GPU_SHARED == 0
+        assert seen[-1] == (expect, None) and net.launch.gpu_shared is None and ops.GPU_SHARED == 0
+
+    # the reducer switches ITS model's tiles_per_block (device arenas only; emulated here by handing it a stand-in comm stream)
+    red = BucketedAllReduce(torch.zeros(8), [("b7", 0, 8)], None, shared_tiles_per_block=2, launch_opts=net.launch)
+    red.comm_stream = object()
+    red._share_gpu(True)
+    assert net.launch.tiles_per_block == 2 and other.launch.tiles_per_block is None and ops.TILES_PER_BLOCK == 0
+    red._share_gpu(False)
+    assert net.launch.tiles_per_block is None
 
 
 def test_gpu_suite_order_puts_parity_before_selfchecks_before_control_flow():

@@ -55,6 +55,25 @@ def _worker(rank, world, port, out):
                 expect = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world)) + step * world
                 assert torch.equal(flat[off:off + n], expect), (name, step)
                 off += n
+        # ---- the bf16 wire format: every bucket is cast to bf16, summed, widened back -- equal to the f32 exchange of the bf16-ROUNDED
+        # per-rank gradients up to one bf16 rounding of the sum (2^-9 relative), and the launch options it toggles are its own model's
+        class _Opts:
+            tiles_per_block = None
+        g = torch.Generator().manual_seed(5 + rank)
+        mine = torch.randn(total, generator=g)
+        flat16 = mine.clone()
+        red16 = BucketedAllReduce(flat16, buckets, None, launch_opts=_Opts(), payload="bf16")
+        red16.begin_step()
+        for unit in ("fc8", "b7", "b6", "b5", "b4"):
+            red16.on_unit_done(unit)
+        red16.finish()
+        parts = [torch.randn(total, generator=torch.Generator().manual_seed(5 + r)) for r in range(world)]
+        exact = sum(parts)
+        rounded = sum(p_.to(torch.bfloat16).float() for p_ in parts)
+        assert flat16.dtype == torch.float32
+        assert float((flat16 - rounded).abs().max()) <= 2.0 ** -8 * float(rounded.abs().max()) + 1e-6
+        assert float((flat16 - exact).abs().max()) <= 2.0 ** -6 * float(exact.abs().max())
+        assert red16.launch_opts.tiles_per_block is None  # (CPU tensors: no comm stream, nothing to share)
         # ---- inference sharding + gather (BASELINE config 3: 10k tiles over p ranks)
         n_items = 10_001
         lo, hi = shard_range(n_items, rank, world)

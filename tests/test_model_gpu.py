@@ -38,13 +38,16 @@ def masks_agree_up_to_ties(logits_ref, mask_ref, mask_got, err):
     return bool((gap[diff] <= 2 * err).all()), int(diff.sum())
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("tag,n,s,c,seed", [("s64_c4", 2, 64, 4, 101), ("s224_c4", 1, 224, 4, 102), ("s256_c5", 1, 256, 5, 103)])
-def test_seg_forward_fp32_matches_golden_and_oracle(golden_dir, tag, n, s, c, seed):
+def test_seg_forward_fp32_matches_golden_and_oracle(golden_dir, tag, n, s, c, seed, precision):
+    """The two paths that carry the north_star tolerance (fp32 logits within 1e-4 relative, masks bit-exact up to ties below the logit error):
+    "fp32" = exact-f32 MFMA, "bf16x3" = split bf16 (hi + lo planes, three 16-bit MFMAs per product, f32 accumulate)."""
     from pistoseg_amd import _lib, ops
 
     g = np.load(os.path.join(golden_dir, f"revise_{tag}.npz"))
     sd = ref_cpu.make_state_dict(c, False, seed=42)
-    model = build(c, "fp32", sd)
+    model = build(c, precision, sd)
     model.eval()
     x, *_ = make_inputs(n, s, c, seed)
     with torch.no_grad():
@@ -61,6 +64,7 @@ def test_seg_forward_fp32_matches_golden_and_oracle(golden_dir, tag, n, s, c, se
         ref = ref_cpu.seg_forward(sd, x)
     err = float((got - ref).abs().max())
     assert err / float(ref.abs().max()) < F32_TOL
+    print(f"[parity] {precision} seg forward {tag}: logits max rel err vs CPU oracle {err / float(ref.abs().max()):.3e}")
     # mask indices (loss.py:57-60): the argmax kernel is bit-exact on identical logits ...
     mask_same_logits = ops.argmax_mask(ref.to(D), mode=_lib.PS_MASK_PLAIN, softmax_first=True).cpu()
     assert np.array_equal(mask_same_logits.numpy(), g["cam_mask"])
@@ -70,12 +74,13 @@ def test_seg_forward_fp32_matches_golden_and_oracle(golden_dir, tag, n, s, c, se
     assert_tie_excused(f"seg masks {tag}", ndiff, mask_e2e.numel(), ok)
 
 
-def test_backbone_features_fp32(golden_dir):
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_backbone_features_fp32(golden_dir, precision):
     from pistoseg_amd.resnet38d import Net
 
     g = np.load(os.path.join(golden_dir, "backbone_s32.npz"))
     sd = ref_cpu.make_state_dict(None, False, seed=42)
-    net = Net(precision="fp32")
+    net = Net(precision=precision)
     net.load_state_dict(sd, strict=True)
     net = net.to(D)
     assert net.eval() is None  # quirk kept from resnet38d.py:191-213
@@ -195,8 +200,8 @@ def test_seg_trainer_fp16_loss_scaling_tracks_fp32():
     assert tr16.skipped_steps == 1 and tr16.loss_scale == 2.0 ** 39 and torch.equal(before, tr16.p_flat)
 
 
-def relu_pattern_flips(saved, collect):
-    """Number of post-ReLU activations whose zero/non-zero pattern differs between device and oracle."""
+def relu_pattern_flips(saved, collect, model=None):
+    """Number of post-ReLU activations whose zero/non-zero pattern differs between device and oracle (model: widens split activations)."""
     flips = 0
     for name, acts in collect.items():
         if name == "conv6":
@@ -204,11 +209,12 @@ def relu_pattern_flips(saved, collect):
         else:
             dev_acts = (saved.unit_in[name],) + tuple(saved.mid[name])
         for d, o in zip(dev_acts, acts):
-            flips += int(((d.float().cpu() > 0) != (o.detach().permute(0, 2, 3, 1) > 0)).sum())
+            d32 = model.act_to_f32(d) if model is not None else d.float()
+            flips += int(((d32.cpu() > 0) != (o.detach().permute(0, 2, 3, 1) > 0)).sum())
     return flips
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
 def test_seg_training_gradients_match_oracle(precision):
     """CE loss + every trainable conv gradient (dropout injected as fixed masks) vs CPU autograd.
 
@@ -247,9 +253,11 @@ def test_seg_training_gradients_match_oracle(precision):
     assert sorted(k for k, p in named.items() if p.requires_grad) == sorted(tk)
     # frozen layers got nothing
     assert named["conv1a.weight"].grad is None and named["b2.conv_branch2a.weight"].grad is None
-    flips = relu_pattern_flips(model._last_saved, collect)
+    flips = relu_pattern_flips(model._last_saved, collect, model)
     if precision == "fp32":
         loss_tol, grad_tol = 1e-5, (2e-4 if flips == 0 else 2e-2)
+    elif precision == "bf16x3":  # 16 mantissa bits per stored value, three-term products: a handful of ReLU-boundary flips are possible
+        loss_tol, grad_tol = 1e-4, (1e-3 if flips == 0 else 2e-2)
     else:  # bf16 storage: thousands of boundary activations differ by construction
         loss_tol, grad_tol = 3e-2, 1.5e-1
     assert abs(float(loss) - float(ref_loss)) < loss_tol * abs(float(ref_loss))
@@ -257,7 +265,7 @@ def test_seg_training_gradients_match_oracle(precision):
     for k in tk:
         assert named[k].grad is not None, k
         a, b = named[k].grad.cpu().double(), sd_ref[k].grad.double()
-        e = float((a - b).norm() / b.norm()) if (flips or precision == "bf16") else rel_err(a, b)
+        e = float((a - b).norm() / b.norm()) if (flips or precision != "fp32") else rel_err(a, b)
         worst = max(worst, e)
         assert e < grad_tol, (k, e, flips)
     print(f"[{precision}] relu pattern flips={flips} worst grad err={worst:.3e}")
@@ -315,6 +323,61 @@ def test_seg_training_gradients_bf16_at_persistent_kernel_batch_match_oracle():
         assert e < 1.5e-1, (k, e)
     print(f"[parity] product bf16 training step n=24 224x224 vs CPU oracle: loss {float(loss):.6f} vs {float(ref_loss):.6f}, logits max rel err "
           f"{e_log:.3e}, worst per-tensor gradient L2 rel err {worst[1]:.3e} ({worst[0]})")
+
+
+def test_seg_training_gradients_fp16_at_persistent_kernel_batch_match_oracle():
+    """BASELINE configs[4] as a TRAINING step (BCSS-WSSS: 4 classes, fp16 MFMA path), product library, against the CPU oracle's autograd.
+    The reference's BCSS branch is `CrossEntropyLoss(reduction='none')` with NO ignore index (models/segmentation_module.py:63-66), so the
+    targets are 0..3 and every pixel counts.  n = 24 tiles of 224 x 224 selects the persistent kernels (asserted); the CE gradient is
+    loss-scaled (2^16, the trainer's default: an unscaled 1/(N H W) = 8e-7 per pixel underflows fp16) and the scale divided out before the
+    per-tensor relative L2 comparison; dropout masks injected on both sides."""
+    import ctypes as C
+
+    from pistoseg_amd import _lib, ops
+
+    lib = _lib.load()
+    assert not hasattr(lib, "ps_debug_set_halo"), "this test must run on the product library"
+    c, n, s, scale = 4, 24, 224, 65536.0
+    for spec, hw, fam in ((ops.ConvSpec(512, 512, 3, 1, 1), 28, (7,)), (ops.ConvSpec(1024, 2048, 3, 1, 4), 28, (7,)), (ops.ConvSpec(256, 256, 3, 1, 1), 56, (7,)),
+                          (ops.ConvSpec(2048, 4096, 1, 1, 1), 28, (8,)), (ops.ConvSpec(256, 512, 3, 2, 1), 56, (4, 5))):
+        g_ = ops._geom(spec, _lib.PS_F16, n, hw, hw, spec.cin, spec.cout)
+        assert int(lib.ps_conv_variant(C.byref(g_), 0)) in fam and int(lib.ps_conv_wgrad_variant(C.byref(g_))) in (1, 2), spec
+    sd = ref_cpu.make_state_dict(c, False, seed=42)
+    model = build(c, "fp16", sd)
+    model.train()
+    g = torch.Generator().manual_seed(79)
+    x = torch.randn(n, 3, s, s, generator=g)
+    target = torch.randint(0, c, (n, s, s), generator=g)  # 0..3, no ignore index
+    drop = {}
+    for k, v in model.sample_dropout(n, D).items():
+        p = 0.3 if k.startswith("b6") else 0.5
+        drop[k] = (torch.rand(v.shape, generator=g) >= p).float() / (1 - p)
+    model.sample_dropout = lambda n_, dev_: {k: v.to(dev_) for k, v in drop.items()}
+    logits = model(x.to(D))
+    loss, dlogits = ops.softmax_ce(logits.detach(), target.to(D), None, want_grad=True, grad_scale=scale)
+    logits.backward(dlogits)
+    torch.cuda.synchronize()
+
+    sd_ref = {k: v.clone() for k, v in sd.items()}
+    tk = ref_cpu.trainable_keys(sd_ref)
+    for k in tk:
+        sd_ref[k].requires_grad_(True)
+    ref_logits = ref_cpu.seg_forward(sd_ref, x, drop)
+    ref_loss = ref_cpu.seg_ce_loss(ref_logits, target, None)
+    ref_loss.backward()
+    named = dict(model.named_parameters())
+    assert abs(float(loss) - float(ref_loss)) < 5e-3 * abs(float(ref_loss))
+    e_log = rel_err(logits.detach().cpu(), ref_logits.detach())
+    worst = ("", 0.0)
+    for k in tk:
+        ga = named[k].grad
+        assert bool(torch.isfinite(ga).all()), k
+        a, b = ga.cpu().double() / scale, sd_ref[k].grad.double()
+        e = float((a - b).norm() / b.norm())
+        worst = max(worst, (k, e), key=lambda t: t[1])
+        assert e < 3e-2, (k, e)
+    print(f"[parity] product fp16 training step (configs[4]: 4 classes, no ignore index) n=24 224x224 vs CPU oracle: loss {float(loss):.6f} vs "
+          f"{float(ref_loss):.6f}, logits max rel err {e_log:.3e}, worst per-tensor gradient L2 rel err {worst[1]:.3e} ({worst[0]})")
 
 
 def _side_stream_trainer(sd, c, n, overlap, lr, wd, steps):

@@ -31,13 +31,14 @@ def build(c, precision, sd):
     return m.to(D)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])  # the two paths that carry the 1e-4 tolerance: exact-f32 MFMA, split bf16 (hi + lo planes)
 @pytest.mark.parametrize("tag,n,s,c,seed", [("s64_c4", 2, 64, 4, 101), ("s224_c4", 1, 224, 4, 102), ("s256_c5", 1, 256, 5, 103)])
-def test_revise_forward_and_masks(golden_dir, tag, n, s, c, seed):
+def test_revise_forward_and_masks(golden_dir, tag, n, s, c, seed, precision):
     from pistoseg_amd import _lib, ops
 
     g = np.load(os.path.join(golden_dir, f"revise_{tag}.npz"))
     sd = ref_cpu.make_state_dict(c, True, seed=42)
-    model = build(c, "fp32", sd)
+    model = build(c, precision, sd)
     model.eval()
     x, pmask, pcam, lab = make_inputs(n, s, c, seed)
     pm, pc, label = with_bg(pmask, pcam, lab)
@@ -52,6 +53,7 @@ def test_revise_forward_and_masks(golden_dir, tag, n, s, c, seed):
         assert rel_err(got.reshape(-1)[torch.from_numpy(g[f"{name}.idx"])], torch.from_numpy(g[f"{name}.val"])) < TOL, name  # reference golden
         assert rel_err(got, r) < TOL, name  # oracle, full tensor
         errs[name] = float((got - r).abs().max())
+    print(f"[parity] {precision} revise forward {tag}: max rel err vs CPU oracle " + ", ".join(f"{k} {rel_err(o.cpu(), r):.2e}" for k, o, r in zip(names, outs, ref)))
     # stage-4 masks (infer_revise_masks.py:137-143): bit-exact on identical inputs ...
     lab_d = label.reshape(n, c).to(D)
     for name, r in zip(("pmask_rv", "pcam_rv", "cam_rv"), (ref[2], ref[3], ref[1])):
@@ -350,7 +352,9 @@ def test_rfm_trainer_step_at_baseline_config3_shape_vs_oracle():
             ref_losses[i] += float(v) * chunk / n
 
     names = ("loss", "loss_cls", "loss_rfm", "loss_ecr")
-    for precision, loss_tol, grad_tol in (("fp32", 1e-4, 5e-3), ("bf16", 5e-2, 2.5e-1)):
+    # bf16: the RFM heads (F, q | k, affinity and their gradients) compute in f32 inside the 16-bit models since round 4 -- the *_rv outputs reach the
+    # loss only through that matrix; before, `f8_4.weight` was 21 % off and the bound 25 %
+    for precision, loss_tol, grad_tol in (("fp32", 1e-4, 5e-3), ("bf16x3", 1e-4, 5e-3), ("bf16", 5e-2, 1e-1)):
         model = build(c, precision, sd)
         model.train()
         assert sorted(model.sample_dropout(2, D)) == sorted(drop)
