@@ -183,9 +183,13 @@ struct Raw8 {
         hi[i] = h0 | (h1 << 16);
         lo[i] = l0 | (l1 << 16);
       }
+      // The plane distance goes into the LANE offset here, not into the scalar offset as for the loads: a 128-bit buffer store whose SOFFSET is
+      // an SGPR reads its data registers late, and hipcc (ROCm 7.2) only guards the immediate-SOFFSET form of that hazard -- it scheduled the
+      // next row's first v_mov straight behind such a store and one dword of the third plane came out as garbage in a few rows per launch
+      // (found by tests/test_split_gpu.py on conv_gemm256_kernel; gfx950).
       __builtin_amdgcn_raw_buffer_store_b128(hi, rs, voff, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(lo, rs, voff, plane, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(hi, rs, voff, 2 * plane, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(lo, rs, voff + plane, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(hi, rs, voff + 2 * plane, 0, 0);
     } else if constexpr (sizeof(T) == 4) {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {

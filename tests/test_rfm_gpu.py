@@ -47,11 +47,18 @@ def test_revise_forward_and_masks(golden_dir, tag, n, s, c, seed, precision):
         ref = ref_cpu.revise_forward(sd, x, pm, pc)
     names = ("cam", "cam_rv", "pmask_rv", "pcam_rv")
     errs = {}
+    # The three *_rv maps are `X_norm @ softmax(q^T k)` (revise_net.py:69-75): the affinity softmax multiplies whatever error its inputs carry --
+    # on the exact-f32 path cam is 3e-6 off the oracle and the *_rv maps 2e-5, a factor of 6
+    # (ten at 224 x 224: 3.9e-6 -> 3.9e-5).  The split path's conv stack holds 16 mantissa bits per stored value (cam: 2-4e-5, inside the
+    # north_star's 1e-4 for the logits), so its *_rv maps land at 1.5-3.2e-4: bound 5e-4 there, stated instead of hidden; the stage-4 MASKS
+    # below must still be bit-exact up to ties.
+    rv_tol = TOL if precision == "fp32" else 5e-4
     for name, o, r in zip(names, outs, ref):
         got = o.cpu()
+        tol = TOL if name == "cam" else rv_tol
         assert tuple(got.shape) == tuple(g[f"{name}.shape"])
-        assert rel_err(got.reshape(-1)[torch.from_numpy(g[f"{name}.idx"])], torch.from_numpy(g[f"{name}.val"])) < TOL, name  # reference golden
-        assert rel_err(got, r) < TOL, name  # oracle, full tensor
+        assert rel_err(got.reshape(-1)[torch.from_numpy(g[f"{name}.idx"])], torch.from_numpy(g[f"{name}.val"])) < tol, name  # reference golden
+        assert rel_err(got, r) < tol, name  # oracle, full tensor
         errs[name] = float((got - r).abs().max())
     print(f"[parity] {precision} revise forward {tag}: max rel err vs CPU oracle " + ", ".join(f"{k} {rel_err(o.cpu(), r):.2e}" for k, o, r in zip(names, outs, ref)))
     # stage-4 masks (infer_revise_masks.py:137-143): bit-exact on identical inputs ...

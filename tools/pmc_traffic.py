@@ -11,7 +11,7 @@ fetch_dir, write_dir, out = sys.argv[1:4]
 
 def family(name):
     stem = re.sub(r"[<(].*", "", name.replace("void ", "").replace("(anonymous namespace)::", ""))
-    dt = "bf16" if ("TraitsBF16" in name or "DF16b" in name) else "f16" if ("TraitsF16" in name or "IDF16_" in name) else "f32" if "TraitsF32" in name else ""
+    dt = "bf16x3" if "TraitsBF16X3" in name else "bf16" if ("TraitsBF16" in name or "DF16b" in name) else "f16" if ("TraitsF16" in name or "IDF16_" in name) else "f32" if "TraitsF32" in name else ""
     return (stem + (f"<{dt}>" if dt else ""))[:100]
 
 
@@ -45,5 +45,13 @@ for k in sorted(set(fe) | set(wr)):
               "hbm_bytes_per_launch_corrected": (2 * ft + wt) / launches * 1024,
               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB units; FETCH_SIZE doubled (gfx950 reports half of wide streaming reads); "
                       "summed over all dispatches of the family, per API launch"}
+# which build the counters belong to: bench.py drops `roofline.traffic` when the kernel sources have changed since (csrc_sha16), and names
+# the commit (passed in: the GPU box's snapshot carries no .git)
+import hashlib, os
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_h = hashlib.sha256()
+for _f in sorted(glob.glob(os.path.join(_root, "pistoseg_amd", "csrc", "*"))):
+    _h.update(open(_f, "rb").read())
+res["_build"] = {"csrc_sha16": _h.hexdigest()[:16], "git_head": sys.argv[4] if len(sys.argv) > 4 else os.environ.get("PISTOSEG_GIT_HEAD", "unknown")}
 json.dump(res, open(out, "w"), indent=1)
-print(json.dumps({k: round(v["hbm_bytes_per_launch_corrected"] / 1e6, 1) for k, v in res.items()}, indent=1))
+print(json.dumps({k: round(v["hbm_bytes_per_launch_corrected"] / 1e6, 1) for k, v in res.items() if not k.startswith("_")}, indent=1))

@@ -1,26 +1,35 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>     e.g. r02b
+# usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag> [git head]     e.g. r04a $(git rev-parse --short HEAD)
 # (the profiled passes run with --no-overlap: weight gradients on the launch stream, so that every kernel's duration is exclusive
 #  and comparable with bench.py's live per-kernel events; the un-profiled line is the default, overlapped, run)
 # writes gpurun_out/prof_<tag>/..., gpurun_out/<tag>_*.json|csv|txt (copy into profiles/ afterwards)
 # PMC counters are collected in their OWN passes with --kernel-trace only (never with --stats / trace domains).
 set -o pipefail
 tag=$1
+head=${2:-unknown}   # `git rev-parse --short HEAD` of the tree that was pushed (the box's snapshot has no .git)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export PISTOSEG_GIT_HEAD=$head
 PMC_ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-infer --no-overlap --no-power"
-# --- BASELINE configs[1]: bs=64 bf16 (the headline)
+# --- BASELINE configs[1]: bs=64 bf16 (the headline).  ONE lease: the un-profiled line first, then the kernel trace of the same command, then the
+# counter passes, then the recomputation of the dominant kernel's fraction from the trace -- so that the kept line, its rocprof summary, the
+# traffic figure and the board's clock / power all describe the same box
+python bench.py > gpurun_out/${tag}_bench_unprofiled.json 2> gpurun_out/${tag}_bench_unprofiled.err &&
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-overlap --no-power > gpurun_out/${tag}_bench_train_bs64_bf16.json 2> gpurun_out/${tag}_bench_profiled.err &&
 cp $(find gpurun_out/prof_${tag} -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_bench_train_bs64_bf16_kernel_stats.csv &&
+python tools/roofline_recompute.py gpurun_out/${tag}_bench_train_bs64_bf16_kernel_stats.csv gpurun_out/${tag}_bench_train_bs64_bf16.json gpurun_out/${tag}_bench_unprofiled.json $head > gpurun_out/${tag}_roofline_recompute.txt &&
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_${tag}_fetch -- python bench.py $PMC_ARGS > /dev/null 2>&1 &&
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_${tag}_write -- python bench.py $PMC_ARGS > /dev/null 2>&1 &&
-python tools/pmc_traffic.py gpurun_out/pmc_${tag}_fetch gpurun_out/pmc_${tag}_write gpurun_out/${tag}_pmc_hbm_traffic.json > /dev/null &&
+python tools/pmc_traffic.py gpurun_out/pmc_${tag}_fetch gpurun_out/pmc_${tag}_write gpurun_out/${tag}_pmc_hbm_traffic.json $head > /dev/null &&
 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_${tag}_mfma_1 -- python bench.py $PMC_ARGS > /dev/null 2>&1 &&
 python tools/pmc_mfma_report.py gpurun_out/pmc_${tag}_mfma_1 > gpurun_out/${tag}_pmc_mfma_busy_train_step.txt &&
-python bench.py > gpurun_out/${tag}_bench_unprofiled.json 2> gpurun_out/${tag}_bench_unprofiled.err &&
 python tools/step_profile.py > gpurun_out/${tag}_step_profile_per_launch.txt 2>&1 &&
 # --- the PARITY path: fp32 storage, exact-f32 MFMA (157 TFLOP/s matrix peak)
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_fp32 -- python bench.py --precision fp32 --steps 3 --warmup 1 --no-cpu-baseline --no-overlap --no-power > gpurun_out/${tag}_bench_fp32_parity_path.json 2>> gpurun_out/${tag}_bench_profiled.err &&
 cp $(find gpurun_out/prof_${tag}_fp32 -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_bench_fp32_parity_path_kernel_stats.csv &&
+# --- the split-bf16 path (1e-4 logits at a third of the bf16 rate): bench line + kernel trace
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_x3 -- python bench.py --precision bf16x3 --steps 3 --warmup 1 --no-cpu-baseline --no-overlap --no-power > gpurun_out/${tag}_bench_bf16x3.json 2>> gpurun_out/${tag}_bench_profiled.err &&
+cp $(find gpurun_out/prof_${tag}_x3 -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_bench_bf16x3_kernel_stats.csv &&
+python bench.py --precision bf16x3 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_bench_bf16x3_unprofiled.json 2>> gpurun_out/${tag}_bench_profiled.err &&
 # --- BASELINE configs[4]: BCSS 4-class, fp16 MFMA path, bs=128 -- bench line + HBM / MFMA counters
 CFG5="--precision fp16 --classes 4 --batch 128"
 python bench.py $CFG5 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_cfg5_fp16_bs128.json 2>> gpurun_out/${tag}_bench_profiled.err &&
