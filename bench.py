@@ -43,7 +43,7 @@ GFLOP_TRAIN_PER_TILE = 556.28  # fwd + dgrad + wgrad, frozen conv1a/b2* skipped
 # numbers mean nothing and its JSON line says so ("test_backend").
 TEST_BACKEND = os.environ.get("PISTOSEG_BENCH_TEST_BACKEND") or None
 # /opt/skills/guides/MI355X_MICROARCH.md, dense.  bf16x3 (split bf16: three 16-bit MFMAs per algorithmic product) is priced at a third of the bf16 peak
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3.0}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3.0, "fp16x3": 2500.0 / 3.0}
 
 
 def parse():
@@ -58,9 +58,9 @@ def parse():
                     help="CE variant of SegmentationModule (models/segmentation_module.py:63-66): wsss4luad = CrossEntropyLoss(ignore_index=3) with "
                          "targets 0..3 (3 = white background, ignored); bcss = CrossEntropyLoss() without an ignore index, targets 0..classes-1.  "
                          "Default: wsss4luad for 3 classes, bcss otherwise (BASELINE configs[4])")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32", "bf16x3"],
-                    help="bf16 / fp16: 16-bit storage, f32 accumulate (throughput); fp32: exact-f32 MFMA; bf16x3: split bf16 (hi + lo planes, three MFMAs per "
-                         "product) -- the two last meet the reference's fp32 results to 1e-4")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32", "bf16x3", "fp16x3"],
+                    help="bf16 / fp16: 16-bit storage, f32 accumulate (throughput); fp32: exact-f32 MFMA; bf16x3 / fp16x3: split bf16 / fp16 (hi + lo planes, three "
+                         "MFMAs per product) -- the three last meet the reference's fp32 results to 1e-4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
     ap.add_argument("--no-power", action="store_true", help="skip the extra untimed pass that samples board power / shader clock (one GPU only)")
@@ -375,14 +375,12 @@ def rfm_bench(args, world, rank, dev, dist_on):
     dt = timed(step, args.steps, dist_on)
 
     def serial_step():  # weight gradients on the launch stream (exclusive per-kernel times), launch schedule of the timed two-stream step (gpu_shared)
-        from pistoseg_amd import ops
-
         ws, tr.wgrad_stream = tr.wgrad_stream, None
-        shared, ops.GPU_SHARED = ops.GPU_SHARED, (1 if ws is not None else ops.GPU_SHARED)
+        model.shared_backward_schedule = ws is not None
         try:
             step()
         finally:
-            tr.wgrad_stream, ops.GPU_SHARED = ws, shared
+            tr.wgrad_stream, model.shared_backward_schedule = ws, False
 
     roof = None
     if rank == 0:
@@ -667,16 +665,15 @@ def main():
 
     def serial_step():
         """The instrumented step runs the weight gradients on the launch stream (per-kernel times are exclusive) but keeps the launch
-        schedule of the timed two-stream step: `gpu_shared` stays set, so the halo / gemm256 partial last rounds are NOT re-issued as tail
-        launches -- the roofline table describes the same dispatches as the headline tiles/s."""
-        from pistoseg_amd import ops
-
+        schedule of the timed two-stream step: `gpu_shared` is set for the backward as there, so the data gradients' partial last rounds are NOT
+        re-issued as tail launches (the forward keeps its tails, as in the timed step) -- the roofline table describes the same dispatches as
+        the headline tiles/s."""
         ws, trainer.wgrad_stream = trainer.wgrad_stream, None
-        shared, ops.GPU_SHARED = ops.GPU_SHARED, (1 if ws is not None else ops.GPU_SHARED)
+        model.shared_backward_schedule = ws is not None
         try:
             train_step()
         finally:
-            trainer.wgrad_stream, ops.GPU_SHARED = ws, shared
+            trainer.wgrad_stream, model.shared_backward_schedule = ws, False
 
     if rank == 0:
         out["roofline"] = roofline_leg(serial_step, args.precision)

@@ -48,7 +48,11 @@ typedef enum ps_dtype {
    * bf16 GEMM with f32 accumulation, i.e. every product is x_hi w_hi + x_lo w_hi + x_hi w_lo (relative error ~2^-16 instead of bf16's
    * 2^-8 at 3 MFMAs per product): the path that meets the reference's fp32 results to 1e-4 (models/resnet38d.py:156-188 computes in fp32)
    * at 16-bit MFMA speed / 3.  Epilogue tensors (add0, out_raw, mask_src, add1, out) are split tensors of `produced channels` planes. */
-  PS_BF16X3 = 3
+  PS_BF16X3 = 3,
+  /* The same scheme on fp16 planes: hi = fp16(v) (11 significant bits), lo = fp16(v - hi) -- 22 bits while lo stays a normal number
+   * (|v| >= 2^-3), an absolute error of at most 2^-25 below that (the 16-bit MFMA keeps fp16 subnormals: tools/f16_denorm_probe.hip), against
+   * the bf16 split's 2^-16 relative.  Range is fp16's: |v| <= 65504, and gradients need the loss scale of the PS_F16 path. */
+  PS_F16X3 = 4
 } ps_dtype;
 
 int ps_version(void);

@@ -67,7 +67,11 @@ void ps_debug_set_wgrad_ovh(int v);
 /* Testing hook: cout tiles per super-column of the conv block raster (default 4; 0 = plain row-major). */
 void ps_debug_set_supertile(int v);
 /* Testing hook: weight-gradient block order: 0 pixel range slowest, 1 pixel range fastest, -1 (default) chosen by shape. */
+/* every tunable above and below back to its library default */
+void ps_debug_reset(void);
 void ps_debug_set_wgrad_raster(int v);
+/* 3x3 stride-1 weight gradients: 1 (default) = padding validity from the precomputed lane-mask table, 0 = per-row tracking in the loaders */
+void ps_debug_set_wgrad_vtab(int v);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ import torch  # noqa: F401  (side effect: loads the HIP runtime torch uses)
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PISTOSEG_HIP_LIB") or os.path.join(HERE, "libpistoseg_hip.so")  # override: A/B-testing another build
 
-PS_F32, PS_BF16, PS_F16, PS_BF16X3 = 0, 1, 2, 3  # PS_BF16X3: split-bf16 conv format (planes [hi | lo | hi]; include/pistoseg_hip.h)
+PS_F32, PS_BF16, PS_F16, PS_BF16X3, PS_F16X3 = 0, 1, 2, 3, 4  # PS_*X3: split 16-bit conv formats (planes [hi | lo | hi]; include/pistoseg_hip.h)
 PS_EPI_NONE, PS_EPI_BNRELU, PS_EPI_RELUBWD = 0, 1, 2
 PS_MASK_PLAIN, PS_MASK_MUL, PS_MASK_FILL = 0, 1, 2
 
@@ -168,7 +168,9 @@ DEBUG_PROTOTYPES = {
     "ps_debug_set_wgrad_ablate": (None, [C.c_int]),
     "ps_debug_set_wgrad_ovh": (None, [C.c_int]),
     "ps_debug_set_supertile": (None, [C.c_int]),
+    "ps_debug_reset": (None, []),
     "ps_debug_set_wgrad_raster": (None, [C.c_int]),
+    "ps_debug_set_wgrad_vtab": (None, [C.c_int]),
 }
 
 DEBUG_LIB_PATH = os.environ.get("PISTOSEG_HIP_DEBUG_LIB") or os.path.join(HERE, "libpistoseg_hip_debug.so")  # override: A/B builds

@@ -34,3 +34,13 @@ int ps_num_cus(void) {
   }
   return cached[dev];
 }
+
+#ifdef PS_DEBUG_HOOKS
+// libpistoseg_hip_debug.so only: every `ps_debug_set_*` tunable back to its default (the lists live beside the tunables' definitions)
+void ps_debug_reset_igemm(void);
+void ps_debug_reset_wgrad(void);
+extern "C" void ps_debug_reset(void) {
+  ps_debug_reset_igemm();
+  ps_debug_reset_wgrad();
+}
+#endif

@@ -77,6 +77,11 @@ __device__ __forceinline__ void ps_tile_of_block(int bid, int ntn, int ntm, int&
 // unmodified K loop of every kernel compute x_hi w_hi + x_lo w_hi + x_hi w_lo as ONE bf16 contraction over 3 C channels against weights
 // laid out [hi | hi | lo] per tap (f32 accumulate).  sizeof == 1 so that the `sizeof(T) == 2` 16-bit fast paths do not take it.
 struct bf16x3_t {};
+struct f16x3_t {};  // the same on fp16 planes (PS_F16X3): 11 + 11 significant bits, fp16's range
+template <typename T> struct is_split_t { static constexpr bool value = std::is_same<T, bf16x3_t>::value || std::is_same<T, f16x3_t>::value; };
+template <typename T> struct plane_of { typedef T type; };               // the 16-bit element type of a split tensor's planes
+template <> struct plane_of<bf16x3_t> { typedef __bf16 type; };
+template <> struct plane_of<f16x3_t> { typedef _Float16 type; };
 
 struct TraitsBF16 {
   typedef __bf16 elem;
@@ -89,6 +94,13 @@ struct TraitsBF16X3 {  // K loop of TraitsBF16 over 3 x the channels, split epil
   typedef __bf16 elem;
   typedef bf16x3_t epi;
   static __device__ __forceinline__ void mma(const u32x4& w, const u32x4& x, f32x4& acc) { TraitsBF16::mma(w, x, acc); }
+};
+struct TraitsF16X3 {
+  typedef _Float16 elem;
+  typedef f16x3_t epi;
+  static __device__ __forceinline__ void mma(const u32x4& w, const u32x4& x, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
+  }
 };
 struct TraitsF16 {
   typedef _Float16 elem;
@@ -137,7 +149,7 @@ constexpr unsigned PAD_ROW = 0x80000000u;
 // Eight consecutive tensor elements as loaded through a buffer descriptor (no conversion until they are needed).
 template <typename T>
 struct Raw8 {
-  static constexpr bool X3 = std::is_same<T, bf16x3_t>::value;
+  static constexpr bool X3 = is_split_t<T>::value, XH = std::is_same<T, f16x3_t>::value;
   static constexpr int NQ = X3 ? 2 : sizeof(T) / 2;  // 16-byte quads (split: the hi and the lo plane's)
   u32x4 q[NQ];
   // plane: byte distance between the planes of a split tensor (ignored by the plain types), wave-uniform.  It travels in the buffer
@@ -152,7 +164,11 @@ struct Raw8 {
     }
   }
   __device__ __forceinline__ void unpack(float* v) const {
-    if constexpr (X3) {
+    if constexpr (XH) {
+      const f16x8 h = __builtin_bit_cast(f16x8, q[0]), l = __builtin_bit_cast(f16x8, q[1]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = static_cast<float>(h[i]) + static_cast<float>(l[i]);
+    } else if constexpr (X3) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         v[2 * i] = __uint_as_float(q[0][i] << 16) + __uint_as_float(q[1][i] << 16);
@@ -176,12 +192,23 @@ struct Raw8 {
   static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rs, int voff, const float* v, int plane = 0) {
     if constexpr (X3) {
       u32x4 hi, lo;
+      if constexpr (XH) {
+        f16x8 h, l;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint32_t h0 = ps_f32_to_bf16(v[2 * i]), h1 = ps_f32_to_bf16(v[2 * i + 1]);
-        const uint32_t l0 = ps_f32_to_bf16(v[2 * i] - __uint_as_float(h0 << 16)), l1 = ps_f32_to_bf16(v[2 * i + 1] - __uint_as_float(h1 << 16));
-        hi[i] = h0 | (h1 << 16);
-        lo[i] = l0 | (l1 << 16);
+        for (int i = 0; i < 8; ++i) {
+          h[i] = static_cast<_Float16>(v[i]);
+          l[i] = static_cast<_Float16>(v[i] - static_cast<float>(h[i]));
+        }
+        hi = __builtin_bit_cast(u32x4, h);
+        lo = __builtin_bit_cast(u32x4, l);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t h0 = ps_f32_to_bf16(v[2 * i]), h1 = ps_f32_to_bf16(v[2 * i + 1]);
+          const uint32_t l0 = ps_f32_to_bf16(v[2 * i] - __uint_as_float(h0 << 16)), l1 = ps_f32_to_bf16(v[2 * i + 1] - __uint_as_float(h1 << 16));
+          hi[i] = h0 | (h1 << 16);
+          lo[i] = l0 | (l1 << 16);
+        }
       }
       // The plane distance goes into the LANE offset here, not into the scalar offset as for the loads: a 128-bit buffer store whose SOFFSET is
       // an SGPR reads its data registers late, and hipcc (ROCm 7.2) only guards the immediate-SOFFSET form of that hazard -- it scheduled the
@@ -222,7 +249,8 @@ template <typename T, int MI, int WI, int MAP = 0, int CW = (sizeof(T) == 2 ? 4 
 __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[MI][WI], int mbase, int cbase, int lane) {
   constexpr bool COLMAP = MAP == 1;
   constexpr int CH = 4 * WI;  // 16 or 8 channels per lane, handled CW at a time
-  constexpr bool X3 = std::is_same<T, bf16x3_t>::value;  // split tensors: planes [hi | lo | hi], a.Cd channels apart (see bf16x3_t)
+  constexpr bool X3 = is_split_t<T>::value;  // split tensors: planes [hi | lo | hi], a.Cd channels apart (see bf16x3_t)
+  typedef typename plane_of<T>::type PT;
   constexpr int NO = CW / 8, ES = X3 ? 2 : (int)sizeof(T);
   static_assert(CW % 8 == 0 && CH % CW == 0, "channel chunk");
   const int frow = lane & 15, g = lane >> 4;
@@ -331,10 +359,10 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
       const int hw = a.Ho * a.Wo;
       auto ld8 = [&](const void* base, int ldc, int m, int c, float* v) {  // 8 channels c.. of row m
         if constexpr (X3) {
-          const __bf16* p = reinterpret_cast<const __bf16*>(base) + (long long)m * ldc + c;
+          const PT* p = reinterpret_cast<const PT*>(base) + (long long)m * ldc + c;
           float lo[8];
-          ps_load8<__bf16>(p, v);
-          ps_load8<__bf16>(p + a.Cd, lo);
+          ps_load8<PT>(p, v);
+          ps_load8<PT>(p + a.Cd, lo);
 #pragma unroll
           for (int i = 0; i < 8; ++i) v[i] += lo[i];
         } else {
@@ -343,16 +371,16 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
       };
       auto st8 = [&](void* base, int ldc, int m, int c, const float* v) {
         if constexpr (X3) {
-          __bf16* p = reinterpret_cast<__bf16*>(base) + (long long)m * ldc + c;
+          PT* p = reinterpret_cast<PT*>(base) + (long long)m * ldc + c;
           float hi[8], lo[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            hi[i] = ps_bf16_to_f32(ps_f32_to_bf16(v[i]));
+            hi[i] = static_cast<float>(static_cast<PT>(v[i]));
             lo[i] = v[i] - hi[i];
           }
-          ps_store8<__bf16>(p, hi);
-          ps_store8<__bf16>(p + a.Cd, lo);
-          ps_store8<__bf16>(p + 2 * a.Cd, hi);
+          ps_store8<PT>(p, hi);
+          ps_store8<PT>(p + a.Cd, lo);
+          ps_store8<PT>(p + 2 * a.Cd, hi);
         } else {
           ps_store8<T>(reinterpret_cast<T*>(base) + (long long)m * ldc + c, v);
         }
@@ -2079,13 +2107,15 @@ PS_TUNABLE g_use_halo = 1;     // window + halo staging for 3x3 stride-1 layers 
 PS_TUNABLE g_halo_tail = 1;   // halo kernel: a partial last round (<= half the CUs) as a second launch of 64-cout half tiles: 0 off, 1 on
 PS_TUNABLE g_halo_ring = 3;   // weight ring depth of the halo kernel (3 | 4 | 5 stages of 16 KiB; 256-pixel tiles: <= 4)
 PS_TUNABLE g_gemm256 = 1;      // 256 x 256 tile kernel for the plain GEMMs (1x1 stride-1, 16-bit): 0 off, 1 by shape, 2 whenever legal
-PS_TUNABLE g_gemm256_min_klines = 32, g_gemm256_min_cd = 1024, g_gemm256_min_tiles = 384;  // the by-shape rule's thresholds: K / 64 and produced channels
+PS_TUNABLE g_gemm256_min_klines = 32, g_gemm256_min_cd = 1024;  // the by-shape rule's thresholds: K / 64 and produced channels
+PS_TUNABLE g_gemm256_min_tiles = 0;  // ... and its minimum launch size in tiles: 0 = 1.5 rounds of the device's CUs (384 on the 256-CU MI355X), > 0 forces a count
 PS_TUNABLE g_gemm256_tail = 1; // gemm256: a partial last round of at most half the CUs goes to a second launch on the gathered-tile kernels: 0 off, 1 on
 PS_TUNABLE g_use_3stage = 0;  // experimental 256x128 three-stage kernel: correct but slower than two 128x128 blocks per CU (r01 measurements)
 PS_TUNABLE g_ablate = 0;
 PS_TUNABLE g_supertile = 4;  // measured best of {0,4,8,16} on the wide 28x28 layers (r01)
 PS_TUNABLE g_force_bm = 0;  // testing: 112 or 128 forces the pixel-tile height of the 128-cout kernel
 PS_TUNABLE g_force_bn = 0;  // testing: 64 or 128 forces the 2-stage tile width
+PS_TUNABLE g_s2split = 1;  // stride-2 3x3 data gradient as four parity-class launches: 0 off, 1 for big 16-bit problems, 2 whenever legal
 
 template <typename Tr, int BM, int BN, int WMW, int WNW>
 int launch_igemm(const IgemmArgs& a0, hipStream_t stream) {
@@ -2204,7 +2234,7 @@ static int pick_ws_variant(long long M, int Cd, int esize, bool halo_ok) {
 }
 
 // The 256 x 256 tile kernel serves plain GEMMs: one tap, no gather arithmetic, 16-bit operands, whole 256-cout tiles, K >= 256.
-// By shape (g_gemm256 == 1): K >= 2048, >= 1024 produced channels and >= 384 tiles (1.5 rounds of the 256 CUs; first 512: at bs = 32 the
+// By shape (g_gemm256 == 1): K >= 2048, >= 1024 produced channels and >= 1.5 rounds of the device's CUs in tiles (384 on MI355X; first 512: at bs = 32 the
 // 1024-channel layers have 392 tiles, and taking them is +1.0-1.2 % of a stage-3 step, profiles/r03_train_ab_gemm256_rule.txt).  Measured r03 on sustained single-kernel loops
 // (profiles/r03_gemm256_vs_ws2.txt): +13..27 % on the >= 2048-channel layers, +-5 % on the K = 1024 / 1024-channel ones; on the WHOLE step
 // (profiles/r03_train_ab_gemm256_rule.txt) the 1024-channel layers with K >= 2048 -- the data gradients 1024 <- 2048 / 2560 and the forward
@@ -2212,7 +2242,8 @@ static int pick_ws_variant(long long M, int Cd, int esize, bool halo_ok) {
 static bool use_gemm256(long long M, int Cd, int esize, int taps, int mul, int div_shift, int klines) {
   if (!g_gemm256 || g_use_glds != 2 || esize != 2 || taps != 1 || mul != 1 || div_shift != 0 || Cd % 256 != 0 || klines < 4) return false;
   if (g_gemm256 == 2) return true;
-  return ((M + 255) / 256) * (Cd / 256) >= g_gemm256_min_tiles && klines >= g_gemm256_min_klines && Cd >= g_gemm256_min_cd;
+  const long long min_tiles = g_gemm256_min_tiles > 0 ? g_gemm256_min_tiles : 3LL * ps_num_cus() / 2;  // (a partitioned device has fewer CUs per round)
+  return ((M + 255) / 256) * (Cd / 256) >= min_tiles && klines >= g_gemm256_min_klines && Cd >= g_gemm256_min_cd;
 }
 
 template <typename Tr>
@@ -2404,6 +2435,12 @@ extern "C" int ps_debug_read_stamps(unsigned long long* host_out) {  // 256 x 4 
 extern "C" void ps_debug_set_halo_ring(int v) { g_halo_ring = v; }
 extern "C" void ps_debug_set_halo_tail(int v) { g_halo_tail = v; }
 extern "C" void ps_debug_set_supertile(int v) { g_supertile = v; }
+// every tunable of this translation unit back to its default (one list, next to the definitions: the tools call ps_debug_reset())
+void ps_debug_reset_igemm(void) {
+  g_use_glds = 2; g_use_pp = 0; g_use_ws = 1; g_use_ws2 = 1; g_use_halo = 1; g_halo_tail = 1; g_halo_ring = 3; g_gemm256 = 1;
+  g_gemm256_min_klines = 32; g_gemm256_min_cd = 1024; g_gemm256_min_tiles = 0; g_gemm256_tail = 1; g_use_3stage = 0; g_ablate = 0;
+  g_supertile = 4; g_force_bm = 0; g_force_bn = 0; g_s2split = 1;
+}
 #endif
 
 extern "C" int ps_conv_supported(const ps_conv_geom* g) { return check_geom(g) == PS_OK ? 1 : 0; }
@@ -2504,12 +2541,12 @@ extern "C" int ps_conv2d_fwd(const ps_conv_geom* g, const void* x, const void* w
   if (int rc = set_extents(a, (long long)g->n * g->h * g->w * a.pix_bytes, (long long)g->cout * a.wrow_bytes, es)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (g->dtype == PS_BF16X3) return dispatch_bn<TraitsBF16X3>(a, s);
+  if (g->dtype == PS_F16X3) return dispatch_bn<TraitsF16X3>(a, s);
   if (g->dtype == PS_BF16) return dispatch_bn<TraitsBF16>(a, s);
   if (g->dtype == PS_F16) return dispatch_bn<TraitsF16>(a, s);
   return dispatch_bn<TraitsF32>(a, s);
 }
 
-PS_TUNABLE g_s2split = 1;  // stride-2 3x3 data gradient as four parity-class launches: 0 off, 1 for big 16-bit problems, 2 whenever legal
 #ifdef PS_DEBUG_HOOKS
 extern "C" void ps_debug_set_s2split(int v) { g_s2split = v; }
 #endif
@@ -2577,8 +2614,10 @@ extern "C" int ps_conv2d_dgrad(const ps_conv_geom* g, const void* dy, const void
   if (int rc = set_extents(a, (long long)g->n * a.Hs * a.Ws * a.pix_bytes, (long long)g->cin * a.wrow_bytes, es)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dgrad_s2_split_ok(g, epi))
-    return g->dtype == PS_BF16X3 ? dgrad_s2_split<TraitsBF16X3>(a, s) : g->dtype == PS_BF16 ? dgrad_s2_split<TraitsBF16>(a, s) : dgrad_s2_split<TraitsF16>(a, s);
+    return g->dtype == PS_BF16X3 ? dgrad_s2_split<TraitsBF16X3>(a, s) : g->dtype == PS_F16X3 ? dgrad_s2_split<TraitsF16X3>(a, s)
+           : g->dtype == PS_BF16 ? dgrad_s2_split<TraitsBF16>(a, s) : dgrad_s2_split<TraitsF16>(a, s);
   if (g->dtype == PS_BF16X3) return dispatch_bn<TraitsBF16X3>(a, s);
+  if (g->dtype == PS_F16X3) return dispatch_bn<TraitsF16X3>(a, s);
   if (g->dtype == PS_BF16) return dispatch_bn<TraitsBF16>(a, s);
   if (g->dtype == PS_F16) return dispatch_bn<TraitsF16>(a, s);
   return dispatch_bn<TraitsF32>(a, s);

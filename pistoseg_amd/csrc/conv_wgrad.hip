@@ -11,7 +11,11 @@
 // Block = 4 waves (2x2), tile BCO x BCI in {64,128}^2, one tap and one pixel range (split-K) per block;
 // partial sums are added to the f32 gradient with global_atomic_add_f32 (64-byte row segments).
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <type_traits>
+#include <vector>
 
 #include "ps_internal.h"
 
@@ -36,6 +40,10 @@ struct WgradArgs {
   int cig, cog;                // item order: cin / cout tiles per group of consecutive items (see decode_item)
   float* part;                 // deterministic mode (DET kernels): workspace [pixel range][cout][taps][cin] f32 for the partial sums
   long long part_stride;       // elements per pixel range = cout * taps * cin
+  // conv_wgrad_ws2_kernel<.., XM = 3>: padding validity of the X rows as a precomputed table of LANE MASKS (wgrad_valid_table):
+  // vtab[((tap * vperiod + ks % vperiod) * 4 + loader wave) * 4 + j] = 64-bit mask of the lanes whose row is inside the image for that tap
+  const unsigned long long* vtab;
+  int vperiod;
 };
 
 struct WTraitsBF16 {
@@ -312,6 +320,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //   1: stride 1 (output map = input map): the tap's row is the pixel's row shifted by a constant, i.e. a per-lane constant offset plus a
 //      SCALAR offset per K-step; only the padding test keeps per-lane state (the shifted coordinates, 11 instructions per row)
 //   2: 1x1, stride 1: no padding either -- constant lane offset + scalar offset, as for dY (no VALU work per K-step at all)
+//   3: as 1, with the padding test looked up instead of tracked: whether pixel m's row is inside the image for a tap depends on m mod (H W),
+//      and a lane's pixel advances by 64 per K-step, so the pattern repeats every P = H W / gcd(H W, 64) K-steps (49 for 28 x 28 and
+//      56 x 56 maps, 16 / 64 for 32 x 32 / 64 x 64).  A host-built table holds, per (tap, K-step mod P, loader wave, DMA instruction), the
+//      64-bit mask of valid LANES; a K-step costs one 32-byte scalar load (issued in front of the dY pieces, which hide its latency) and ONE
+//      v_cndmask per X piece instead of 11 VALU instructions per row (4 instead of 44 per wave and K-step: the loaders' issue stream is
+//      part of the K-step's critical path)
 template <bool F16, int XM, bool DET = false>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs a) {
   constexpr int ES = 2, KP = 64, BCO = 256, BCI = 128;
@@ -361,14 +375,17 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
     const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)a.dy_bytes, 0x00020000);
     // XM >= 1: the descriptor starts `xpad` bytes BEFORE the tensor (the largest negative tap shift), so that scalar + lane offsets of
     // every row are non-negative; nothing in front of the tensor is ever read (those rows fail the padding test)
-    const int xpad = XM == 1 ? (a.dil * a.W + a.dil) * (int)a.x_pix_bytes : 0;
+    const int xpad = (XM == 1 || XM == 3) ? (a.dil * a.W + a.dil) * (int)a.x_pix_bytes : 0;
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x - xpad), 0, (int)a.x_bytes + xpad, 0x00020000);
     const int g_rowin = lane / (RBG / 16), g_pos = lane % (RBG / 16);
     const int x_rowin = lane / (RBX / 16), x_pos = lane % (RBX / 16);
     const int n_img = a.M / (a.Ho * a.Wo);
     unsigned goff[NIG], xchunk[NIX];
-    int xn[NIX], xp[NIX], xq[NIX];
+    int xn[XM == 3 ? 1 : NIX], xp[XM == 3 ? 1 : NIX], xq[XM == 3 ? 1 : NIX];
     int item = first, ks = 0, ks_end = 0, dy_off = 0, dx_off = 0;
+    [[maybe_unused]] int vkk = 0;                                 // XM 3: ks mod vperiod
+    [[maybe_unused]] const unsigned long long* vrow = nullptr;    // XM 3: this (tap, wave)'s masks of K-step 0; 16 masks (128 bytes) per K-step
+    [[maybe_unused]] const unsigned pad_row = PAD_ROW;
     auto item_setup = [&](int it) {
       int tci, tco, tap;
       decode(it, tci, tco, tap, ks, ks_end);
@@ -383,7 +400,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
 #pragma unroll
       for (int j = 0; j < NIX; ++j) {
         const int R = (wave * NIX + j) * RPX + x_rowin;
-        if constexpr (XM != 2) {
+        if constexpr (XM != 2 && XM != 3) {
           const uint32_t m = (uint32_t)(ks * KP + R);
           const uint32_t n = fdiv(m, a.div_hw);
           const uint32_t rem = m - n * a.div_hw.d;
@@ -393,6 +410,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
         }
         xchunk[j] = (unsigned)(tci * BCI * ES + ((x_pos ^ row_swz<ES, RBX>(R)) << 4));
         if constexpr (XM >= 1) xchunk[j] += (unsigned)(R * (int)a.x_pix_bytes);  // the lane's constant row offset
+      }
+      if constexpr (XM == 3) {
+        vkk = ks % a.vperiod;
+        vrow = a.vtab + ((long long)tap * a.vperiod * 4 + wave) * 4;
       }
     };
     item_setup(item);
@@ -405,15 +426,33 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
       unsigned char* sx = sg + G_BYTES;
       const int gso = ks * KP * (int)a.dy_pix_bytes;
       const bool stage = !(PS_ABLATE(a.ablate) == 3 && issued >= 3);  // timing experiment (results WRONG): consumers run on stale LDS contents
+      // XM 3: this K-step's four lane masks -- a uniform address, i.e. one scalar load, whose latency the dY pieces below cover
+      unsigned long long vm[XM == 3 ? NIX : 1];
+      if constexpr (XM == 3) {
+        // (address made visibly wave-uniform and read through the constant address space: an SMEM load, counted by lgkmcnt -- a VECTOR load
+        // here would sit in the loaders' in-order vmcnt queue in front of the dY pieces, and waiting for it would drain the previous step's)
+        const unsigned long long addr = reinterpret_cast<unsigned long long>(vrow + (long long)vkk * 16);
+        const unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)addr), ahi = __builtin_amdgcn_readfirstlane((unsigned)(addr >> 32));
+        typedef const __attribute__((address_space(4))) unsigned long long* cptr;
+        const cptr vp = (cptr)(((unsigned long long)ahi << 32) | alo);
+#pragma unroll
+        for (int j = 0; j < NIX; ++j) vm[j] = vp[j];
+        vkk = (vkk + 1 == a.vperiod) ? 0 : vkk + 1;
+      }
 #pragma unroll
       for (int j = 0; j < NIG; ++j)
         if (stage) BLDS16(rsG, sg + (wave * NIG + j) * 1024, goff[j], gso);
+      if constexpr (XM == 3) __builtin_amdgcn_sched_barrier(0);  // keep the masks' first use (and its lgkmcnt wait) behind all the dY pieces
       // scalar part of an X row's offset (XM >= 1): (first pixel of the K-step + the tap's shift) rows, from the padded descriptor base
       const int xso = XM >= 1 ? (ks * KP + dy_off * a.W + dx_off) * (int)a.x_pix_bytes + xpad : 0;
 #pragma unroll
       for (int j = 0; j < NIX; ++j) {
         if constexpr (XM == 2) {
           if (stage) BLDS16(rsX, sx + (wave * NIX + j) * 1024, xchunk[j], xso);  // (rows past the last pixel: outside the descriptor -> zeros)
+        } else if constexpr (XM == 3) {
+          // lane offset where the lane's bit is set, the padding marker elsewhere: the uniform mask is used as the select's lane mask directly
+          const unsigned off = __builtin_amdgcn_inverse_ballot_w64(vm[j]) ? xchunk[j] : pad_row;
+          if (stage) BLDS16(rsX, sx + (wave * NIX + j) * 1024, off, xso);
         } else if constexpr (XM == 1) {
           const bool ok = (unsigned)xp[j] < (unsigned)a.H && (unsigned)xq[j] < (unsigned)a.W;  // (past the last image: outside the descriptor)
           if (stage) BLDS16(rsX, sx + (wave * NIX + j) * 1024, ok ? xchunk[j] : PAD_ROW, xso);
@@ -922,6 +961,54 @@ int launch_wgrad(WgradArgs a, hipStream_t s) {
   return PS_OK;
 }
 
+PS_TUNABLE g_wgrad_vtab = 1;  // 3x3 stride-1 layers: padding validity from the precomputed lane-mask table (XM = 3) instead of per-row tracking (XM = 1)
+
+// The lane-mask table of conv_wgrad_ws2_kernel<.., XM = 3> for an H x W map and a dilation (device memory, built once per device and
+// geometry -- a handful per network -- and kept for the life of the process: the per-device kernel / tuning cache the C-ABI allows; the
+// one-time build copies synchronously).  nullptr when the validity pattern's period exceeds 128 K-steps (the kernel then tracks the
+// rows itself, XM = 1).  Entry [tap][kk][wave][j]: bit l = the X row staged by lane l of loader `wave`'s j-th piece of K-step kk -- row
+// R = (wave * 4 + j) * 4 + l / 16 of the step, pixel m = 64 kk + R, (p, q) = divmod(m mod (H W), W) -- is inside the image for `tap`.
+static const unsigned long long* wgrad_valid_table(int H, int W, int dil, int* period) {
+  static std::mutex mu;
+  static std::map<std::tuple<int, int, int, int>, std::pair<const unsigned long long*, int>> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  const auto key = std::make_tuple(dev, H, W, dil);
+  auto it = cache.find(key);
+  if (it != cache.end()) { *period = it->second.second; return it->second.first; }
+  const long long hw = (long long)H * W;
+  long long gcd = hw, b = 64;
+  while (b) { const long long t = gcd % b; gcd = b; b = t; }
+  const long long P = hw / gcd;
+  const unsigned long long* dptr = nullptr;
+  if (P <= 128) {
+    std::vector<unsigned long long> host((size_t)9 * P * 16, 0ull);
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = (tap / 3 - 1) * dil, dx = (tap % 3 - 1) * dil;
+      for (long long kk = 0; kk < P; ++kk)
+        for (int w = 0; w < 4; ++w)
+          for (int j = 0; j < 4; ++j) {
+            unsigned long long mask = 0;
+            for (int r = 0; r < 4; ++r) {
+              const long long m = kk * 64 + (w * 4 + j) * 4 + r, rem = m % hw, p = rem / W, q = rem % W;
+              if (p + dy >= 0 && p + dy < H && q + dx >= 0 && q + dx < W) mask |= 0xFFFFull << (16 * r);
+            }
+            host[(((size_t)tap * P + kk) * 4 + w) * 4 + j] = mask;
+          }
+    }
+    void* d = nullptr;
+    if (hipMalloc(&d, host.size() * 8) == hipSuccess) {
+      if (hipMemcpy(d, host.data(), host.size() * 8, hipMemcpyHostToDevice) == hipSuccess) dptr = static_cast<const unsigned long long*>(d);
+      else (void)hipFree(d);
+    }
+    (void)hipGetLastError();
+  }
+  cache[key] = {dptr, (int)P};
+  *period = (int)P;
+  return dptr;
+}
+
 // Geometry-derived fields + pixel-range count of conv_wgrad_ws2_kernel; returns the number of ranges that get work.
 static long long plan_wgrad_ws2(WgradArgs& a) {
   a.tiles_co = a.cout / 256;
@@ -962,6 +1049,8 @@ int launch_wgrad_ws2(WgradArgs a, hipStream_t s) {
   const unsigned grid = ps_persistent_grid(items, a.nb, a.tpb);
   const size_t lds = 3 * 64 * (256 + 128) * 2;
   if (a.stride == 1 && a.taps == 1) hipLaunchKernelGGL((conv_wgrad_ws2_kernel<Tr::F16, 2, DET>), dim3(grid), dim3(512), lds, s, a);
+  else if (a.stride == 1 && a.taps == 9 && g_wgrad_vtab && (a.vtab = wgrad_valid_table(a.H, a.W, a.dil, &a.vperiod)) != nullptr)
+    hipLaunchKernelGGL((conv_wgrad_ws2_kernel<Tr::F16, 3, DET>), dim3(grid), dim3(512), lds, s, a);
   else if (a.stride == 1) hipLaunchKernelGGL((conv_wgrad_ws2_kernel<Tr::F16, 1, DET>), dim3(grid), dim3(512), lds, s, a);
   else hipLaunchKernelGGL((conv_wgrad_ws2_kernel<Tr::F16, 0, DET>), dim3(grid), dim3(512), lds, s, a);
   PS_CHECK_LAUNCH("conv_wgrad_ws2");
@@ -1078,6 +1167,8 @@ int fill_wgrad_args(const ps_conv_geom* g, const void* x, const void* dy, float*
   a.dy_bytes = (unsigned)gb;
   a.part = nullptr;
   a.part_stride = (long long)a.cout * a.taps * a.cin;
+  a.vtab = nullptr;
+  a.vperiod = 1;
   return PS_OK;
 }
 
@@ -1096,6 +1187,10 @@ extern "C" void ps_debug_set_wgrad256(int v) { g_wgrad256 = v; }
 extern "C" void ps_debug_set_wgrad_ablate(int v) { g_wgrad_ablate = v; }
 extern "C" void ps_debug_set_wgrad_ovh(int v) { g_wgrad_ovh = v; }
 extern "C" void ps_debug_set_wgrad_raster(int v) { g_wgrad_raster = v; }
+extern "C" void ps_debug_set_wgrad_vtab(int v) { g_wgrad_vtab = v; }
+void ps_debug_reset_wgrad(void) {
+  g_wgrad_ws = 1; g_wgrad_ablate = 0; g_wgrad_ovh = 16; g_wgrad_ws2 = 1; g_wgrad256 = 0; g_wgrad_raster = -1; g_wgrad_vtab = 1;
+}
 #endif
 
 extern "C" int ps_conv_wgrad_variant(const ps_conv_geom* g) {

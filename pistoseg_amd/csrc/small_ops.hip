@@ -962,7 +962,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // Row-wise format conversion between f32 and the activation / weight storage formats: rows of c logical channels, 8 per thread,
 // arbitrary row pitches (channel slices of wider buffers).  f32 -> {bf16, f16, split}; {bf16, f16, split} -> f32.
-// Split (PS_BF16X3): three bf16 planes of c channels per row; pattern 0 = [hi | lo | hi] (activations), 1 = [hi | hi | lo] (weights);
+// Split (PS_BF16X3 / PS_F16X3): three bf16 / fp16 planes of c channels per row; pattern 0 = [hi | lo | hi] (activations), 1 = [hi | hi | lo] (weights);
 // hi = bf16(v) RNE, lo = bf16(v - hi); reading back: hi + lo (the lo plane is plane 1 or 2 by pattern).
 // ------------------------------------------------------------------------------------------------
 template <int SRC, int DST>
@@ -980,10 +980,11 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(const unsigned char* 
     } else if constexpr (SRC == PS_F16) {
       ps_load8<_Float16>(reinterpret_cast<const _Float16*>(src) + r * ld_src + c, v);
     } else {
-      const __bf16* p = reinterpret_cast<const __bf16*>(src) + r * ld_src + c;
+      typedef typename std::conditional<SRC == PS_F16X3, _Float16, __bf16>::type PT;
+      const PT* p = reinterpret_cast<const PT*>(src) + r * ld_src + c;
       float lo[8];
-      ps_load8<__bf16>(p, v);
-      ps_load8<__bf16>(p + (pattern ? 2 : 1) * cch, lo);
+      ps_load8<PT>(p, v);
+      ps_load8<PT>(p + (pattern ? 2 : 1) * cch, lo);
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] += lo[k];
     }
@@ -994,16 +995,17 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(const unsigned char* 
     } else if constexpr (DST == PS_F16) {
       ps_store8<_Float16>(reinterpret_cast<_Float16*>(dst) + r * ld_dst + c, v);
     } else {
-      __bf16* p = reinterpret_cast<__bf16*>(dst) + r * ld_dst + c;
+      typedef typename std::conditional<DST == PS_F16X3, _Float16, __bf16>::type PT;
+      PT* p = reinterpret_cast<PT*>(dst) + r * ld_dst + c;
       float hi[8], lo[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        hi[k] = ps_bf16_to_f32(ps_f32_to_bf16(v[k]));
+        hi[k] = static_cast<float>(static_cast<PT>(v[k]));
         lo[k] = v[k] - hi[k];
       }
-      ps_store8<__bf16>(p, hi);
-      ps_store8<__bf16>(p + cch, pattern ? hi : lo);
-      ps_store8<__bf16>(p + 2 * cch, pattern ? lo : hi);
+      ps_store8<PT>(p, hi);
+      ps_store8<PT>(p + cch, pattern ? hi : lo);
+      ps_store8<PT>(p + 2 * cch, pattern ? lo : hi);
     }
   }
 }
@@ -1025,10 +1027,12 @@ extern "C" int ps_convert_rows(const void* src, int32_t src_fmt, int64_t ld_src,
   if (src_fmt == PS_F32) {
     if (dst_fmt == PS_BF16) PS_CVT(PS_F32, PS_BF16);
     else if (dst_fmt == PS_F16) PS_CVT(PS_F32, PS_F16);
+    else if (dst_fmt == PS_F16X3) PS_CVT(PS_F32, PS_F16X3);
     else PS_CVT(PS_F32, PS_BF16X3);
   } else {
     if (src_fmt == PS_BF16) PS_CVT(PS_BF16, PS_F32);
     else if (src_fmt == PS_F16) PS_CVT(PS_F16, PS_F32);
+    else if (src_fmt == PS_F16X3) PS_CVT(PS_F16X3, PS_F32);
     else PS_CVT(PS_BF16X3, PS_F32);
   }
 #undef PS_CVT

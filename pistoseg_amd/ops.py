@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import PS_BF16, PS_BF16X3, PS_EPI_BNRELU, PS_EPI_NONE, PS_EPI_RELUBWD, PS_F16, PS_F32, ConvGeom, Epilogue, Tensor4
+from ._lib import PS_BF16, PS_BF16X3, PS_F16X3, PS_EPI_BNRELU, PS_EPI_NONE, PS_EPI_RELUBWD, PS_F16, PS_F32, ConvGeom, Epilogue, Tensor4
 
 Tensor = torch.Tensor
 
@@ -29,7 +29,7 @@ _VARIANT_NAMES = {1: "conv_igemm_kernel", 2: "conv_igemm_ws_kernel", 3: "conv_ig
 
 def _conv_label(kind: str, g: ConvGeom) -> str:
     """Kernel family serving this launch (asked of the library: ps_conv_variant mirrors the dispatcher)."""
-    dt = {PS_BF16: "bf16", PS_F16: "f16", PS_BF16X3: "bf16x3"}.get(g.dtype, "f32")
+    dt = {PS_BF16: "bf16", PS_F16: "f16", PS_BF16X3: "bf16x3", PS_F16X3: "fp16x3"}.get(g.dtype, "f32")
     if kind == "wgrad":
         v = int(_lib.load().ps_conv_wgrad_variant(C.byref(g)))
         return f"{ {2: 'conv_wgrad256_kernel', 1: 'conv_wgrad_ws2_kernel'}.get(v, 'conv_wgrad_kernel') }<{dt}>"
@@ -123,10 +123,11 @@ def _geom(spec: ConvSpec, dtype: int, n: int, h: int, w: int, ldc_x: int, ldc_y:
 
 
 def _conv_dt(t: Tensor, split: bool) -> int:
-    """C-ABI dtype of a conv launch on activation tensor t: `split` marks bf16 tensors holding the three planes [hi | lo | hi] (PS_BF16X3)."""
+    """C-ABI dtype of a conv launch on activation tensor t: `split` marks bf16 / fp16 tensors holding the three planes [hi | lo | hi]
+    (PS_BF16X3 / PS_F16X3)."""
     if split:
-        assert t.dtype == torch.bfloat16, "split tensors are bf16 planes"
-        return PS_BF16X3
+        assert t.dtype in (torch.bfloat16, torch.float16), "split tensors are bf16 or fp16 planes"
+        return PS_BF16X3 if t.dtype == torch.bfloat16 else PS_F16X3
     return _dt(t)
 
 
@@ -341,8 +342,8 @@ def convert_rows(src: Tensor, dst: Tensor, c: int, *, src_split: bool = False, d
             exp *= t.shape[d]
         return ld
 
-    sf = PS_BF16X3 if src_split else _dt(src)
-    df = PS_BF16X3 if dst_split else _dt(dst)
+    sf = _conv_dt(src, True) if src_split else _dt(src)
+    df = _conv_dt(dst, True) if dst_split else _dt(dst)
     assert src.shape[-1] == (3 if src_split else 1) * c and dst.shape[-1] == (3 if dst_split else 1) * c
     lib = _lib.load()
     _lib.check(lib.ps_convert_rows(src.data_ptr(), sf, pitch(src), dst.data_ptr(), df, pitch(dst), rows, c, int(weights), _stream()), "ps_convert_rows")

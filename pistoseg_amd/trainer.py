@@ -122,8 +122,8 @@ class SegTrainer(_ArenaMixin):
         self.pb_flat = torch.empty(total, device=dev, dtype=model.compute_dtype) if model.precision in ("bf16", "fp16") else None
         # fp16 activations gradients underflow without a loss scale (a CE gradient is ~1/(N*H*W) = 3e-7 per pixel):
         # dynamic scaling a la torch.cuda.amp.GradScaler (x0.5 and skip on overflow, x2 every 200 clean steps).
-        self.dynamic_scale = model.precision == "fp16" and loss_scale is None
-        self.loss_scale = float(loss_scale) if loss_scale is not None else (65536.0 if model.precision == "fp16" else 1.0)
+        self.dynamic_scale = model.precision in ("fp16", "fp16x3") and loss_scale is None
+        self.loss_scale = float(loss_scale) if loss_scale is not None else (65536.0 if model.precision in ("fp16", "fp16x3") else 1.0)
         self.clean_steps, self.skipped_steps = 0, 0
         self.grads: Dict[str, Tensor] = {}
         self.offsets: Dict[str, Tuple[int, int]] = {}
@@ -221,8 +221,8 @@ class RFMTrainer(_ArenaMixin):
         self.buf_flat = torch.zeros(total, device=dev, dtype=torch.float32)
         # 16-bit shadow of the weights, refreshed by the fused optimiser (the split path re-derives its [hi | hi | lo] planes from the master instead)
         self.pb_flat = torch.empty(total, device=dev, dtype=model.compute_dtype) if model.precision in ("bf16", "fp16") else None
-        self.dynamic_scale = model.precision == "fp16" and loss_scale is None
-        self.loss_scale = float(loss_scale) if loss_scale is not None else (1024.0 if model.precision == "fp16" else 1.0)
+        self.dynamic_scale = model.precision in ("fp16", "fp16x3") and loss_scale is None
+        self.loss_scale = float(loss_scale) if loss_scale is not None else (1024.0 if model.precision in ("fp16", "fp16x3") else 1.0)
         self.clean_steps, self.skipped_steps = 0, 0
         self.grads: Dict[str, Tensor] = {}
         self.offsets: Dict[str, Tuple[int, int]] = {}

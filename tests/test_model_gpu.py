@@ -38,11 +38,11 @@ def masks_agree_up_to_ties(logits_ref, mask_ref, mask_got, err):
     return bool((gap[diff] <= 2 * err).all()), int(diff.sum())
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "fp16x3"])
 @pytest.mark.parametrize("tag,n,s,c,seed", [("s64_c4", 2, 64, 4, 101), ("s224_c4", 1, 224, 4, 102), ("s256_c5", 1, 256, 5, 103)])
 def test_seg_forward_fp32_matches_golden_and_oracle(golden_dir, tag, n, s, c, seed, precision):
     """The two paths that carry the north_star tolerance (fp32 logits within 1e-4 relative, masks bit-exact up to ties below the logit error):
-    "fp32" = exact-f32 MFMA, "bf16x3" = split bf16 (hi + lo planes, three 16-bit MFMAs per product, f32 accumulate)."""
+    "fp32" = exact-f32 MFMA, "bf16x3" / "fp16x3" = split bf16 / fp16 (hi + lo planes, three 16-bit MFMAs per product, f32 accumulate)."""
     from pistoseg_amd import _lib, ops
 
     g = np.load(os.path.join(golden_dir, f"revise_{tag}.npz"))
@@ -74,7 +74,7 @@ def test_seg_forward_fp32_matches_golden_and_oracle(golden_dir, tag, n, s, c, se
     assert_tie_excused(f"seg masks {tag}", ndiff, mask_e2e.numel(), ok)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "fp16x3"])
 def test_backbone_features_fp32(golden_dir, precision):
     from pistoseg_amd.resnet38d import Net
 
@@ -214,7 +214,7 @@ def relu_pattern_flips(saved, collect, model=None):
     return flips
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3", "fp16x3"])
 def test_seg_training_gradients_match_oracle(precision):
     """CE loss + every trainable conv gradient (dropout injected as fixed masks) vs CPU autograd.
 
@@ -237,8 +237,9 @@ def test_seg_training_gradients_match_oracle(precision):
         p = 0.3 if k.startswith("b6") else 0.5
         drop[k] = (torch.rand(v.shape, generator=g) >= p).float() / (1 - p)
     model.sample_dropout = lambda n_, dev_: {k: v.to(dev_) for k, v in drop.items()}
+    scale = 65536.0 if precision == "fp16x3" else 1.0  # fp16 planes: the CE gradient (~1e-5 per pixel here) needs the fp16 path's loss scale
     logits = model(x.to(D))
-    loss, dlogits = ops.softmax_ce(logits.detach(), target.to(D), 3, want_grad=True)
+    loss, dlogits = ops.softmax_ce(logits.detach(), target.to(D), 3, want_grad=True, grad_scale=scale)
     logits.backward(dlogits)
 
     sd_ref = {k: v.clone() for k, v in sd.items()}
@@ -256,7 +257,7 @@ def test_seg_training_gradients_match_oracle(precision):
     flips = relu_pattern_flips(model._last_saved, collect, model)
     if precision == "fp32":
         loss_tol, grad_tol = 1e-5, (2e-4 if flips == 0 else 2e-2)
-    elif precision == "bf16x3":  # 16 mantissa bits per stored value, three-term products: a handful of ReLU-boundary flips are possible
+    elif precision in ("bf16x3", "fp16x3"):  # 16 / 22 significant bits per stored value, three-term products: a handful of ReLU-boundary flips are possible
         loss_tol, grad_tol = 1e-4, (1e-3 if flips == 0 else 2e-2)
     else:  # bf16 storage: thousands of boundary activations differ by construction
         loss_tol, grad_tol = 3e-2, 1.5e-1
@@ -264,7 +265,7 @@ def test_seg_training_gradients_match_oracle(precision):
     worst = 0.0
     for k in tk:
         assert named[k].grad is not None, k
-        a, b = named[k].grad.cpu().double(), sd_ref[k].grad.double()
+        a, b = named[k].grad.cpu().double() / scale, sd_ref[k].grad.double()
         e = float((a - b).norm() / b.norm()) if (flips or precision != "fp32") else rel_err(a, b)
         worst = max(worst, e)
         assert e < grad_tol, (k, e, flips)

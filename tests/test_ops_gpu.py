@@ -675,7 +675,7 @@ def test_wgrad_deterministic_mode(case, dtype, library):
     for rep in range(3):
         dw = init.clone().to(D)
         if rep == 2:  # garbage in the workspace must not matter
-            ops._wgrad_workspace(max(need, 16), D).fill_(0x7F)
+            ops._wgrad_workspace(max(need, 16), D, ops._stream()).fill_(0x7F)
         ops.conv2d_wgrad(spec, xd, gyd, dw, deterministic=True)
         outs.append(dw)
     torch.cuda.synchronize()

@@ -19,16 +19,19 @@ def rel_err(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
 
 
-def split_repr(t):
-    """The value a split tensor can hold: hi + lo with hi = bf16(t), lo = bf16(t - hi)."""
-    hi = t.to(torch.bfloat16).float()
-    return hi + (t - hi).to(torch.bfloat16).float()
+BF, HF = torch.bfloat16, torch.float16  # plane types of the two split formats (PS_BF16X3, PS_F16X3)
 
 
-def planes(t, weights=False):
-    """f32 [..., C] -> bf16 [..., 3C]: [hi | lo | hi] (activations) or [hi | hi | lo] (weights)."""
-    hi = t.to(torch.bfloat16)
-    lo = (t - hi.float()).to(torch.bfloat16)
+def split_repr(t, dt=BF):
+    """The value a split tensor can hold: hi + lo with hi = dt(t), lo = dt(t - hi)."""
+    hi = t.to(dt).float()
+    return hi + (t - hi).to(dt).float()
+
+
+def planes(t, weights=False, dt=BF):
+    """f32 [..., C] -> 16-bit [..., 3C]: [hi | lo | hi] (activations) or [hi | hi | lo] (weights)."""
+    hi = t.to(dt)
+    lo = (t - hi.float()).to(dt)
     return torch.cat([hi, hi, lo] if weights else [hi, lo, hi], dim=-1).contiguous()
 
 
@@ -41,29 +44,32 @@ def nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
 
+@pytest.mark.parametrize("dt", [BF, HF])
 @pytest.mark.parametrize("weights", [False, True])
-def test_convert_rows_split_planes_and_casts(weights):
+def test_convert_rows_split_planes_and_casts(weights, dt):
     """ps_convert_rows: f32 -> split planes (both layouts) bit for bit as torch's RNE casts give them, back to f32 = hi + lo exactly; strided
     rows (channel slices of wider buffers); the plain 16-bit casts."""
     from pistoseg_amd import ops
 
     g = torch.Generator().manual_seed(11)
     rows, c = 37, 72
-    src = torch.randn(rows, c, generator=g) * torch.logspace(-6, 6, rows).view(-1, 1)
-    wide = torch.full((rows, 3 * c + 24), 7.0, dtype=torch.bfloat16, device=D)
+    src = torch.randn(rows, c, generator=g) * torch.logspace(-6, 6 if dt == BF else 3, rows).view(-1, 1)  # (fp16 planes: |v| <= 65504)
+    wide = torch.full((rows, 3 * c + 24), 7.0, dtype=dt, device=D)
     ops.convert_rows(src.to(D), wide[:, 8:8 + 3 * c], c, dst_split=True, weights=weights)
-    assert torch.equal(wide[:, 8:8 + 3 * c].cpu(), planes(src, weights))
+    assert torch.equal(wide[:, 8:8 + 3 * c].cpu(), planes(src, weights, dt))
     assert bool((wide[:, :8] == 7.0).all()) and bool((wide[:, 8 + 3 * c:] == 7.0).all())  # nothing outside the slice is touched
     if not weights:
         back = torch.empty(rows, c, device=D)
         ops.convert_rows(wide[:, 8:8 + 3 * c], back, c, src_split=True)
-        assert torch.equal(back.cpu(), split_repr(src))
+        assert torch.equal(back.cpu(), split_repr(src, dt))
         assert rel_err(back.cpu(), src) < 2.0 ** -16
-    for dt in (torch.bfloat16, torch.float16):
+        if dt == HF:  # 22 significant bits while lo is a normal fp16 number, 2^-25 absolute below
+            assert float((back.cpu() - src).abs().div(src.abs().clamp_min(2.0 ** -3)).max()) < 2.0 ** -21
+    for dt2 in (torch.bfloat16, torch.float16):
         small = (torch.randn(rows, c, generator=g)).to(D)
-        low = torch.empty(rows, c, device=D, dtype=dt)
+        low = torch.empty(rows, c, device=D, dtype=dt2)
         ops.convert_rows(small, low, c)
-        assert torch.equal(low.cpu(), small.cpu().to(dt))
+        assert torch.equal(low.cpu(), small.cpu().to(dt2))
         up = torch.empty(rows, c, device=D)
         ops.convert_rows(low, up, c)
         assert torch.equal(up.cpu(), low.cpu().float())
@@ -84,8 +90,9 @@ SPLIT_CASES = [
 ]
 
 
+@pytest.mark.parametrize("dt", [BF, HF])
 @pytest.mark.parametrize("case,family", SPLIT_CASES)
-def test_split_conv_fwd_dgrad_wgrad_match_fp32_cpu(case, family):
+def test_split_conv_fwd_dgrad_wgrad_match_fp32_cpu(case, family, dt):
     """Forward with the full epilogue (residual add, raw output, BN + ReLU + dropout output), data gradient with the ReLU-mask epilogue and a
     second addend, weight gradient (three bf16 launches on plane slices): all within 1e-4 of torch-CPU fp32 on the same split-representable
     operands (resnet38d.py:16-21,38-41,64,86)."""
@@ -96,48 +103,50 @@ def test_split_conv_fwd_dgrad_wgrad_match_fp32_cpu(case, family):
     n, h, w, cin, cout, k, s_, d = case
     spec = ops.ConvSpec(cin, cout, k, s_, d)
     if family is not None:
-        g_ = ops._geom(spec, _lib.PS_BF16X3, n, h, w, 3 * cin, 3 * cout)
+        g_ = ops._geom(spec, _lib.PS_BF16X3 if dt == BF else _lib.PS_F16X3, n, h, w, 3 * cin, 3 * cout)
         want = {"halo": (7,), "ws2": (4, 5), "gemm256": (8,)}[family]
         assert int(_lib.load().ps_conv_variant(C.byref(g_), 0)) in want
+    SR = lambda t: split_repr(t, dt)
+    PL = lambda t, weights=False: planes(t, weights, dt)
     g = torch.Generator().manual_seed(sum(case))
-    x = split_repr(torch.randn(n, cin, h, w, generator=g)).requires_grad_(True)
-    wt = split_repr(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5).requires_grad_(True)
+    x = SR(torch.randn(n, cin, h, w, generator=g)).requires_grad_(True)
+    wt = SR(torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5).requires_grad_(True)
     pad = d if k == 3 else 0
     y = F.conv2d(x, wt, stride=s_, padding=pad, dilation=d)
-    res = split_repr(torch.randn(y.shape, generator=g))
+    res = SR(torch.randn(y.shape, generator=g))
     scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
     drop = (torch.rand(n, cout, generator=g) > 0.3).float() / 0.7
     act = F.relu((y + res) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)) * drop.view(n, cout, 1, 1)
-    gy = split_repr(torch.randn(y.shape, generator=g))
+    gy = SR(torch.randn(y.shape, generator=g))
     y.backward(gy)
-    mask_src = split_repr(F.relu(torch.randn(n, cin, h, w, generator=g)))
-    add1 = split_repr(torch.randn(n, cin, h, w, generator=g))
+    mask_src = SR(F.relu(torch.randn(n, cin, h, w, generator=g)))
+    add1 = SR(torch.randn(n, cin, h, w, generator=g))
     sc2 = torch.rand(cin, generator=g) + 0.5
     gx_ref = torch.where(mask_src > 0, x.grad * sc2.view(1, -1, 1, 1), torch.zeros(())) + add1
 
     ho, wo = spec.out_hw(h, w)
-    xd = planes(nhwc(x.detach())).to(D)
-    wf = planes(wt.detach().permute(0, 2, 3, 1).contiguous(), weights=True).to(D)  # [cout][kh][kw][hi | hi | lo]
-    wd = planes(wt.detach().permute(1, 2, 3, 0).contiguous(), weights=True).to(D)  # [cin][kh][kw][hi | hi | lo]
+    xd = PL(nhwc(x.detach())).to(D)
+    wf = PL(wt.detach().permute(0, 2, 3, 1).contiguous(), weights=True).to(D)  # [cout][kh][kw][hi | hi | lo]
+    wd = PL(wt.detach().permute(1, 2, 3, 0).contiguous(), weights=True).to(D)  # [cin][kh][kw][hi | hi | lo]
     nan = float("nan")
-    out_raw = torch.full((n, ho, wo, 3 * cout), nan, device=D, dtype=torch.bfloat16)
+    out_raw = torch.full((n, ho, wo, 3 * cout), nan, device=D, dtype=dt)
     # the activated output as a channel slice of a wider buffer (the fused bottleneck's [a | a3] layout)
-    wide = torch.full((n, ho, wo, 3 * cout + 3 * 64), nan, device=D, dtype=torch.bfloat16)
+    wide = torch.full((n, ho, wo, 3 * cout + 3 * 64), nan, device=D, dtype=dt)
     out_act = wide[..., 3 * 64:]
-    ops.conv2d_fwd(spec, xd, wf, add0=planes(nhwc(res)).to(D), out_raw=out_raw, bn_scale=scale.to(D), bn_shift=shift.to(D), drop=drop.to(D),
+    ops.conv2d_fwd(spec, xd, wf, add0=PL(nhwc(res)).to(D), out_raw=out_raw, bn_scale=scale.to(D), bn_shift=shift.to(D), drop=drop.to(D),
                    out_act=out_act, split=True)
     assert rel_err(merge(out_raw.cpu()), nhwc((y + res).detach())) < TOL
     assert rel_err(merge(out_act.cpu()), nhwc(act.detach())) < TOL
     assert torch.equal(out_raw[..., :cout], out_raw[..., 2 * cout:])  # both hi planes written
     assert bool(torch.isnan(wide[..., :3 * 64].float()).all())         # nothing outside the slice touched
-    gyd = planes(nhwc(gy)).to(D)
-    gx = torch.full((n, h, w, 3 * cin), nan, device=D, dtype=torch.bfloat16)
-    ops.conv2d_dgrad(spec, gyd, wd, (h, w), mask_src=planes(nhwc(mask_src)).to(D), bn_scale=sc2.to(D), add1=planes(nhwc(add1)).to(D), out=gx, split=True)
+    gyd = PL(nhwc(gy)).to(D)
+    gx = torch.full((n, h, w, 3 * cin), nan, device=D, dtype=dt)
+    ops.conv2d_dgrad(spec, gyd, wd, (h, w), mask_src=PL(nhwc(mask_src)).to(D), bn_scale=sc2.to(D), add1=PL(nhwc(add1)).to(D), out=gx, split=True)
     assert rel_err(merge(gx.cpu()), nhwc(gx_ref)) < TOL
     dw = torch.zeros((cout, k, k, cin), device=D, dtype=torch.float32)
     ops.conv2d_wgrad(spec, xd, gyd, dw, split=True)
     assert rel_err(dw.cpu(), wt.grad.permute(0, 2, 3, 1)) < TOL
-    print(f"[split conv {case}] raw {rel_err(merge(out_raw.cpu()), nhwc((y + res).detach())):.2e} act {rel_err(merge(out_act.cpu()), nhwc(act.detach())):.2e} "
+    print(f"[split conv {str(dt)[6:]} {case}] raw {rel_err(merge(out_raw.cpu()), nhwc((y + res).detach())):.2e} act {rel_err(merge(out_act.cpu()), nhwc(act.detach())):.2e} "
           f"dgrad {rel_err(merge(gx.cpu()), nhwc(gx_ref)):.2e} wgrad {rel_err(dw.cpu(), wt.grad.permute(0, 2, 3, 1)):.2e}")
 
 

@@ -74,21 +74,8 @@ def main():
             res = {}
             for r in range(3):  # interleaved rounds
                 for vn, vv in variants:
-                    lib.ps_debug_set_3stage(0)
-                    lib.ps_debug_set_pp(0)
-                    lib.ps_debug_set_ws(1)
-                    lib.ps_debug_set_ws2(1)
-                    lib.ps_debug_set_halo(1)
-                    lib.ps_debug_set_gemm256(1)
-                    lib.ps_debug_set_gemm256_tail(1)
+                    lib.ps_debug_reset()
                     lib.ps_debug_set_halo_ring(args.halo_ring)
-                    lib.ps_debug_set_halo_tail(1)
-                    lib.ps_debug_set_ablate(0)
-                    lib.ps_debug_set_wgrad_ws2(1)
-                    lib.ps_debug_set_wgrad256(0)
-                    lib.ps_debug_set_wgrad_ablate(0)
-                    lib.ps_debug_set_wgrad_ovh(16)
-                    lib.ps_debug_set_supertile(4)
                     getattr(lib, "ps_debug_set_" + vn)(int(vv))
                     fns[what]()
                     torch.cuda.synchronize()
@@ -104,18 +91,7 @@ def main():
                 t = min(ts)
                 line += f" {vn}={vv}: {t*1e3:7.1f}us {flops/t/1e9:6.0f}TF"
         print(line, flush=True)
-    lib.ps_debug_set_3stage(0)
-    lib.ps_debug_set_bn(0)
-    lib.ps_debug_set_bm(0)
-    lib.ps_debug_set_ablate(0)
-    lib.ps_debug_set_pp(0)
-    lib.ps_debug_set_ws(1)
-    lib.ps_debug_set_ws2(1)
-    lib.ps_debug_set_halo(1)
-    lib.ps_debug_set_gemm256(1)
-    lib.ps_debug_set_wgrad_ws2(1)
-    lib.ps_debug_set_wgrad_ablate(0)
-    lib.ps_debug_set_wgrad_raster(-1)
+    lib.ps_debug_reset()
 
 if __name__ == "__main__":
     main()

@@ -10,16 +10,18 @@ lib = sys.argv[1] if len(sys.argv) > 1 else "pistoseg_amd/libpistoseg_hip.so"
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 tmp = "/tmp/_kregs"
 subprocess.run(["rm", "-rf", tmp]); subprocess.run(["mkdir", "-p", tmp])
-# unbundle the gfx950 code object, then read its msgpack metadata as text
-subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--type=o", f"--input={lib}", "--unbundle", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
-                f"--output={tmp}/dev.co"], check=False, capture_output=True)
-import os
-if not os.path.exists(f"{tmp}/dev.co") or os.path.getsize(f"{tmp}/dev.co") == 0:
-    # fat binary sits in section .hip_fatbin
-    subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, f"{tmp}/fat.bin"], check=True)
-    subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--type=o", f"--input={tmp}/fat.bin", "--unbundle",
-                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={tmp}/dev.co"], check=True)
-out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", f"{tmp}/dev.co"], capture_output=True, text=True).stdout
+# the library's .hip_fatbin section holds one offload bundle per translation unit: unbundle each, read its msgpack metadata as text
+subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, f"{tmp}/fat.bin"], check=True)
+blob = open(f"{tmp}/fat.bin", "rb").read()
+magic = b"__CLANG_OFFLOAD_BUNDLE__"
+starts = [i for i in range(len(blob)) if blob.startswith(magic, i)]
+out = ""
+for n, st in enumerate(starts):
+    en = starts[n + 1] if n + 1 < len(starts) else len(blob)
+    open(f"{tmp}/b{n}.bin", "wb").write(blob[st:en])
+    subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--type=o", f"--input={tmp}/b{n}.bin", "--unbundle",
+                    "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={tmp}/dev{n}.co"], check=True, capture_output=True)
+    out += subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", f"{tmp}/dev{n}.co"], capture_output=True, text=True).stdout
 kern = []
 cur = {}
 for ln in out.splitlines():

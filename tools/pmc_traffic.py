@@ -11,7 +11,7 @@ fetch_dir, write_dir, out = sys.argv[1:4]
 
 def family(name):
     stem = re.sub(r"[<(].*", "", name.replace("void ", "").replace("(anonymous namespace)::", ""))
-    dt = "bf16x3" if "TraitsBF16X3" in name else "bf16" if ("TraitsBF16" in name or "DF16b" in name) else "f16" if ("TraitsF16" in name or "IDF16_" in name) else "f32" if "TraitsF32" in name else ""
+    dt = "bf16x3" if "TraitsBF16X3" in name else "fp16x3" if "TraitsF16X3" in name else "bf16" if ("TraitsBF16" in name or "DF16b" in name) else "f16" if ("TraitsF16" in name or "IDF16_" in name) else "f32" if "TraitsF32" in name else ""
     return (stem + (f"<{dt}>" if dt else ""))[:100]
 
 

@@ -21,8 +21,8 @@ K, W = prof["steps"], prof["warmup"]
 batch = prof["config"]["per_gpu_batch"]
 n_train, n_infer = W + K + 1, (max(1, W) + K if "infer_value" in prof else 0)
 dt = prof["dtype"]
-peak = {"bf16": 2500.0, "fp16": 2500.0, "bf16x3": 2500.0 / 3, "fp32": 157.3}[dt]
-tag = {"bf16": "TraitsBF16,", "fp16": "TraitsF16,", "bf16x3": "TraitsBF16X3,", "fp32": "TraitsF32,"}[dt]
+peak = {"bf16": 2500.0, "fp16": 2500.0, "bf16x3": 2500.0 / 3, "fp16x3": 2500.0 / 3, "fp32": 157.3}[dt]
+tag = {"bf16": "TraitsBF16,", "fp16": "TraitsF16,", "bf16x3": "TraitsBF16X3,", "fp16x3": "TraitsF16X3,", "fp32": "TraitsF32,"}[dt]
 rows = [r for r in csv.DictReader(open(stats_csv)) if "conv_igemm_halo_kernel" in r["Name"] and tag in r["Name"]]
 main = [r for r in rows if r["Name"].split("IgemmArgs")[0].rstrip("( ").endswith(", 4>")]
 tail = [r for r in rows if r["Name"].split("IgemmArgs")[0].rstrip("( ").endswith(", 2>")]

@@ -43,14 +43,12 @@ else:
         def one(): tr.train_step(x, y)
 if SERIAL:
     tr.wgrad_stream = None
-RESET = {"wgrad_raster": -1, "halo_tail": 1, "supertile": 4, "wgrad_ovh": 16, "gemm256": 1, "gemm256_tail": 1, "wgrad256": 0, "gemm256_rule": 32 * 10000 + 1024, "gemm256_min_tiles": 384,
-         "ws": 1, "ws2": 1, "halo": 1, "halo_ring": 3, "s2split": 1, "bm": 0, "bn": 0, "wgrad_ws": 1, "wgrad_ws2": 1, "3stage": 0, "pp": 0}
 from pistoseg_amd import ops
 _geom = ops._geom
 def _geom_unshared(*a):  # A/B of the gpu_shared launch option: the pseudo-switch `gpu_shared=0` hides the two-stream backward's hint from the library
     g = _geom(*a); g.gpu_shared = 0; return g
 def apply(v):
-    for k, d in RESET.items(): getattr(lib, "ps_debug_set_" + k)(d)
+    lib.ps_debug_reset()  # every tunable back to the library default (one list, in the library)
     ops._geom = _geom
     if v != "base":
         for kv in v.split(","):
