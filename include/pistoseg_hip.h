@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PS_VERSION 220 /* major*10000 + minor*100 + patch */
+#define PS_VERSION 221 /* major*10000 + minor*100 + patch */
 
 typedef enum ps_status {
   PS_OK = 0,
@@ -84,6 +84,11 @@ typedef struct ps_conv_geom {
                             * of the two-stream backward): the partial last round of a launch is then NOT re-issued as a second launch of
                             * smaller tiles -- the co-running kernel's blocks fill those CUs, and the split costs 2 % of a training step
                             * (profiles/r03_tail_split_two_streams.txt).  0 = the launch has the GPU to itself.  Bit-identical results. */
+  int32_t cus_reserved;   /* launch option of the persistent kernels: size the grid (and the static tile schedule) for `#CUs - cus_reserved` compute
+                            * units, leaving the rest to a co-running kernel that HOLDS its CUs for as long as it lives -- an RCCL collective beside
+                            * the backward.  A persistent block that cannot become resident serialises its whole static share behind the others
+                            * (+33 % on a training step beside a 16-CU kernel); with the reservation every block starts at once and the launch costs
+                            * the ideal #CUs / (#CUs - reserved).  0 = all CUs.  Bit-identical results for every value. */
 } ps_conv_geom;
 
 /* Epilogue applied to the f32 accumulator `acc` of every produced element (pixel m, channel c):

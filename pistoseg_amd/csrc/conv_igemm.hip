@@ -42,6 +42,7 @@ struct IgemmArgs {
   int ablate;                 // timing experiments only (results WRONG): 1 = stage the first two K-steps only; 2 = also no per-step barriers (ws kernel)
   int nb, tpb;                // persistent kernels: blocks per batch (#CUs), tiles per block (0 = one batch), see ps_block_items
   int shared;                 // host side only (ps_conv_geom.gpu_shared): another stream fills this launch's partial last round -- no tail launch
+  int reserved;               // host side only (ps_conv_geom.cus_reserved): CUs left to a co-running kernel; the persistent grids use the rest
   // stride-2 data gradient, one launch per output parity class (conv_igemm_ws2_kernel<.., SPLIT>): the produced grid Ho x Wo is the
   // class's sub-grid, pixel (p', q') of it is pixel (oy + 2p', ox + 2q') of the full Hf x Wf gradient, and only the taps in tap_mask
   // (those that hit dy at integer positions for this parity) are staged and multiplied.  epi_M = rows of the full tensor.
@@ -2150,6 +2151,7 @@ int check_geom(const ps_conv_geom* g) {
   PS_REQUIRE(g->n > 0 && g->h > 0 && g->w > 0, "conv: empty input %dx%dx%d", g->n, g->h, g->w);
   PS_REQUIRE(g->tiles_per_block >= 0 && g->tiles_per_block <= 4096, "conv: tiles_per_block %d out of range", g->tiles_per_block);
   PS_REQUIRE(g->gpu_shared == 0 || g->gpu_shared == 1, "conv: gpu_shared %d (0 or 1)", g->gpu_shared);
+  PS_REQUIRE(g->cus_reserved >= 0 && g->cus_reserved <= 4096, "conv: cus_reserved %d out of range", g->cus_reserved);
   const int es = ps_esize(g->dtype);
   PS_REQUIRE((g->cin * es) % 128 == 0 && (g->cout * es) % 128 == 0,
              "conv: cin=%d cout=%d must be multiples of %d channels", g->cin, g->cout, 128 / es);
@@ -2210,6 +2212,12 @@ int set_extents(IgemmArgs& a, long long src_bytes, long long wgt_bytes, int es) 
 // Column-block width of the halo kernel's 8-row tiles for a feature map of width w: 28 (224-pixel tiles; the 28 / 56 / 112 / 224-wide
 // maps of 224 x 224 inputs) or 32 (256-pixel tiles; the 32 / 64 / 128 / 256-wide maps of 256 x 256 inputs, stages 2 and 4 of the
 // reference: infer_pseudo_masks.py:50, infer_revise_masks.py:46); 0 if neither divides w.
+// CUs the persistent kernels of a launch may count on (ps_conv_geom.cus_reserved; at least a quarter of the device)
+static int usable_cus(int reserved) {
+  const int n = ps_num_cus();
+  return reserved <= 0 ? n : (n - reserved > n / 4 ? n - reserved : n / 4);
+}
+
 static int halo_tile_width(int w) { return (w <= 0 || w > 256) ? 0 : (w % 28 == 0 ? 28 : (w % 32 == 0 ? 32 : 0)); }
 
 static int pick_ws_variant(long long M, int Cd, int esize, bool halo_ok) {
@@ -2327,7 +2335,7 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s, bool allow_gemm256 = true) {
     if (v == PS_CONV_HALO) {
       const int tw = halo_tile_width(a.Ws);
       b.ntm = (a.M / a.Ws + 7) / 8 * (a.Ws / tw);  // blocks of 8 global rows x column blocks of tw
-      b.nb = ps_num_cus();
+      b.nb = usable_cus(a.reserved);
       b.tpb = a.tpb;
       // The partial last round.  With T = ntm x ntn tiles on nb CUs, R = T mod nb <= nb / 2 tiles would keep R CUs busy for a whole round
       // (512-channel layers at bs=64: 896 tiles = 3.5 rounds).  Those R tiles -- whole pixel tiles, R % ntn == 0 -- go to a second launch
@@ -2374,7 +2382,7 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s, bool allow_gemm256 = true) {
     const int bm = v == PS_CONV_WS2_256 ? 256 : v == PS_CONV_WS2_224 ? 224 : v == PS_CONV_WS_128 ? 128 : 112;
     b.ntm = (a.M + bm - 1) / bm;
     const dim3 grid((unsigned)(b.ntm * b.ntn));
-    b.nb = ps_num_cus();
+    b.nb = usable_cus(a.reserved);
     b.tpb = a.tpb;
     const dim3 pgrid(ps_persistent_grid((long long)b.ntm * b.ntn, b.nb, b.tpb));  // persistent: one block per CU (per batch)
     if constexpr (kLargeTiles) {
@@ -2538,6 +2546,7 @@ extern "C" int ps_conv2d_fwd(const ps_conv_geom* g, const void* x, const void* w
   a.epi = *epi;
   a.tpb = g->tiles_per_block;
   a.shared = g->gpu_shared;
+  a.reserved = g->cus_reserved;
   if (int rc = set_extents(a, (long long)g->n * g->h * g->w * a.pix_bytes, (long long)g->cout * a.wrow_bytes, es)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (g->dtype == PS_BF16X3) return dispatch_bn<TraitsBF16X3>(a, s);
@@ -2574,7 +2583,7 @@ static int dgrad_s2_split(const IgemmArgs& a0, hipStream_t s) {
       const long long c256 = ((t256 * b.ntn + 255) / 256) * 256, c224 = ((t224 * b.ntn + 255) / 256) * 224;
       const bool use224 = c224 * 103 < c256 * 100;
       b.ntm = (int)(use224 ? t224 : t256);
-      b.nb = ps_num_cus();
+      b.nb = usable_cus(a0.reserved);
       b.tpb = a0.tpb;
       const dim3 pgrid(ps_persistent_grid((long long)b.ntm * b.ntn, b.nb, b.tpb));
       if (use224) hipLaunchKernelGGL((conv_igemm_ws2_kernel<Tr, 224, true>), pgrid, dim3(512), 3 * (224 * 128 + 128 * 128), s, b);
@@ -2611,6 +2620,7 @@ extern "C" int ps_conv2d_dgrad(const ps_conv_geom* g, const void* dy, const void
   a.epi = *epi;
   a.tpb = g->tiles_per_block;
   a.shared = g->gpu_shared;
+  a.reserved = g->cus_reserved;
   if (int rc = set_extents(a, (long long)g->n * a.Hs * a.Ws * a.pix_bytes, (long long)g->cin * a.wrow_bytes, es)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dgrad_s2_split_ok(g, epi))

@@ -37,6 +37,7 @@ struct WgradArgs {
   int raster;                  // block order (see kernel)
   int ablate;                  // timing experiments only (results WRONG): 1 = no atomics, 2 = plain stores instead of atomics
   int nb, tpb;                 // persistent kernel: blocks per batch (#CUs), items per block (0 = one batch), see ps_block_items
+  int reserved;                // host side only (ps_conv_geom.cus_reserved): CUs left to a co-running kernel
   int cig, cog;                // item order: cin / cout tiles per group of consecutive items (see decode_item)
   float* part;                 // deterministic mode (DET kernels): workspace [pixel range][cout][taps][cin] f32 for the partial sums
   long long part_stride;       // elements per pixel range = cout * taps * cin
@@ -1020,7 +1021,8 @@ static long long plan_wgrad_ws2(WgradArgs& a) {
   a.raster = 0;
   a.ablate = g_wgrad_ablate;
   const long long tiles = (long long)a.tiles_co * a.tiles_ci * a.taps;
-  const int ncu = ps_num_cus();
+  const int all_cus = ps_num_cus();
+  const int ncu = a.reserved <= 0 ? all_cus : std::max(all_cus - a.reserved, all_cus / 4);  // (the split-K plan is made for the CUs the launch may count on)
   // Pixel-range count: one block per CU works through ceil(items / CUs) items of `per` K-steps each (+ ~6 K-steps' worth of
   // atomics and pipeline refill per item); ties go to fewer ranges (fewer atomics).
   long long splits = 1, best = -1;
@@ -1157,6 +1159,7 @@ int fill_wgrad_args(const ps_conv_geom* g, const void* x, const void* dy, float*
   a.taps = g->ksize * g->ksize; a.ctr = g->ksize / 2;
   a.cin = g->cin; a.cout = g->cout;
   a.tpb = g->tiles_per_block;
+  a.reserved = g->cus_reserved;
   a.x_pix_bytes = (long long)g->ldc_x * es;
   a.dy_pix_bytes = (long long)g->ldc_y * es;
   a.div_hw = make_fastdiv((uint32_t)(a.Ho * a.Wo));

@@ -50,10 +50,17 @@ class BucketedAllReduce:
     dispatcher re-balances (the `tiles_per_block` launch option of ps_conv_geom); forward passes and single-GPU runs keep the fully persistent schedule."""
 
     def __init__(self, flat: Tensor, buckets: List[Tuple[str, int, int]], group=None, shared_tiles_per_block: int = 1, launch_opts=None,
-                 payload: str = "fp32"):
-        """launch_opts: the `ops.LaunchOpts` of the model whose backward runs beside the buckets (its `tiles_per_block` is what `_share_gpu`
-        switches: state of THAT model's launches, not of the process).  payload: "fp32" | "bf16" (see the module docstring)."""
-        assert payload in ("fp32", "bf16")
+                 payload: str = "fp32", share: str = "batch", reserved_cus: int = 16):
+        """launch_opts: the `ops.LaunchOpts` of the model whose backward runs beside the buckets (what `_share_gpu` switches is state of THAT
+        model's launches, not of the process).  payload: "fp32" | "bf16" (see the module docstring).
+        share: how the conv launches make room for the communication kernels while buckets are in flight --
+          "batch"  : `tiles_per_block = shared_tiles_per_block` -- small blocks that the hardware dispatcher re-balances (+11 % on a step beside a
+                     16-CU kernel, +1.5 % alone: profiles/r03_hog_step_probe.txt);
+          "reserve": `cus_reserved = reserved_cus` -- the persistent grids and their static schedules are sized for the other CUs, every block
+                     is resident at once and the launch costs the ideal #CUs / (#CUs - reserved) (profiles/r04_hog_step_probe.txt).  Set
+                     reserved_cus to the CUs the collective really holds (RCCL: its channel count, NCCL_MAX_NCHANNELS)."""
+        assert payload in ("fp32", "bf16") and share in ("batch", "reserve")
+        self.share, self.reserved_cus = share, reserved_cus
         self.flat, self.buckets, self.group = flat, buckets, group
         self.comm_stream = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None
         self.shared_tiles_per_block = shared_tiles_per_block
@@ -68,7 +75,10 @@ class BucketedAllReduce:
     def _share_gpu(self, on: bool) -> None:
         if self.comm_stream is None or on == self._sharing or self.launch_opts is None:
             return
-        self.launch_opts.tiles_per_block = self.shared_tiles_per_block if on else None  # a per-launch argument of the C-ABI (ps_conv_geom)
+        if self.share == "reserve":  # (both are per-launch arguments of the C-ABI: ps_conv_geom)
+            self.launch_opts.cus_reserved = self.reserved_cus if on else None
+        else:
+            self.launch_opts.tiles_per_block = self.shared_tiles_per_block if on else None
         self._sharing = on
 
     def begin_step(self) -> None:

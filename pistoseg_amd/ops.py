@@ -110,16 +110,21 @@ class LaunchOpts:
     gpu_shared: Optional[int] = None
     # weight gradients without atomics / top-k ties in index order (see DETERMINISTIC below); None = the module default = torch's switch
     deterministic: Optional[bool] = None
+    # CUs left to a co-running kernel that holds them (an RCCL collective): the persistent kernels' grid and static schedule are sized for
+    # the rest (ps_conv_geom.cus_reserved); set by dist.BucketedAllReduce(share="reserve") while buckets are in flight
+    cus_reserved: Optional[int] = None
 
 
 TILES_PER_BLOCK = 0  # module defaults (see LaunchOpts): read when a launch is ENQUEUED
 GPU_SHARED = 0
+CUS_RESERVED = 0
 
 
 def _geom(spec: ConvSpec, dtype: int, n: int, h: int, w: int, ldc_x: int, ldc_y: int, opts: Optional[LaunchOpts] = None) -> ConvGeom:
     tpb = TILES_PER_BLOCK if opts is None or opts.tiles_per_block is None else opts.tiles_per_block
     shared = GPU_SHARED if opts is None or opts.gpu_shared is None else opts.gpu_shared
-    return ConvGeom(dtype, n, h, w, spec.cin, spec.cout, spec.ksize, spec.stride, spec.dilation, ldc_x, ldc_y, int(tpb), int(shared))
+    reserved = CUS_RESERVED if opts is None or opts.cus_reserved is None else opts.cus_reserved
+    return ConvGeom(dtype, n, h, w, spec.cin, spec.cout, spec.ksize, spec.stride, spec.dilation, ldc_x, ldc_y, int(tpb), int(shared), int(reserved))
 
 
 def _conv_dt(t: Tensor, split: bool) -> int:

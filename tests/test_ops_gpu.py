@@ -825,12 +825,13 @@ def test_full_size_layers_kernel_families_agree(case, library):
     assert abs(a1 - a3) < 6 * s1 + 1e-4 * abs(a3), (a1, a3, s1)
 
 
-@pytest.mark.parametrize("tpb", [1, 2, 5])
+@pytest.mark.parametrize("tpb", [1, 2, 5, -16, -100, -4000])  # negative: ps_conv_geom.cus_reserved = -tpb instead
 @pytest.mark.selfcheck
 def test_persistent_kernels_batched_work_split_is_exact(tpb, library):
-    """ps_conv_geom.tiles_per_block = n: the persistent kernels' blocks are dispatched in batches and take n work items each (used while
-    an all-reduce shares the GPU).  Only the item -> block assignment changes: forward / data gradient are bit-identical to the
-    one-batch schedule, the weight gradient up to f32 atomic ordering."""
+    """ps_conv_geom.tiles_per_block = n: the persistent kernels' blocks are dispatched in batches and take n work items each;
+    ps_conv_geom.cus_reserved = r: their grid and static schedule are sized for #CUs - r compute units (both used while an all-reduce
+    shares the GPU; 4000 reserved: clamped to a quarter of the device).  Only the item -> block assignment changes: forward / data
+    gradient are bit-identical to the default schedule, the weight gradient up to f32 atomic ordering (its split-K plan follows the CU count)."""
     from pistoseg_amd import _lib, ops
 
     lib = _lib.load()
@@ -859,12 +860,12 @@ def test_persistent_kernels_batched_work_split_is_exact(tpb, library):
         assert conv_variant(spec, dtype, n, h, w, "fwd") in (V_HALO, V_WS2_224, V_WS2_256)
         assert conv_variant(spec, dtype, n, h, w, "wgrad") in (1, 2)
         try:
-            ops.TILES_PER_BLOCK = 0
+            ops.TILES_PER_BLOCK, ops.CUS_RESERVED = 0, 0
             ref = run()
-            ops.TILES_PER_BLOCK = tpb
+            ops.TILES_PER_BLOCK, ops.CUS_RESERVED = (tpb, 0) if tpb > 0 else (0, -tpb)
             got = run()
         finally:
-            ops.TILES_PER_BLOCK = 0
+            ops.TILES_PER_BLOCK, ops.CUS_RESERVED = 0, 0
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
         assert rel_err(got[2].cpu(), ref[2].cpu()) < 1e-5
 

@@ -15,21 +15,29 @@ x = torch.randn(64, 3, 224, 224, device=D); y = torch.randint(0, 4, (64, 224, 22
 hog_stream = torch.cuda.Stream()
 for _ in range(3): tr.train_step(x, y)
 torch.cuda.synchronize()
+def run(label):
+    best = 1e9
+    for _ in range(2):
+        torch.cuda.synchronize()
+        if hog:
+            with torch.cuda.stream(hog_stream):
+                _lib.check(lib.ps_debug_hog(hog, 400000, 96 * 1024, hog_stream.cuda_stream), "hog")  # 0.4 s, 96 KiB LDS each: those CUs are lost
+            torch.cuda._sleep(2000000)
+        t0 = time.perf_counter()
+        for _ in range(8): tr.train_step(x, y)
+        torch.cuda.current_stream().synchronize()
+        tr.wgrad_stream.synchronize()
+        best = min(best, (time.perf_counter() - t0) / 8)
+        torch.cuda.synchronize()
+    print(f"hog={hog:2d} CUs {label}: {best*1e3:6.2f} ms/step  {64/best:6.0f} tiles/s", flush=True)
+
+
 for hog in (0, 16, 32):
-    for tpb in (0, 2, 1):
+    for tpb in (0, 2, 1):  # static persistent schedule | small batches of tiles that the dispatcher re-balances
         ops.TILES_PER_BLOCK = tpb
-        best = 1e9
-        for _ in range(2):
-            torch.cuda.synchronize()
-            if hog:
-                with torch.cuda.stream(hog_stream):
-                    _lib.check(lib.ps_debug_hog(hog, 400000, 96 * 1024, hog_stream.cuda_stream), "hog")  # 0.4 s, 96 KiB LDS each: those CUs are lost
-                torch.cuda._sleep(2000000)
-            t0 = time.perf_counter()
-            for _ in range(8): tr.train_step(x, y)
-            torch.cuda.current_stream().synchronize()
-            tr.wgrad_stream.synchronize()
-            best = min(best, (time.perf_counter() - t0) / 8)
-            torch.cuda.synchronize()
-        print(f"hog={hog:2d} CUs tpb={tpb}: {best*1e3:6.2f} ms/step  {64/best:6.0f} tiles/s", flush=True)
-ops.TILES_PER_BLOCK = 0
+        run(f"tiles_per_block={tpb}")
+    ops.TILES_PER_BLOCK = 0
+    for res in (16, 32):   # grid and static schedule sized for #CUs - reserved (ps_conv_geom.cus_reserved)
+        ops.CUS_RESERVED = res
+        run(f"cus_reserved={res}  ")
+    ops.CUS_RESERVED = 0
