@@ -50,11 +50,14 @@ def _geom_unshared(*a):  # A/B of the gpu_shared launch option: the pseudo-switc
 def apply(v):
     lib.ps_debug_reset()  # every tunable back to the library default (one list, in the library)
     ops._geom = _geom
+    if hasattr(model, "heads_f32"): model.heads_f32 = False
     if v != "base":
         for kv in v.split(","):
             k, val = kv.split("=")
             if k == "gpu_shared":
                 ops._geom = _geom if int(val) else _geom_unshared
+            elif k == "heads_f32":  # --rfm: the RFM heads in f32 (1) or in the backbone's 16-bit type (0)
+                model.heads_f32 = bool(int(val))
             else:
                 getattr(lib, "ps_debug_set_" + k)(int(val))
 for _ in range(5): one()
