@@ -49,3 +49,13 @@ def test_bench_infer4_workload_runs():
     d = run_bench("--workload", "infer4", "--batch", "2", "--tile", "64", "--steps", "2", "--warmup", "1")
     assert d["value"] > 0 and "infer_revise_masks.py" in d["config"]["workload"] and d["config"]["tiles_per_gpu"] == 4
     assert d["roofline_tail"]["bound"] == "hbm" and d["roofline_tail"]["achieved"] > 0
+
+
+@pytest.mark.parametrize("precision", ["fp16x3", "bf16x3"])
+def test_bench_split_precisions_and_bcss_variant(precision):
+    """`bench.py --precision fp16x3|bf16x3` (the split paths that carry the 1e-4 tolerance) prices its roofline against a third of the 16-bit MFMA
+    peak; `--classes 4` selects the reference's BCSS CE (no ignore index, targets 0..3: models/segmentation_module.py:63-66)."""
+    d = run_bench("--batch", "2", "--tile", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-power", "--precision", precision, "--classes", "4")
+    assert d["dtype"] == precision and d["value"] > 0
+    assert abs(d["roofline"]["peak"] - 2500.0 / 3) < 0.1 and d["roofline"]["kernel"].endswith(f"<{precision}>") or "wgrad" in d["roofline"]["kernel"]
+    assert "ignore_index=None" in d["config"]["workload"] and "targets 0..3" in d["config"]["workload"]

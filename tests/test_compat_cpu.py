@@ -213,6 +213,14 @@ def test_launch_options_are_per_model_state_and_reach_the_geometry(monkeypatch):
     assert net.launch.tiles_per_block == 2 and other.launch.tiles_per_block is None and ops.TILES_PER_BLOCK == 0
     red._share_gpu(False)
     assert net.launch.tiles_per_block is None
+    # ... or, share="reserve", its cus_reserved: grids sized for the CUs the collective leaves
+    red = BucketedAllReduce(torch.zeros(8), [("b7", 0, 8)], None, launch_opts=net.launch, share="reserve", reserved_cus=32)
+    red.comm_stream = object()
+    red._share_gpu(True)
+    assert net.launch.cus_reserved == 32 and net.launch.tiles_per_block is None and other.launch.cus_reserved is None
+    assert ops._geom(spec, 1, 2, 28, 28, 512, 512, net.launch).cus_reserved == 32 and ops._geom(spec, 1, 2, 28, 28, 512, 512, other.launch).cus_reserved == 0
+    red._share_gpu(False)
+    assert net.launch.cus_reserved is None
 
 
 def test_gpu_suite_order_puts_parity_before_selfchecks_before_control_flow():
