@@ -205,7 +205,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 1) void conv_wgrad_kernel(
       const int q4 = l16 >> 2, p4 = l16 & 3;
 #pragma unroll
       for (int kk = 0; kk < KP / 32; ++kk) {
-        bf16x8 af[MI], bf[NI];
+        u32x4 af[MI], bf[NI];  // raw dwords, typed at the MFMA only (see conv_wgrad_ws2_kernel: typed assembly costs the F16 instantiation v_bfi re-packing)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int R = kk * 32 + 8 * g + 4 * h + q4;
@@ -214,18 +214,18 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 1) void conv_wgrad_kernel(
             const int c0 = wr * (BCO / 2) + i * 16;  // channel base inside the tile
             const int chunk = (c0 >> 3) + (p4 >> 1);
             const unsigned char* ad = sg + R * RBG + ((chunk ^ row_swz<ES, RBG>(R)) << 4) + (p4 & 1) * 8;
-            const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ad));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) af[i][4 * h + e] = t[e];
+            const u32x2 t = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ad)));
+            af[i][2 * h] = t[0];
+            af[i][2 * h + 1] = t[1];
           }
 #pragma unroll
           for (int j = 0; j < NI; ++j) {
             const int c0 = wc * (BCI / 2) + j * 16;
             const int chunk = (c0 >> 3) + (p4 >> 1);
             const unsigned char* ad = sx + R * RBX + ((chunk ^ row_swz<ES, RBX>(R)) << 4) + (p4 & 1) * 8;
-            const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ad));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bf[j][4 * h + e] = t[e];
+            const u32x2 t = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ad)));
+            bf[j][2 * h] = t[0];
+            bf[j][2 * h + 1] = t[1];
           }
         }
 #pragma unroll
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 1) void conv_wgrad_kernel(
             if constexpr (Tr::F16)
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[i]), __builtin_bit_cast(f16x8, bf[j]), acc[i][j], 0, 0, 0);
             else
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
           }
       }
     } else {
@@ -524,17 +524,20 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
   const int a_base = (8 * g + q4) * RBG + (p4 & 1) * 8 + (((wr * 16) + (p4 >> 1)) << 4);
   const int b_base = G_BYTES + (8 * g + q4) * RBX + (p4 & 1) * 8 + ((((wc ^ (s3 >> 2)) << 3) + (p4 >> 1)) << 4);
 
-  auto mfma1 = [&](f32x4& c, const bf16x8& x, const bf16x8& y) {
+  // Fragments live in registers as raw dwords (u32x4 = eight 16-bit K values), typed only at the MFMA: assembled element by element as bf16
+  // vectors and re-typed for the fp16 MFMA, hipcc re-packed every transposed read with v_bfi_b32 and waited for it right behind the read
+  // (48 extra VALU + 33 extra s_waitcnt per K-step in the F16 instantiation: its weight gradients ran 18-30 % behind the bf16 ones)
+  auto mfma1 = [&](f32x4& c, const u32x4& x, const u32x4& y) {
     if constexpr (F16) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
-    else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
+    else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), c, 0, 0, 0);
   };
   // One K-half (32 pixels): the 2 x (MI + NI) = 24 transposed reads of (stage st, K-half kk) into (afn, bfn), INTERLEAVED with the
   // MI x NI = 32 MFMAs on (afo, bfo), whose operands are already in registers: 3 reads, 4 MFMAs, 3 reads, 4 MFMAs, ...  A burst of
   // 24 LDS instructions in front of the MFMAs (the first version) left the matrix pipe idle for their issue time twice per
   // K-step -- this wave is its SIMD's only MFMA source: the consumers alone (loads ablated) ran at 1200-1360 TFLOP/s.  The order
   // is pinned with scheduling barriers (hipcc otherwise hoists every read to the top).
-  auto half = [&](auto do_mma, const unsigned char* st, int kk, bf16x8 (&afn)[MI], bf16x8 (&bfn)[NI], const bf16x8 (&afo)[MI],
-                  const bf16x8 (&bfo)[NI], f32x4 (&acc)[MI][NI]) {  // do_mma: std::true_type / std::false_type (an item's first half step)
+  auto half = [&](auto do_mma, const unsigned char* st, int kk, u32x4 (&afn)[MI], u32x4 (&bfn)[NI], const u32x4 (&afo)[MI],
+                  const u32x4 (&bfo)[NI], f32x4 (&acc)[MI][NI]) {  // do_mma: std::true_type / std::false_type (an item's first half step)
     int z;
     asm volatile("s_mov_b32 %0, 0" : "=s"(z));  // opaque zero: keeps the address arithmetic inside the loop (see above)
     const int sd = s3 + z;
@@ -542,14 +545,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
     auto read1 = [&](int r) {  // r: 0..15 = A fragment r >> 1, half r & 1; 16..23 = B fragment (r - 16) >> 1, half (r - 16) & 1
       if (r < 2 * MI) {
         const int i = r >> 1, h = r & 1, roff = kk * 32 + 4 * h;
-        const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(st + a_base + roff * RBG + ((i ^ sd) << 5)));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) afn[i][4 * h + e] = t[e];
+        const u32x2 t = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(st + a_base + roff * RBG + ((i ^ sd) << 5))));
+        afn[i][2 * h] = t[0];
+        afn[i][2 * h + 1] = t[1];
       } else {
         const int j = (r - 2 * MI) >> 1, h = r & 1, roff = kk * 32 + 4 * h;
-        const bf16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(st + b_base + roff * RBX + ((j ^ (sd & 3)) << 5)));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bfn[j][4 * h + e] = t[e];
+        const u32x2 t = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(st + b_base + roff * RBX + ((j ^ (sd & 3)) << 5))));
+        bfn[j][2 * h] = t[0];
+        bfn[j][2 * h + 1] = t[1];
       }
     };
 #pragma unroll
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
     }
     static_assert(NR == 24 && NM == 32, "interleave pattern");
   };
-  auto mma = [&](f32x4 (&acc)[MI][NI], const bf16x8 (&af)[MI], const bf16x8 (&bf)[NI]) {
+  auto mma = [&](f32x4 (&acc)[MI][NI], const u32x4 (&af)[MI], const u32x4 (&bf)[NI]) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -583,7 +586,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 af0[MI], bf0[NI], af1[MI], bf1[NI];
+    u32x4 af0[MI], bf0[NI], af1[MI], bf1[NI];
     {  // first K-step of the item (ks1 > ks0 always): nothing to overlap its first reads with
       const unsigned char* st = smem + cur * STAGE;
       half(std::false_type{}, st, 0, af0, bf0, af1, bf1, acc);

@@ -26,10 +26,13 @@ python tools/step_profile.py > gpurun_out/${tag}_step_profile_per_launch.txt 2>&
 # --- the PARITY path: fp32 storage, exact-f32 MFMA (157 TFLOP/s matrix peak)
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_fp32 -- python bench.py --precision fp32 --steps 3 --warmup 1 --no-cpu-baseline --no-overlap --no-power > gpurun_out/${tag}_bench_fp32_parity_path.json 2>> gpurun_out/${tag}_bench_profiled.err &&
 cp $(find gpurun_out/prof_${tag}_fp32 -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_bench_fp32_parity_path_kernel_stats.csv &&
-# --- the split-bf16 path (1e-4 logits at a third of the bf16 rate): bench line + kernel trace
+# --- the split paths (1e-4 logits at a third of the 16-bit rate): bench lines + kernel traces
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_x3 -- python bench.py --precision bf16x3 --steps 3 --warmup 1 --no-cpu-baseline --no-overlap --no-power > gpurun_out/${tag}_bench_bf16x3.json 2>> gpurun_out/${tag}_bench_profiled.err &&
 cp $(find gpurun_out/prof_${tag}_x3 -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_bench_bf16x3_kernel_stats.csv &&
 python bench.py --precision bf16x3 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_bench_bf16x3_unprofiled.json 2>> gpurun_out/${tag}_bench_profiled.err &&
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_hx3 -- python bench.py --precision fp16x3 --steps 3 --warmup 1 --no-cpu-baseline --no-overlap --no-power > gpurun_out/${tag}_bench_fp16x3.json 2>> gpurun_out/${tag}_bench_profiled.err &&
+cp $(find gpurun_out/prof_${tag}_hx3 -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_bench_fp16x3_kernel_stats.csv &&
+python bench.py --precision fp16x3 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_bench_fp16x3_unprofiled.json 2>> gpurun_out/${tag}_bench_profiled.err &&
 # --- BASELINE configs[4]: BCSS 4-class, fp16 MFMA path, bs=128 -- bench line + HBM / MFMA counters
 CFG5="--precision fp16 --classes 4 --batch 128"
 python bench.py $CFG5 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_cfg5_fp16_bs128.json 2>> gpurun_out/${tag}_bench_profiled.err &&
