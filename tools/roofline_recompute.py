@@ -11,6 +11,7 @@ MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md).  The line's own `roofline` (
 beside it with the lease's board power / shader clock."""
 import csv
 import json
+import re
 import sys
 
 stats_csv, prof_json, live_json = sys.argv[1:4]
@@ -24,8 +25,9 @@ dt = prof["dtype"]
 peak = {"bf16": 2500.0, "fp16": 2500.0, "bf16x3": 2500.0 / 3, "fp16x3": 2500.0 / 3, "fp32": 157.3}[dt]
 tag = {"bf16": "TraitsBF16,", "fp16": "TraitsF16,", "bf16x3": "TraitsBF16X3,", "fp16x3": "TraitsF16X3,", "fp32": "TraitsF32,"}[dt]
 rows = [r for r in csv.DictReader(open(stats_csv)) if "conv_igemm_halo_kernel" in r["Name"] and tag in r["Name"]]
-main = [r for r in rows if r["Name"].split("IgemmArgs")[0].rstrip("( ").endswith(", 4>")]
-tail = [r for r in rows if r["Name"].split("IgemmArgs")[0].rstrip("( ").endswith(", 2>")]
+wi = lambda r: re.search(r", (\d)>\(", r["Name"]).group(1)  # last template argument: cout fragments per wave (4 = main dispatch, 2 = tail half tiles)
+main = [r for r in rows if wi(r) == "4"]
+tail = [r for r in rows if wi(r) == "2"]
 ns = lambda rs: sum(float(r["TotalDurationNs"]) for r in rs)
 calls = lambda rs: sum(int(r["Calls"]) for r in rs)
 # GFLOP of the halo launches per step, from the line itself (flops_per_launch_avg x launches_per_step of the instrumented TRAINING step)
@@ -35,7 +37,6 @@ scale = batch / 64.0 * (prof["config"]["tile"] / 224.0) ** 2
 halo_train_gf, halo_infer_gf = 18703.5 * scale, 9943.5 * scale
 total_gf = n_train * halo_train_gf + n_infer * halo_infer_gf
 total_ns = ns(main) + ns(tail)
-ach = total_gf / total_ns * 1e3  # GFLOP / ns = EFLOP/s -> x 1e3 = TFLOP/s ... (GF/ns = 1e9/1e-9 = 1e18) -> TFLOP/s = x 1e6; see below
 ach = total_gf * 1e9 / (total_ns * 1e-9) / 1e12
 print(f"# roofline recomputation from one lease (build {head}; dtype {dt}, batch {batch}, tile {prof['config']['tile']})")
 print(f"profiled run      : bench.py --steps {K} --warmup {W} --no-overlap  ->  {n_train} training steps + {n_infer} inference passes in the trace")
