@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PS_VERSION 221 /* major*10000 + minor*100 + patch */
+#define PS_VERSION 222 /* major*10000 + minor*100 + patch */
 
 typedef enum ps_status {
   PS_OK = 0,
@@ -367,6 +367,13 @@ int ps_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, in
  * shadow_dtype in {PS_BF16, PS_F16} (p_shadow may be NULL). */
 int ps_adamw_step_scaled(float* p, const float* g, float* m, float* v, void* p_shadow, int32_t shadow_dtype, int64_t n, float lr,
                          float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_inv_scale, void* stream);
+/* The same update with the overflow check of dynamic loss scaling ON THE DEVICE (no host round trip per step): state[0] = optimiser steps applied so
+ * far, state[1] = non-finite elements of this step's gradient (written by ps_nonfinite_count into &state[1]; zero it first).  When state[1] != 0 the
+ * launch leaves p / m / v / shadow untouched; otherwise it applies AdamW with bias corrections from t = state[0] + 1 and then advances state[0].
+ * replaces: torch.cuda.amp.GradScaler.step's `if not found_inf: optimizer.step()` around AdamW.step (Lightning's fp16 precision plugin,
+ * models/segmentation_module.py:86-90). */
+int ps_adamw_step_guarded(float* p, const float* g, float* m, float* v, void* p_shadow, int32_t shadow_dtype, int64_t n, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, int32_t* state, float grad_inv_scale, void* stream);
 /* torch.optim.SGD with momentum (dampening 0, no nesterov) and L2 weight decay:
  *   g' = g + wd*p;  buf = first ? g' : mom*buf + g';  p -= lr*buf */
 int ps_sgd_step(float* p, const float* g, float* buf, void* p_bf16, int64_t n, float lr, float momentum,

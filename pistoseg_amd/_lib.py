@@ -112,6 +112,7 @@ PROTOTYPES = {
     "ps_adamw_step": (C.c_int, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
     "ps_sgd_step": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _I, _P]),
     "ps_adamw_step_scaled": (C.c_int, [_P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
+    "ps_adamw_step_guarded": (C.c_int, [_P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _F, _P, _F, _P]),
     "ps_sgd_step_scaled": (C.c_int, [_P, _P, _P, _P, _I, _L, _F, _F, _F, _I, _F, _P]),
     "ps_softmax_scatter_accum": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _P]),
     "ps_canvas_resize_accum": (C.c_int, [_P, _P, _D, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

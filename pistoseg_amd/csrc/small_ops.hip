@@ -568,10 +568,20 @@ __global__ __launch_bounds__(256) void cast_f32_lowp_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------------
 // optimisers over a flat arena
 // ------------------------------------------------------------------------------------------------
+// state (guarded form, ps_adamw_step_guarded): state[0] = optimiser steps applied so far, state[1] = non-finite gradient elements of THIS
+// step (ps_nonfinite_count).  The launch does nothing when state[1] != 0 -- the overflow check of dynamic loss scaling without a host round
+// trip -- and otherwise takes its bias corrections from t = state[0] + 1 (a skipped step must not advance Adam's step count).
 template <typename SH>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, SH* __restrict__ pb, long long n, float lr,
-                                                    float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float ginv) {
+                                                    float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, float ginv,
+                                                    const int* __restrict__ state) {
+  if (state) {
+    if (state[1] != 0) return;
+    const float t = (float)(state[0] + 1);
+    bc1 = 1.f - powf(b1, t);
+    bc2_sqrt = sqrtf(1.f - powf(b2, t));
+  }
   const long long stride = (long long)gridDim.x * 256 * 4;
   const float step_size = lr / bc1, decay = 1.f - lr * wd;
   auto upd = [&](float& pk, float gk, float& mk, float& vk) {
@@ -899,11 +909,37 @@ extern "C" int ps_adamw_step_scaled(float* p, const float* g, float* m, float* v
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (p_shadow && shadow_dtype == PS_F16)
     hipLaunchKernelGGL(adamw_kernel<_Float16>, dim3(grid_for(n, 256 * 4, 1 << 30)), dim3(256), 0, s, p, g, m, v, (_Float16*)p_shadow, (long long)n, lr,
-                       beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_inv_scale);
+                       beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_inv_scale, (const int*)nullptr);
   else
     hipLaunchKernelGGL(adamw_kernel<__bf16>, dim3(grid_for(n, 256 * 4, 1 << 30)), dim3(256), 0, s, p, g, m, v, (__bf16*)p_shadow, (long long)n, lr,
-                       beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_inv_scale);
+                       beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_inv_scale, (const int*)nullptr);
   PS_CHECK_LAUNCH("adamw_step");
+  return PS_OK;
+}
+
+namespace {
+__global__ void adamw_state_advance_kernel(int* state) {
+  if (state[1] == 0) state[0] += 1;
+}
+}  // namespace
+
+extern "C" int ps_adamw_step_guarded(float* p, const float* g, float* m, float* v, void* p_shadow, int32_t shadow_dtype, int64_t n,
+                                     float lr, float beta1, float beta2, float eps, float weight_decay, int32_t* state,
+                                     float grad_inv_scale, void* stream) {
+  PS_REQUIRE(p && g && m && v && state && n >= 0, "adamw_step_guarded: bad argument");
+  PS_REQUIRE(!p_shadow || shadow_dtype == PS_BF16 || shadow_dtype == PS_F16, "adamw_step_guarded: shadow dtype %d unsupported", shadow_dtype);
+  if (n == 0) return PS_OK;
+  PS_REQUIRE(ps_aligned16(p) && ps_aligned16(g) && ps_aligned16(m) && ps_aligned16(v) && (!p_shadow || (reinterpret_cast<uintptr_t>(p_shadow) & 7u) == 0),
+             "adamw_step_guarded: arenas must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (p_shadow && shadow_dtype == PS_F16)
+    hipLaunchKernelGGL(adamw_kernel<_Float16>, dim3(grid_for(n, 256 * 4, 1 << 30)), dim3(256), 0, s, p, g, m, v, (_Float16*)p_shadow, (long long)n, lr,
+                       beta1, beta2, eps, weight_decay, 1.f, 1.f, grad_inv_scale, (const int*)state);
+  else
+    hipLaunchKernelGGL(adamw_kernel<__bf16>, dim3(grid_for(n, 256 * 4, 1 << 30)), dim3(256), 0, s, p, g, m, v, (__bf16*)p_shadow, (long long)n, lr,
+                       beta1, beta2, eps, weight_decay, 1.f, 1.f, grad_inv_scale, (const int*)state);
+  hipLaunchKernelGGL(adamw_state_advance_kernel, dim3(1), dim3(1), 0, s, state);  // behind the update: every block of it read the old count
+  PS_CHECK_LAUNCH("adamw_step_guarded");
   return PS_OK;
 }
 

@@ -527,6 +527,21 @@ def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, p_shadow: Optional[Te
     )
 
 
+def adamw_step_guarded(p: Tensor, g: Tensor, m: Tensor, v: Tensor, p_shadow: Optional[Tensor], lr: float, betas, eps: float, weight_decay: float,
+                       state: Tensor, grad_inv_scale: float = 1.0) -> None:
+    """AdamW with the dynamic-loss-scale overflow check on the device (ps_adamw_step_guarded): state = int32[2] = (steps applied so far, non-finite
+    elements of this step's gradient); a step whose gradient overflowed changes nothing, an applied one advances state[0]."""
+    _require_gpu(p, g, m, v, state)
+    assert state.dtype == torch.int32 and state.numel() == 2 and state.is_contiguous()
+    lib = _lib.load()
+    sdt = PS_BF16 if p_shadow is None else _dt(p_shadow)
+    _lib.check(
+        lib.ps_adamw_step_guarded(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(p_shadow), sdt, p.numel(), lr, betas[0], betas[1], eps,
+                                  weight_decay, state.data_ptr(), float(grad_inv_scale), _stream()),
+        "ps_adamw_step_guarded",
+    )
+
+
 def dropout2d_masks(segments, n: int, device, seed: int, offset: int):
     """segments: [(name, channels, p)] -> {name: [n, channels] f32 multipliers (0 or 1/(1-p))}, all drawn by ONE launch into one flat
     buffer (Philox4x32-10 keyed by (seed, offset); nn.Dropout2d's Bernoulli draw, resnet38d.py:63,67,85,90, revise_net.py:11,50)."""
@@ -548,11 +563,13 @@ def dropout2d_masks(segments, n: int, device, seed: int, offset: int):
     return out
 
 
-def nonfinite_count(g: Tensor) -> Tensor:
-    """1-element int32 device tensor: number of inf/nan entries of the f32 tensor g."""
+def nonfinite_count(g: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """1-element int32 device tensor: number of inf/nan entries of the f32 tensor g (out: a zeroed 1-element int32 view to count into)."""
     _require_gpu(g)
     assert g.dtype == torch.float32 and g.is_contiguous()
-    out = torch.zeros(1, device=g.device, dtype=torch.int32)
+    if out is None:
+        out = torch.zeros(1, device=g.device, dtype=torch.int32)
+    assert out.dtype == torch.int32 and out.numel() == 1
     lib = _lib.load()
     _lib.check(lib.ps_nonfinite_count(g.data_ptr(), g.numel(), out.data_ptr(), _stream()), "ps_nonfinite_count")
     return out

@@ -125,6 +125,12 @@ class SegTrainer(_ArenaMixin):
         self.dynamic_scale = model.precision in ("fp16", "fp16x3") and loss_scale is None
         self.loss_scale = float(loss_scale) if loss_scale is not None else (65536.0 if model.precision in ("fp16", "fp16x3") else 1.0)
         self.clean_steps, self.skipped_steps = 0, 0
+        # Dynamic loss scaling without a host round trip per step: the overflow check gates the optimiser ON THE DEVICE (ps_adamw_step_guarded:
+        # opt_state = [steps applied, non-finite elements of this step]); the host learns each step's flag through an asynchronous 4-byte copy and
+        # adapts the scale `scale_lag` steps later (`settle()` brings the bookkeeping up to date; it is exact once called).
+        self.opt_state = torch.zeros(2, device=dev, dtype=torch.int32)
+        self.scale_lag = 2
+        self._pending_flags = []  # (event, pinned flag, loss scale the step ran with), oldest first
         self.grads: Dict[str, Tensor] = {}
         self.offsets: Dict[str, Tuple[int, int]] = {}
         off = 0
@@ -171,20 +177,43 @@ class SegTrainer(_ArenaMixin):
         if self.reducer is not None:
             self.reducer.finish()
         if self.dynamic_scale:
-            # one 4-byte D2H per step (the all-reduce already summed the arenas, so every rank sees the same count)
-            if int(ops.nonfinite_count(self.g_flat).item()) > 0:
-                self.loss_scale = max(self.loss_scale * 0.5, 1.0)
-                self.clean_steps = 0
-                self.skipped_steps += 1
-                return loss
-            self.clean_steps += 1
+            # (the all-reduce already summed the arenas, so every rank sees the same count and takes the same decisions)
+            flag = self.opt_state[1:]
+            flag.zero_()
+            ops.nonfinite_count(self.g_flat, out=flag)
+            ops.adamw_step_guarded(self.p_flat, self.g_flat, self.m_flat, self.v_flat, self.pb_flat, self.lr, self.betas, self.eps,
+                                   self.weight_decay, self.opt_state, grad_inv_scale=1.0 / self.loss_scale)
+            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host.copy_(flag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending_flags.append((ev, host, self.loss_scale))
+            model.invalidate_weight_cache()
+            self.settle(keep=self.scale_lag)
+            return loss
         self.step_count += 1
         ops.adamw_step(self.p_flat, self.g_flat, self.m_flat, self.v_flat, self.pb_flat, self.lr, self.betas, self.eps,
                        self.weight_decay, self.step_count, grad_inv_scale=1.0 / self.loss_scale)
         model.invalidate_weight_cache()
-        if self.dynamic_scale and self.clean_steps >= 200:
-            self.loss_scale, self.clean_steps = min(self.loss_scale * 2.0, 2.0 ** 24), 0
         return loss
+
+    def settle(self, keep: int = 0) -> None:
+        """Bring the dynamic-loss-scale bookkeeping (`loss_scale`, `skipped_steps`, `step_count`, `clean_steps`) up to date with all but the
+        newest `keep` steps: waits for their overflow flags (torch.cuda.amp.GradScaler's policy: x 0.5 and skip on overflow, x 2 every 200 clean
+        steps).  A flag only ever lowers the scale below the scale ITS step ran with, so two overflowing steps enqueued with the same scale
+        halve it once."""
+        while len(self._pending_flags) > keep:
+            ev, host, used = self._pending_flags.pop(0)
+            ev.synchronize()
+            if int(host[0]) > 0:
+                self.loss_scale = max(min(self.loss_scale, used * 0.5), 1.0)
+                self.clean_steps = 0
+                self.skipped_steps += 1
+            else:
+                self.step_count += 1
+                self.clean_steps += 1
+                if self.clean_steps >= 200:
+                    self.loss_scale, self.clean_steps = min(self.loss_scale * 2.0, 2.0 ** 24), 0
 
     def lr_scheduler_step(self, gamma: float = 0.9) -> None:
         """ExponentialLR(gamma=0.9) once per epoch (segmentation_module.py:88)."""

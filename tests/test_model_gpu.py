@@ -184,7 +184,8 @@ def test_seg_trainer_fp16_loss_scaling_tracks_fp32():
         out[prec] = (losses, tr, model)
     l32, l16 = out["fp32"][0], out["fp16"][0]
     tr16, m16 = out["fp16"][1], out["fp16"][2]
-    assert tr16.skipped_steps == 0 and tr16.loss_scale == 65536.0
+    tr16.settle()  # the overflow flags reach the host asynchronously (device-guarded optimiser): settle() waits for the outstanding ones
+    assert tr16.skipped_steps == 0 and tr16.loss_scale == 65536.0 and tr16.step_count == 3 and tr16.opt_state.tolist() == [3, 0]
     # step 1 sees identical weights: fp16 storage error only.  Later steps compare two Adam trajectories (every weight moves by
     # ~lr * sign(g) per step, so elements whose gradient sits at the rounding floor diverge): loose bound.
     assert abs(l32[0] - l16[0]) < 2e-3 * abs(l32[0]), (l32, l16)
@@ -196,8 +197,17 @@ def test_seg_trainer_fp16_loss_scaling_tracks_fp32():
     tr16.loss_scale = 2.0 ** 40
     before = tr16.p_flat.clone()
     m16.sample_dropout = lambda n_, dev_: drops[0]
+    shadow_before, m_before = tr16.pb_flat.clone(), tr16.m_flat.clone()
     tr16.train_step(x.to(D), target.to(D))
-    assert tr16.skipped_steps == 1 and tr16.loss_scale == 2.0 ** 39 and torch.equal(before, tr16.p_flat)
+    tr16.train_step(x.to(D), target.to(D))  # enqueued before the host knows about the first overflow: same scale, skipped on the device as well
+    tr16.settle()
+    # both steps were skipped ON THE DEVICE (weights, moments, shadow and Adam's step count untouched); the scale is halved ONCE per scale that overflowed
+    assert tr16.skipped_steps == 2 and tr16.loss_scale == 2.0 ** 39 and tr16.step_count == 3 and tr16.opt_state[0].item() == 3
+    assert torch.equal(before, tr16.p_flat) and torch.equal(shadow_before, tr16.pb_flat) and torch.equal(m_before, tr16.m_flat)
+    tr16.loss_scale = 65536.0
+    tr16.train_step(x.to(D), target.to(D))
+    tr16.settle()
+    assert tr16.step_count == 4 and tr16.opt_state.tolist() == [4, 0] and not torch.equal(before, tr16.p_flat)
 
 
 def relu_pattern_flips(saved, collect, model=None):

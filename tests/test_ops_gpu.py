@@ -432,6 +432,29 @@ def test_scaled_optimizers_fp16_shadow_and_nonfinite():
     assert int(ops.nonfinite_count(t.to(D))) == 0
     t[5], t[n - 1], t[4097] = float("inf"), float("nan"), float("-inf")
     assert int(ops.nonfinite_count(t.to(D))) == 3
+    # the device-guarded AdamW (ps_adamw_step_guarded): equal to torch's AdamW over the APPLIED steps -- bias corrections from its own step
+    # count --, and a step whose gradient overflowed changes nothing (GradScaler.step's `if not found_inf`)
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pt], lr=1e-3, weight_decay=0.05)
+    pg, mg, vg = p0.clone().to(D), torch.zeros(n, device=D), torch.zeros(n, device=D)
+    shg = torch.empty(n, device=D, dtype=torch.float16)
+    state = torch.zeros(2, device=D, dtype=torch.int32)
+    for step in range(5):
+        gr2 = torch.randn(n, generator=g)
+        overflow = step in (1, 3)
+        gdev = (gr2 * scale).to(D)
+        if overflow:
+            gdev[17] = float("inf")
+        else:
+            pt.grad = gr2.clone()
+            opt.step()
+        before = (pg.clone(), mg.clone(), vg.clone(), shg.clone())
+        state[1:].zero_()
+        ops.nonfinite_count(gdev, out=state[1:])
+        ops.adamw_step_guarded(pg, gdev, mg, vg, shg, 1e-3, (0.9, 0.999), 1e-8, 0.05, state, grad_inv_scale=1.0 / scale)
+        if overflow:
+            assert all(torch.equal(a, b) for a, b in zip(before, (pg, mg, vg, shg))) and state.tolist()[1] == 1
+    assert state.tolist()[0] == 3 and rel_err(pg.cpu(), pt.detach()) < 1e-6 and torch.equal(shg.cpu(), pg.cpu().half())
 
 
 @pytest.mark.selfcheck

@@ -23,6 +23,7 @@ for prec in ("bf16", "fp16"):
         assert all(l == l and l < 1e4 for l in losses), losses
         finals.append(tr.p_flat.clone())
         if run == 0:
+            if hasattr(tr, "settle"): tr.settle()
             print(f"[{prec}] loss: " + " ".join(f"{l:.3f}" for l in losses[::max(1, steps // 12)]) + f" -> {losses[-1]:.3f}; skipped steps {tr.skipped_steps}, loss scale {tr.loss_scale}", flush=True)
             assert losses[-1] < 0.8 * losses[0], "the fixed batch is not being fitted"
     d = (finals[0] - finals[1]).abs()
