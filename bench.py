@@ -369,10 +369,15 @@ def rfm_bench(args, world, rank, dev, dist_on):
     lab = (torch.rand(n, c - 1, generator=g) < 0.5).float()
     lab[torch.arange(n), torch.randint(0, c - 1, (n,), generator=g)] = 1.0
     label = torch.cat([torch.ones(n, 1), lab], 1).to(dev)
-    step = lambda: tr.train_step(x, pmask, pcam, label)
+    last = [None]
+
+    def step():
+        last[0] = tr.train_step(x, pmask, pcam, label)
+
     for _ in range(args.warmup):
         step()
     dt = timed(step, args.steps, dist_on)
+    final_losses = [float(v) for v in last[0]]  # (loss, loss_cls, loss_rfm, loss_ecr) of the last timed step: must be finite
 
     def serial_step():  # weight gradients on the launch stream (exclusive per-kernel times), launch schedule of the timed two-stream step (gpu_shared)
         ws, tr.wgrad_stream = tr.wgrad_stream, None
@@ -401,6 +406,7 @@ def rfm_bench(args, world, rank, dev, dist_on):
             "config": {"workload": f"BASELINE configs[3]: revise_pseudo_labels.py train_epoch step, RFM net C={c}, cls+rfm+ecr losses, PolyOptimizer",
                        "per_gpu_batch": n, "global_batch": n * world, "tile": args.tile, "parallelism": f"dp{world}"},
             "train_conv_tflops_per_gpu": round(value / world * GFLOP_TRAIN_PER_TILE * (args.tile / 224.0) ** 2 / 1e3, 1),
+            "final_loss": final_losses[0], "final_losses": dict(zip(("loss", "loss_cls", "loss_rfm", "loss_ecr"), final_losses)),
             "roofline": roof}
         if cpu is not None:
             out["cpu_baseline"] = cpu
@@ -618,15 +624,21 @@ def main():
     init_weights_he(model, seed=42)
     model = model.to(dev)
     ignore_index, target_hi = ce_variant(args)
-    trainer = SegTrainer(model, lr=1e-3, weight_decay=0.05, ignore_index=ignore_index,
+    # lr: the synthetic net (He-initialised, frozen random BatchNorm statistics, no pretrained weights) diverges under AdamW steps of 1e-3 -- in fp16
+    # the activations leave the format's range after the first update and every later step runs on NaNs (found in round 4: the configs[4] line had been
+    # timed on non-finite data).  2e-4 (the reference's default is 5e-4, segmentation_train.py:63) keeps the loss finite and falling; the step's
+    # work does not depend on it, and the line reports `final_loss` so that a non-finite run cannot pass unnoticed.
+    trainer = SegTrainer(model, lr=2e-4, weight_decay=0.05, ignore_index=ignore_index,
                          process_group=torch.distributed.group.WORLD if dist_on else None, overlap_wgrad=not args.no_overlap,
                          deterministic=args.deterministic)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     x = torch.randn(args.batch, 3, args.tile, args.tile, generator=g).to(dev)
     y = torch.randint(0, target_hi, (args.batch, args.tile, args.tile), generator=g).to(dev)
 
+    last_loss = [None]
+
     def train_step():
-        trainer.train_step(x, y)
+        last_loss[0] = trainer.train_step(x, y)
 
     for _ in range(args.warmup):
         train_step()
@@ -645,6 +657,11 @@ def main():
                    "deterministic": bool(args.deterministic)},
         "train_conv_tflops_per_gpu": round(value / world * GFLOP_TRAIN_PER_TILE * (args.tile / 224.0) ** 2 / 1e3, 1),
     }
+    out["final_loss"] = float(last_loss[0])  # (read after the timed region) CE of the last timed step: must be finite
+    if hasattr(trainer, "settle"):
+        trainer.settle()
+        if trainer.dynamic_scale:
+            out["loss_scale"] = {"final": trainer.loss_scale, "skipped_steps": trainer.skipped_steps, "applied_steps": trainer.step_count}
     if TEST_BACKEND:
         out["test_backend"] = TEST_BACKEND + ": ranks share GPUs, numbers are not measurements"
 

@@ -131,6 +131,10 @@ class SegTrainer(_ArenaMixin):
         self.opt_state = torch.zeros(2, device=dev, dtype=torch.int32)
         self.scale_lag = 2
         self._pending_flags = []  # (event, pinned flag, loss scale the step ran with), oldest first
+        # (pinned slots and events are made once: allocating pinned memory synchronises the device)
+        self._flag_slots = [torch.empty(1, dtype=torch.int32, pin_memory=True) for _ in range(self.scale_lag + 2)] if self.dynamic_scale else []
+        self._flag_events = [torch.cuda.Event() for _ in self._flag_slots]
+        self._flag_next = 0
         self.grads: Dict[str, Tensor] = {}
         self.offsets: Dict[str, Tuple[int, int]] = {}
         off = 0
@@ -183,9 +187,10 @@ class SegTrainer(_ArenaMixin):
             ops.nonfinite_count(self.g_flat, out=flag)
             ops.adamw_step_guarded(self.p_flat, self.g_flat, self.m_flat, self.v_flat, self.pb_flat, self.lr, self.betas, self.eps,
                                    self.weight_decay, self.opt_state, grad_inv_scale=1.0 / self.loss_scale)
-            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            self.settle(keep=len(self._flag_slots) - 1)  # (a free slot in the ring)
+            host, ev = self._flag_slots[self._flag_next], self._flag_events[self._flag_next]
+            self._flag_next = (self._flag_next + 1) % len(self._flag_slots)
             host.copy_(flag, non_blocking=True)
-            ev = torch.cuda.Event()
             ev.record()
             self._pending_flags.append((ev, host, self.loss_scale))
             model.invalidate_weight_cache()

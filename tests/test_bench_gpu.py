@@ -26,6 +26,7 @@ def test_bench_json_contract_small_config():
         assert isinstance(d[k], t), (k, d[k])
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["unit"] == "tiles/s" and d["value"] > 0 and "workload" in d["config"] and "model" not in d["config"]
+    assert d["final_loss"] == d["final_loss"] and 0 < d["final_loss"] < 1e3  # finite: the timed steps ran on sane numbers
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
     r = d["roofline"]
     assert r["bound"] in ("mfma", "hbm") and r["unit"] in ("TFLOP/s", "GB/s") and r["peak"] > 0 and r["achieved"] > 0
@@ -40,6 +41,7 @@ def test_bench_json_contract_small_config():
 def test_bench_rfm_workload_carries_roofline_and_cpu_baseline():
     d = run_bench("--workload", "rfm", "--batch", "2", "--tile", "64", "--steps", "2", "--warmup", "1", "--cpu-tiles", "1")
     assert d["value"] > 0 and "configs[3]" in d["config"]["workload"] and d["n_gpus"] == 1
+    assert all(v == v and abs(v) < 1e4 for v in d["final_losses"].values())  # finite
     r, c = d["roofline"], d["cpu_baseline"]
     assert r["bound"] == "mfma" and r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "stage-3" in c["sample"]
