@@ -36,7 +36,7 @@ def _data(kind):
     drops = []
     for _ in range(2):
         drops.append({name: (torch.rand(n, c, generator=g) >= p).float() / (1 - p) for name, c, p in DROP_SPECS})
-    if kind == "seg":
+    if kind.startswith("seg"):
         x = torch.randn(n, 3, 64, 64, generator=g)
         y = torch.randint(0, 4, (n, 64, 64), generator=g)
         return (x, y), drops
@@ -68,7 +68,7 @@ def _run(rank, world, port, backend, kind, out):
         pg = dist.group.WORLD if world > 1 else None
         it = iter(drops)
         sample = lambda n_, dev_: {k: v[sl].to(dev_) for k, v in next(it).items()}
-        if kind == "seg":
+        if kind.startswith("seg"):
             from pistoseg_amd.seg_model import ResNet38dSeg
             from pistoseg_amd.trainer import SegTrainer
 
@@ -76,7 +76,9 @@ def _run(rank, world, port, backend, kind, out):
             model.load_state_dict(ref_cpu.make_state_dict(3, False, seed=42))
             model = model.to(D)
             model.sample_dropout = sample
-            tr = SegTrainer(model, lr=1e-3, weight_decay=0.05, ignore_index=3, process_group=pg, bucket_mb=64.0, track_iou=False)
+            # "seg_bf16": the second wire format (buckets cast to bf16, summed, widened back) with CUs reserved for the collectives
+            extra = dict(grad_payload="bf16", share="reserve", reserved_cus=32) if kind == "seg_bf16" else {}
+            tr = SegTrainer(model, lr=1e-3, weight_decay=0.05, ignore_index=3, process_group=pg, bucket_mb=64.0, track_iou=False, **extra)
             step = lambda: float(tr.train_step(inputs[0][sl].to(D), inputs[1][sl].to(D)))
         else:
             from pistoseg_amd.revise_net import Net
@@ -105,7 +107,7 @@ def _run(rank, world, port, backend, kind, out):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["seg", "rfm"])
+@pytest.mark.parametrize("kind", ["seg", "rfm", "seg_bf16"])
 def test_two_rank_step_equals_single_process_step(kind):
     backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
     ctx = mp.get_context("spawn")
@@ -134,6 +136,10 @@ def test_two_rank_step_equals_single_process_step(kind):
     d = abs(r0[3] - single[3])
     if kind == "seg":
         assert float(d.mean()) < 1e-6 and float(d.max()) <= 2 * 2 * 1e-3 * 1.1  # Adam sign noise bound, see test_modules_gpu
+    elif kind == "seg_bf16":
+        # gradients rounded to bf16 on the wire (2^-9 relative): Adam's normalised update moves by that fraction of lr per step on average
+        print(f"seg_bf16: mean |dp| {float(d.mean()):.3e}, max |dp| {float(d.max()):.3e}")
+        assert float(d.mean()) < 2e-5 and float(d.max()) <= 2 * 2 * 1e-3 * 1.1
     else:
         # plain SGD: the update is linear in the gradient.  Between a 4-tile step and two 2-tile steps the weight gradients are summed
         # in a different order (f32 atomics) and step 2 starts from parameters that already differ in the last bits, so the
@@ -174,6 +180,21 @@ def _rccl_world1(port, out):
             red.finish()
             want = torch.cat([torch.full((n,), float(step * 3 + i + 1)) for i in range(3)])
             ok = ok and bool(torch.equal(flat.cpu(), want))
+        # the bf16 wire format and the CU reservation through the same communicator: cast -> RCCL all-reduce of the bf16 staging slice -> widen,
+        # all on the communication stream; the launch option toggled is the given model's
+        class _Opts:
+            tiles_per_block = None
+            cus_reserved = None
+        opts = _Opts()
+        red16 = BucketedAllReduce(flat, red.buckets, dist.group.WORLD, launch_opts=opts, payload="bf16", share="reserve", reserved_cus=32)
+        red16.begin_step()
+        vals = torch.randn(3 * n, device="cuda")
+        flat.copy_(vals)
+        red16.on_unit_done("fc8")
+        ok = ok and opts.cus_reserved == 32 and opts.tiles_per_block is None
+        red16.on_unit_done("b7")
+        red16.finish()
+        ok = ok and opts.cus_reserved is None and bool(torch.equal(flat, vals.to(torch.bfloat16).float()))
         out.put(("ok" if ok else "values wrong (side stream ran ahead of the producer?)"))
         dist.destroy_process_group()
     except Exception as e:  # pragma: no cover
