@@ -131,8 +131,8 @@ def test_two_rank_step_equals_single_process_step(kind):
     for k in r0[4]:
         assert (r0[4][k] == r1[4][k]).all(), f"ranks diverged on {k}"
     # global loss = mean of the per-rank means (equal shard sizes; every loss of the path is a mean over samples of per-sample terms)
-    for s in range(2):
-        assert abs(0.5 * (r0[2][s] + r1[2][s]) - single[2][s]) < 2e-4 * abs(single[2][s])
+    for s in range(2):  # (seg_bf16: step 2 starts from weights updated with bf16-rounded gradients)
+        assert abs(0.5 * (r0[2][s] + r1[2][s]) - single[2][s]) < (2e-3 if kind == "seg_bf16" and s > 0 else 2e-4) * abs(single[2][s])
     d = abs(r0[3] - single[3])
     if kind == "seg":
         assert float(d.mean()) < 1e-6 and float(d.max()) <= 2 * 2 * 1e-3 * 1.1  # Adam sign noise bound, see test_modules_gpu
@@ -190,11 +190,15 @@ def _rccl_world1(port, out):
         red16.begin_step()
         vals = torch.randn(3 * n, device="cuda")
         flat.copy_(vals)
+        seen = []
+        share = red16._share_gpu
+        red16._share_gpu = lambda on: (share(on), seen.append((on, opts.cus_reserved, opts.tiles_per_block)))[0]
         red16.on_unit_done("fc8")
-        ok = ok and opts.cus_reserved == 32 and opts.tiles_per_block is None
         red16.on_unit_done("b7")
         red16.finish()
-        ok = ok and opts.cus_reserved is None and bool(torch.equal(flat, vals.to(torch.bfloat16).float()))
+        # (a finished bucket may hand the CUs back before the next one is launched: only the first and the last transition are fixed)
+        ok = ok and seen[0] == (True, 32, None) and seen[-1] == (False, None, None) and opts.cus_reserved is None
+        ok = ok and bool(torch.equal(flat, vals.to(torch.bfloat16).float()))
         out.put(("ok" if ok else "values wrong (side stream ran ahead of the producer?)"))
         dist.destroy_process_group()
     except Exception as e:  # pragma: no cover
