@@ -69,6 +69,10 @@ def parse():
     ap.add_argument("--deterministic", action="store_true",
                     help="weight gradients without atomics (ps_conv2d_wgrad_det): the reference's Trainer(deterministic=True) / use_deterministic_algorithms(True)")
     ap.add_argument("--no-overlap", action="store_true", help="weight gradients on the launch stream instead of a second stream")
+    ap.add_argument("--grad-payload", default="fp32", choices=["fp32", "bf16"],
+                    help="N > 1: wire format of the gradient exchange (bf16: buckets cast, all-reduced, widened back: half the xGMI bytes)")
+    ap.add_argument("--share", default="batch", help="N > 1: how the conv launches make room for the collectives while buckets are in flight: "
+                                                     "'batch' (tiles_per_block = 1) or 'reserve[:CUS]' (cus_reserved, default 32)")
     ap.add_argument("--cpu-tiles", type=int, default=8, help="tiles per CPU-baseline step (SURVEY 8d: bs=8, 1 warm-up + 3 timed)")
     ap.add_argument("--workload", default="seg", choices=["seg", "rfm", "infer2", "infer4"],
                     help="seg: BASELINE configs[1]/[4] (segmentation_train.py step, the headline metric); rfm: configs[3], the stage-3 step "
@@ -79,6 +83,12 @@ def parse():
     ap.add_argument("--pack", default=None, help="infer2: write logits_32x32 of every rank into this ONE packed file")
     ap.add_argument("--streams", type=int, default=1, help="infer2: HIP streams that consecutive (independent) batches alternate between")
     return ap.parse_args()
+
+
+def share_args(args):
+    mode, _, cus = args.share.partition(":")
+    assert mode in ("batch", "reserve"), args.share
+    return dict(grad_payload=args.grad_payload, share=mode, reserved_cus=int(cus) if cus else 32)
 
 
 def spawn_ranks(args) -> int:
@@ -367,7 +377,7 @@ def rfm_bench(args, world, rank, dev, dist_on):
     # and falling; the line reports them.
     rfm_lr = args.lr if args.lr is not None else 1e-3
     tr = RFMTrainer(model, lr=rfm_lr, wt_dec=5e-4, max_step=10 ** 6, process_group=torch.distributed.group.WORLD if dist_on else None,
-                    overlap_wgrad=not args.no_overlap, deterministic=args.deterministic)
+                    overlap_wgrad=not args.no_overlap, deterministic=args.deterministic, **share_args(args))
     g = torch.Generator(device="cpu").manual_seed(4321 + rank)
     n = args.batch
     x = torch.randn(n, 3, args.tile, args.tile, generator=g).to(dev)
@@ -640,7 +650,7 @@ def main():
     lr = args.lr if args.lr is not None else (2e-4 if args.precision in ("fp16", "fp16x3") else 1e-3)
     trainer = SegTrainer(model, lr=lr, weight_decay=0.05, ignore_index=ignore_index,
                          process_group=torch.distributed.group.WORLD if dist_on else None, overlap_wgrad=not args.no_overlap,
-                         deterministic=args.deterministic)
+                         deterministic=args.deterministic, **share_args(args))
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     x = torch.randn(args.batch, 3, args.tile, args.tile, generator=g).to(dev)
     y = torch.randint(0, target_hi, (args.batch, args.tile, args.tile), generator=g).to(dev)
@@ -664,7 +674,7 @@ def main():
         "config": {"workload": f"BASELINE configs[{1 if (args.classes, args.precision, args.batch) == (3, 'bf16', 64) else 4}]: segmentation_train.py step, "
                                f"ResNet38-d seg model, {args.classes}-class CE(ignore_index={ignore_index}), targets 0..{target_hi - 1}, AdamW(lr={lr:g}), random-init",
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "tile": args.tile, "parallelism": f"dp{world}",
-                   "deterministic": bool(args.deterministic)},
+                   "deterministic": bool(args.deterministic), "grad_payload": args.grad_payload, "share": args.share},
         "train_conv_tflops_per_gpu": round(value / world * GFLOP_TRAIN_PER_TILE * (args.tile / 224.0) ** 2 / 1e3, 1),
     }
     out["final_loss"] = float(last_loss[0])  # (read after the timed region) CE of the last timed step: must be finite
