@@ -73,10 +73,14 @@ __device__ __forceinline__ void ps_tile_of_block(int bid, int ntn, int ntm, int&
   }
 }
 
-// Epilogue storage tag of the split-bf16 path (PS_BF16X3): a tensor of C logical channels is three planes of C bf16 channels per pixel,
-// [hi | lo | hi] with hi = bf16(v), lo = bf16(v - hi) (the value is hi + lo, 16 mantissa bits); the duplicated hi plane is what lets the
-// unmodified K loop of every kernel compute x_hi w_hi + x_lo w_hi + x_hi w_lo as ONE bf16 contraction over 3 C channels against weights
-// laid out [hi | hi | lo] per tap (f32 accumulate).  sizeof == 1 so that the `sizeof(T) == 2` 16-bit fast paths do not take it.
+// Epilogue storage tag of the split-bf16 path (PS_BF16X3).  A value is hi + lo with hi = bf16(v), lo = bf16(v - hi) (16 significant bits); a
+// tensor of C logical channels stores 2 C bf16 channels per pixel in blocks of 32 logical channels: [hi(32) | lo(32)] = one 128-byte
+// K-line.  Weights are laid out the same way along their K axis, so every kernel STAGES a split tensor exactly like a plain 16-bit one (the
+// loaders do not know the difference) and a staged K-line's two 64-byte halves are the hi and the lo fragments of the same 32 channels.
+// The consumers multiply each K-line THREE times -- hi.hi, hi.lo, lo.hi on the fragments they hold anyway (Tr::split) -- with f32
+// accumulation: x w up to the dropped lo.lo term at 3 MFMAs per product, with the LDS-DMA pieces and fragment reads of 2.  (Round 4's
+// first version duplicated the hi plane -- [hi | lo | hi] against [hi | hi | lo] -- so that the K loops ran unchanged over 3 C channels:
+// 6 bytes per value, 3 x the pieces and reads.)  sizeof == 1 so that the `sizeof(T) == 2` 16-bit fast paths do not take it.
 struct bf16x3_t {};
 struct f16x3_t {};  // the same on fp16 planes (PS_F16X3): 11 + 11 significant bits, fp16's range
 template <typename T> struct is_split_t { static constexpr bool value = std::is_same<T, bf16x3_t>::value || std::is_same<T, f16x3_t>::value; };
@@ -87,18 +91,21 @@ template <> struct plane_of<f16x3_t> { typedef _Float16 type; };
 struct TraitsBF16 {
   typedef __bf16 elem;
   typedef __bf16 epi;
+  static constexpr bool split = false;
   static __device__ __forceinline__ void mma(const u32x4& w, const u32x4& x, f32x4& acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
   }
 };
-struct TraitsBF16X3 {  // K loop of TraitsBF16 over 3 x the channels, split epilogue
+struct TraitsBF16X3 {  // bf16 staging and MFMA; each K-line multiplied three times (hi.hi, hi.lo, lo.hi); split epilogue
   typedef __bf16 elem;
   typedef bf16x3_t epi;
+  static constexpr bool split = true;
   static __device__ __forceinline__ void mma(const u32x4& w, const u32x4& x, f32x4& acc) { TraitsBF16::mma(w, x, acc); }
 };
 struct TraitsF16X3 {
   typedef _Float16 elem;
   typedef f16x3_t epi;
+  static constexpr bool split = true;
   static __device__ __forceinline__ void mma(const u32x4& w, const u32x4& x, f32x4& acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
   }
@@ -106,6 +113,7 @@ struct TraitsF16X3 {
 struct TraitsF16 {
   typedef _Float16 elem;
   typedef _Float16 epi;
+  static constexpr bool split = false;
   static __device__ __forceinline__ void mma(const u32x4& w, const u32x4& x, f32x4& acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
   }
@@ -113,6 +121,7 @@ struct TraitsF16 {
 struct TraitsF32 {
   typedef float elem;
   typedef float epi;
+  static constexpr bool split = false;
   // a 16-byte chunk holds 4 consecutive k of this lane's row; MFMA j consumes element j of both operands,
   // i.e. k = 4*(chunk) + j for lane group (lane>>4): every k of the K-line is visited exactly once.
   static __device__ __forceinline__ void mma(const u32x4& w, const u32x4& x, f32x4& acc) {
@@ -153,12 +162,12 @@ struct Raw8 {
   static constexpr bool X3 = is_split_t<T>::value, XH = std::is_same<T, f16x3_t>::value;
   static constexpr int NQ = X3 ? 2 : sizeof(T) / 2;  // 16-byte quads (split: the hi and the lo plane's)
   u32x4 q[NQ];
-  // plane: byte distance between the planes of a split tensor (ignored by the plain types), wave-uniform.  It travels in the buffer
-  // instruction's scalar offset, which takes no part in the range check: a row past the end is dropped through its lane offset alone.
-  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int voff, int plane = 0) {
+  // split tensors: voff addresses 8 hi values; their lo partners sit 64 bytes further (the other half of the 32-channel block), which the
+  // compiler folds into the instruction's immediate offset
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int voff) {
     if constexpr (X3) {
       q[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
-      q[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, plane, 0);  // plane distance as the instruction's SCALAR offset: no second address register
+      q[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 64, 0, 0);
     } else {
 #pragma unroll
       for (int k = 0; k < NQ; ++k) q[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16 * k, 0, 0);
@@ -190,7 +199,7 @@ struct Raw8 {
       for (int i = 0; i < 8; ++i) v[i] = static_cast<float>(h[i]);
     }
   }
-  static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rs, int voff, const float* v, int plane = 0) {
+  static __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rs, int voff, const float* v) {
     if constexpr (X3) {
       u32x4 hi, lo;
       if constexpr (XH) {
@@ -211,13 +220,12 @@ struct Raw8 {
           lo[i] = l0 | (l1 << 16);
         }
       }
-      // The plane distance goes into the LANE offset here, not into the scalar offset as for the loads: a 128-bit buffer store whose SOFFSET is
-      // an SGPR reads its data registers late, and hipcc (ROCm 7.2) only guards the immediate-SOFFSET form of that hazard -- it scheduled the
-      // next row's first v_mov straight behind such a store and one dword of the third plane came out as garbage in a few rows per launch
-      // (found by tests/test_split_gpu.py on conv_gemm256_kernel; gfx950).
+      // (Offsets of split stores never go through an SGPR scalar offset: a 128-bit buffer store whose SOFFSET is an SGPR reads its data registers
+      // late, and hipcc (ROCm 7.2) only guards the immediate-SOFFSET form of that hazard -- the first version of this epilogue addressed its
+      // planes that way, the compiler scheduled the next row's first v_mov straight behind the store and one dword came out as garbage in a few
+      // rows per launch; found by tests/test_split_gpu.py on conv_gemm256_kernel, gfx950.)
       __builtin_amdgcn_raw_buffer_store_b128(hi, rs, voff, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(lo, rs, voff + plane, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(hi, rs, voff + 2 * plane, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(lo, rs, voff + 64, 0, 0);
     } else if constexpr (sizeof(T) == 4) {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -250,13 +258,13 @@ template <typename T, int MI, int WI, int MAP = 0, int CW = (sizeof(T) == 2 ? 4 
 __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[MI][WI], int mbase, int cbase, int lane) {
   constexpr bool COLMAP = MAP == 1;
   constexpr int CH = 4 * WI;  // 16 or 8 channels per lane, handled CW at a time
-  constexpr bool X3 = is_split_t<T>::value;  // split tensors: planes [hi | lo | hi], a.Cd channels apart (see bf16x3_t)
+  constexpr bool X3 = is_split_t<T>::value;  // split tensors: blocks of 32 logical channels stored [hi(32) | lo(32)] (see bf16x3_t)
   typedef typename plane_of<T>::type PT;
+  auto sch = [](int c) { return X3 ? ((c >> 5) << 6) + (c & 31) : c; };  // logical channel -> stored channel (of its hi half)
   constexpr int NO = CW / 8, ES = X3 ? 2 : (int)sizeof(T);
   static_assert(CW % 8 == 0 && CH % CW == 0, "channel chunk");
   const int frow = lane & 15, g = lane >> 4;
   const ps_epilogue& e = a.epi;
-  const int plane = a.Cd * ES;
   const int row0 = COLMAP ? mbase + (frow & 7) * a.Wo + (frow >> 3) : mbase + frow;  // row of fragment mi: row0 + mi * RSTEP
   constexpr int RSTEP = COLMAP ? 2 : 16;
   // MAP 2: fragment row mi is pixel m = row0 + 16 mi of the class's sub-grid -> row rrow[mi] of the full tensor (epi_M = dropped)
@@ -271,8 +279,8 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
     }
   }
   auto roff = [&](int mi, int ldc, int cb) {  // byte offset of fragment row mi, channel cb, in a tensor of row stride ldc
-    if constexpr (MAP == 2) return (rrow[mi] * ldc + cb) * ES;
-    else return ((row0 + mi * RSTEP) * ldc + cb) * ES;
+    if constexpr (MAP == 2) return (rrow[mi] * ldc + sch(cb)) * ES;
+    else return ((row0 + mi * RSTEP) * ldc + sch(cb)) * ES;
   };
   auto rsrc = [&](const void* base, int ldc) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, a.epi_M * ldc * ES, 0x00020000);
@@ -313,7 +321,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
 #pragma unroll
       for (int mi = 0; mi < LW; ++mi)
 #pragma unroll
-        for (int o = 0; o < NO; ++o) t[mi][o].load(rs, roff(mi, ldc, cb) + 8 * o * ES, plane);
+        for (int o = 0; o < NO; ++o) t[mi][o].load(rs, roff(mi, ldc, cb) + 8 * o * ES);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -322,7 +330,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
           t[mi % LW][o].unpack(f);
 #pragma unroll
           for (int i = 0; i < 8; ++i) acc[mi][(c0 + 8 * o + i) / 4][i & 3] += f[i];
-          if (mi + LW < MI) t[mi % LW][o].load(rs, roff(mi + LW, ldc, cb) + 8 * o * ES, plane);
+          if (mi + LW < MI) t[mi % LW][o].load(rs, roff(mi + LW, ldc, cb) + 8 * o * ES);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -340,7 +348,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
             const float y = fmaxf(x * sc[8 * o + i] + sh[8 * o + i], 0.f);
             f[i] = bnrelu ? y : x;
           }
-          Raw8<T>::store(rs, roff(mi, ldc, cb) + 8 * o * ES, f, plane);
+          Raw8<T>::store(rs, roff(mi, ldc, cb) + 8 * o * ES, f);
         }
     };
     if (e.add0) add_rows(e.add0, e.ldc_add0);
@@ -360,10 +368,10 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
       const int hw = a.Ho * a.Wo;
       auto ld8 = [&](const void* base, int ldc, int m, int c, float* v) {  // 8 channels c.. of row m
         if constexpr (X3) {
-          const PT* p = reinterpret_cast<const PT*>(base) + (long long)m * ldc + c;
+          const PT* p = reinterpret_cast<const PT*>(base) + (long long)m * ldc + sch(c);
           float lo[8];
           ps_load8<PT>(p, v);
-          ps_load8<PT>(p + a.Cd, lo);
+          ps_load8<PT>(p + 32, lo);
 #pragma unroll
           for (int i = 0; i < 8; ++i) v[i] += lo[i];
         } else {
@@ -372,7 +380,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
       };
       auto st8 = [&](void* base, int ldc, int m, int c, const float* v) {
         if constexpr (X3) {
-          PT* p = reinterpret_cast<PT*>(base) + (long long)m * ldc + c;
+          PT* p = reinterpret_cast<PT*>(base) + (long long)m * ldc + sch(c);
           float hi[8], lo[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
@@ -380,8 +388,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
             lo[i] = v[i] - hi[i];
           }
           ps_store8<PT>(p, hi);
-          ps_store8<PT>(p + a.Cd, lo);
-          ps_store8<PT>(p + 2 * a.Cd, hi);
+          ps_store8<PT>(p + 32, lo);
         } else {
           ps_store8<T>(reinterpret_cast<T*>(base) + (long long)m * ldc + c, v);
         }
@@ -422,7 +429,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
 #pragma unroll
       for (int mi = 0; mi < LW; ++mi)
 #pragma unroll
-        for (int o = 0; o < NO; ++o) t[mi][o].load(rs, roff(mi, e.ldc_mask, cb) + 8 * o * ES, plane);
+        for (int o = 0; o < NO; ++o) t[mi][o].load(rs, roff(mi, e.ldc_mask, cb) + 8 * o * ES);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -434,7 +441,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
             const float x = acc[mi][(c0 + 8 * o + i) / 4][i & 3] * sc[8 * o + i];
             acc[mi][(c0 + 8 * o + i) / 4][i & 3] = ms[i] > 0.f ? x : 0.f;
           }
-          if (mi + LW < MI) t[mi % LW][o].load(rs, roff(mi + LW, e.ldc_mask, cb) + 8 * o * ES, plane);
+          if (mi + LW < MI) t[mi % LW][o].load(rs, roff(mi + LW, e.ldc_mask, cb) + 8 * o * ES);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -601,12 +608,21 @@ __global__ __launch_bounds__(64 * WMW * WNW) void conv_igemm_kernel(const IgemmA
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) xf[kk][mi] = *reinterpret_cast<const u32x4*>(st + xfrag + mi * 2048 + coff);
     }
+    if constexpr (Tr::split) {  // the K-line's halves are the hi and the lo fragments of 32 channels: hi.hi + hi.lo + lo.hi
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+      for (int t = 0; t < 3; ++t)
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int i = 0; i < WI; ++i) Tr::mma(wf[kk][i], xf[kk][mi], acc[mi][i]);
+          for (int i = 0; i < WI; ++i) Tr::mma(wf[t == 2 ? 1 : 0][i], xf[t == 1 ? 1 : 0][mi], acc[mi][i]);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int i = 0; i < WI; ++i) Tr::mma(wf[kk][i], xf[kk][mi], acc[mi][i]);
+    }
     if (s + 1 < nsteps) stage_commit(cur ^ 1);
     __syncthreads();
   }
@@ -1130,6 +1146,23 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_ws_kernel(const IgemmArgs a
   __builtin_amdgcn_s_barrier();  // step 0 staged
   for (int s = 0; s < nsteps; ++s) {
     const unsigned char* st = smem + (s & 1) * STAGE;
+    if constexpr (Tr::split) {  // hi.hi + hi.lo + lo.hi on the two halves of the K-line (see bf16x3_t)
+      u32x4 wf[2][WI], xf[2][MI];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int coff = ((g + 4 * kk) ^ sw) << 4;
+#pragma unroll
+        for (int i = 0; i < WI; ++i) wf[kk][i] = *reinterpret_cast<const u32x4*>(st + wfrag + i * 2048 + coff);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) xf[kk][mi] = *reinterpret_cast<const u32x4*>(st + xfrag + mi * 2048 + coff);
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int i = 0; i < WI; ++i) Tr::mma(wf[t == 2 ? 1 : 0][i], xf[t == 1 ? 1 : 0][mi], acc[mi][i]);
+    } else {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int coff = ((g + 4 * kk) ^ sw) << 4;
@@ -1142,6 +1175,7 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_ws_kernel(const IgemmArgs a
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int i = 0; i < WI; ++i) Tr::mma(wf[i], xf[mi], acc[mi][i]);
+    }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (PS_ABLATE(a.ablate) != 2) __builtin_amdgcn_s_barrier();
@@ -1326,9 +1360,17 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
     // MFMAs on (wfo, xfo), whose operands are already in registers: read, 2 MFMAs, read, 2 MFMAs, ... so the matrix pipe
     // starts right behind the barrier / the wait instead of idling through a burst of 11-12 LDS instructions (the order is
     // pinned with scheduling barriers; hipcc otherwise hoists all reads to the top).
+    // Split types (Tr::split): a K-line's halves are the hi and the lo fragments of 32 channels and the K-step runs THREE MFMA groups on them,
+    //   A: read hi -> (wf0, xf0)  |  MFMAs x_hi(previous step) . w_lo(previous step) = (xf0 being replaced, wf1)
+    //   B: read lo -> (wf1, xf1)  |  MFMAs x_hi . w_hi = (xf0, wf0)
+    //   C: (no reads)             |  MFMAs x_lo . w_hi = (xf1, wf0)
+    // with the two register sets the plain loop already keeps.  In A the pixel fragments xf0 are operand AND read destination: with three MFMAs
+    // per read slot, the MFMA that uses xf0[j] (slot <= (4 j + 3) / 3) is issued before the read that replaces it (slot WI + j) -- program order,
+    // which the in-order wave keeps.
     auto half = [&](const unsigned char* st, int coff, u32x4 (&wfn)[WI], u32x4 (&xfn)[MI], const u32x4 (&wfo)[WI], const u32x4 (&xfo)[MI],
                     bool do_mma) {
-      constexpr int NR = WI + MI, NM = MI * WI, PER = PS_READ_PER;
+      constexpr int NR = WI + MI, NM = MI * WI, PER = Tr::split ? 3 : PS_READ_PER;
+      static_assert(!Tr::split || (NM - 1) / 3 < WI + (NM - 1) / WI, "split: every MFMA on the old pixel fragments precedes their replacement");
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         if (r < WI) wfn[r] = *reinterpret_cast<const u32x4*>(st + wfrag + r * 2048 + coff);
@@ -1346,6 +1388,15 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
       }
       __builtin_amdgcn_sched_barrier(0);
     };
+    auto group_c = [&]() {  // split types: x_lo . w_hi, both already in registers
+      if constexpr (Tr::split) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int i = 0; i < WI; ++i) Tr::mma(wf0[i], xf1[mi], acc[mi][i]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
     {  // first K-step of the tile: nothing to overlap the first reads with
       const unsigned char* st = smem + cur * STAGE;
       half(st, coff0, wf0, xf0, wf1, xf1, false);
@@ -1353,23 +1404,27 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
       __builtin_amdgcn_sched_barrier(0);
       half(st, coff1, wf1, xf1, wf0, xf0, true);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      group_c();
       __builtin_amdgcn_s_barrier();
       cur = (cur == 2) ? 0 : cur + 1;
     }
     for (int s = 1; s < nsteps; ++s) {
       const unsigned char* st = smem + cur * STAGE;
-      half(st, coff0, wf0, xf0, wf1, xf1, true);  // this step's first K-half is read behind the previous step's second-half MFMAs
+      // this step's first K-half is read behind the previous step's outstanding MFMAs (plain: its second half; split: x_hi . w_lo)
+      if constexpr (Tr::split) half(st, coff0, wf0, xf0, wf1, xf0, true);
+      else half(st, coff0, wf0, xf0, wf1, xf1, true);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       half(st, coff1, wf1, xf1, wf0, xf0, true);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads of this slot are done: the loaders may refill it
+      group_c();
       __builtin_amdgcn_s_barrier();
       cur = (cur == 2) ? 0 : cur + 1;
     }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int i = 0; i < WI; ++i) Tr::mma(wf1[i], xf1[mi], acc[mi][i]);
+      for (int i = 0; i < WI; ++i) Tr::mma(wf1[i], Tr::split ? xf0[mi] : xf1[mi], acc[mi][i]);  // (split: the last step's x_hi . w_lo)
     int tm, tn;
     ps_tile_of_block(tile, a.ntn, a.ntm, tm, tn, a.supertile);
     conv_epilogue<typename Tr::epi, MI, WI, SPLIT ? 2 : 0>(a, acc, tm * BM + wm * WM, tn * BN + wn * WN, lane);
@@ -2004,7 +2059,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
       (void)PER;
       return;
 #else
-      constexpr int NR = WI + MI, NM = MI * WI, PER = PS_READ_PER;
+      constexpr int NR = WI + MI, NM = MI * WI, PER = Tr::split ? 3 : PS_READ_PER;  // (split types: three MFMA groups per K-line, see conv_igemm_ws2_kernel)
+      static_assert(!Tr::split || (NM - 1) / 3 < WI + (NM - 1) / WI, "split: every MFMA on the old pixel fragments precedes their replacement");
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
 #ifndef PS_HALO_NO_READS  // (diagnostic build, results WRONG: MFMAs on stale registers -- the bare MFMA stream between the barriers)
@@ -2032,7 +2088,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
       const unsigned char* wst = smem + cur * B_BYTES + wfrag;
       const int soff = wbuf * WIN_BYTES + (tx - 1) * a.dstep * 1024;
 #ifndef PS_HALO_NO_CONSUMERS  // (A/B build, results WRONG: the consumers only keep the barriers -- what the loaders alone sustain)
-      half(wst, coff0, soff, 0, wf0, xf0, wf1, xf1, !first_of_tile);
+      if constexpr (Tr::split) half(wst, coff0, soff, 0, wf0, xf0, wf1, xf0, !first_of_tile);  // x_hi(previous step) . w_lo(previous step) while this step's hi arrives
+      else half(wst, coff0, soff, 0, wf0, xf0, wf1, xf1, !first_of_tile);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef PS_HALO_STAMPS
       unsigned long long t_a, t_b, t_c;
@@ -2042,6 +2099,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
       __builtin_amdgcn_sched_barrier(0);
       half(wst, coff1, soff, 64, wf1, xf1, wf0, xf0, true);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (Tr::split) {  // x_lo . w_hi, both in registers
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int i = 0; i < WI; ++i) Tr::mma(wf0[i], xf1[mi], acc[mi][i]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #ifdef PS_HALO_STAMPS
       PS_STAMP(t_b);
       st_seg1 += t_b - t_a;
@@ -2068,7 +2132,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int i = 0; i < WI; ++i) Tr::mma(wf1[i], xf1[mi], acc[mi][i]);
+      for (int i = 0; i < WI; ++i) Tr::mma(wf1[i], Tr::split ? xf0[mi] : xf1[mi], acc[mi][i]);  // (split: the last step's x_hi . w_lo)
 #else
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -2256,9 +2320,10 @@ static bool use_gemm256(long long M, int Cd, int esize, int taps, int mul, int d
 
 template <typename Tr>
 int dispatch_bn(const IgemmArgs& a, hipStream_t s, bool allow_gemm256 = true) {
-  if constexpr (sizeof(typename Tr::elem) == 2) {
+  if constexpr (sizeof(typename Tr::elem) == 2 && !Tr::split) {
     // (one tile per block, dispatched by the hardware: this kernel re-balances around CUs held by a communication kernel by itself, so
     // the tiles_per_block launch option of the persistent kernels does not apply to it)
+    // (split types stay on the wave-specialised kernels: conv_gemm256_kernel's eight-phase loop has no third MFMA group)
     if (allow_gemm256 && use_gemm256(a.M, a.Cd, 2, a.taps, a.mul, a.div_shift, a.klines)) {
       IgemmArgs b = a;
       b.ntn = a.Cd / 256;
@@ -2458,8 +2523,9 @@ extern "C" int ps_conv_variant(const ps_conv_geom* g, int32_t dgrad) {
   const long long ho = (g->h - 1) / g->stride + 1, wo = (g->w - 1) / g->stride + 1;
   const long long M = dgrad ? (long long)g->n * g->h * g->w : (long long)g->n * ho * wo;
   if (g_use_3stage + g_use_pp != 0) return PS_CONV_OTHER;
-  if (use_gemm256(M, dgrad ? g->cin : g->cout, ps_esize(g->dtype), g->ksize * g->ksize, dgrad ? 1 : g->stride,
-                                              dgrad && g->stride == 2 ? 1 : 0, ps_planes(g->dtype) * (dgrad ? g->cout : g->cin) * ps_esize(g->dtype) / 128))
+  if (ps_planes(g->dtype) == 1 &&
+      use_gemm256(M, dgrad ? g->cin : g->cout, ps_esize(g->dtype), g->ksize * g->ksize, dgrad ? 1 : g->stride, dgrad && g->stride == 2 ? 1 : 0,
+                  (dgrad ? g->cout : g->cin) * ps_esize(g->dtype) / 128))
     return PS_CONV_GEMM256;
   // both directions of a stride-1 3x3 layer gather on the input grid h x w
   const bool halo_ok = g->ksize == 3 && g->stride == 1 && halo_tile_width(g->w) != 0 && g->dilation <= 4;
@@ -2538,7 +2604,7 @@ extern "C" int ps_conv2d_fwd(const ps_conv_geom* g, const void* x, const void* w
   a.M = g->n * a.Ho * a.Wo;
   a.mul = g->stride; a.dstep = g->dilation; a.div_shift = 0;
   a.taps = g->ksize * g->ksize; a.ctr = g->ksize / 2;
-  const int kc = ps_planes(g->dtype) * g->cin;  // contracted channels per tap (split format: [hi | lo | hi] against [hi | hi | lo])
+  const int kc = ps_planes(g->dtype) * g->cin;  // stored channels per tap (split formats: 32-channel blocks [hi | lo], each one 128-byte K-line)
   a.klines = kc * es / 128;
   a.pix_bytes = (long long)g->ldc_x * es;
   a.wrow_bytes = (long long)a.taps * kc * es;

@@ -45,7 +45,17 @@ struct WgradArgs {
   // vtab[((tap * vperiod + ks % vperiod) * 4 + loader wave) * 4 + j] = 64-bit mask of the lanes whose row is inside the image for that tap
   const unsigned long long* vtab;
   int vperiod;
+  // split 16-bit operands (PS_BF16X3 / PS_F16X3: 32-channel blocks [hi(32) | lo(32)] per pixel): which half of every block this launch reads.
+  // The weight gradient contracts over PIXELS, so hi / lo cannot share a K-line as in the forward kernels: dW = x_hi dy_hi + x_hi dy_lo + x_lo dy_hi is
+  // three launches of the 16-bit kernels, whose loaders gather the chosen halves (a per-lane source offset, fixed per item)
+  int x_split, x_lo, dy_split, dy_lo;
 };
+
+// byte offset, inside a pixel's row, of the 8 channels c0 + 8 chunk .. of a 16-bit tensor (plain, or one half of a split one)
+__device__ __forceinline__ unsigned wg_chunk_off(int c0, int chunk, int split, int lo) {
+  const int ch = c0 + 8 * chunk;
+  return split ? (unsigned)((((ch >> 5) << 6) + (ch & 31) + (lo << 5)) * 2) : (unsigned)(ch * 2);
+}
 
 struct WTraitsBF16 {
   static constexpr int ES = 2, KP = 64;
@@ -130,7 +140,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 1) void conv_wgrad_kernel(
 #pragma unroll
   for (int j = 0; j < NIG; ++j) {
     const int R = (wave * NIG + j) * RPG + g_rowin;
-    goff[j] = (unsigned)(R * (int)a.dy_pix_bytes + co0 * ES + ((g_pos ^ row_swz<ES, RBG>(R)) << 4));
+    if constexpr (ES == 2) goff[j] = (unsigned)(R * (int)a.dy_pix_bytes) + wg_chunk_off(co0, g_pos ^ row_swz<ES, RBG>(R), a.dy_split, a.dy_lo);
+    else goff[j] = (unsigned)(R * (int)a.dy_pix_bytes + co0 * ES + ((g_pos ^ row_swz<ES, RBG>(R)) << 4));
   }
   int xn[NIX], xp[NIX], xq[NIX];
   unsigned xchunk[NIX];
@@ -142,7 +153,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 1) void conv_wgrad_kernel(
     const uint32_t rem = m - n * a.div_hw.d;
     const uint32_t p = fdiv(rem, a.div_w);
     xn[j] = (int)n; xp[j] = (int)p; xq[j] = (int)(rem - p * a.div_w.d);
-    xchunk[j] = (unsigned)(ci0 * ES + ((x_pos ^ row_swz<ES, RBX>(R)) << 4));
+    if constexpr (ES == 2) xchunk[j] = wg_chunk_off(ci0, x_pos ^ row_swz<ES, RBX>(R), a.x_split, a.x_lo);
+    else xchunk[j] = (unsigned)(ci0 * ES + ((x_pos ^ row_swz<ES, RBX>(R)) << 4));
   }
   const int n_img = a.M / (a.Ho * a.Wo);
 
@@ -396,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
 #pragma unroll
       for (int j = 0; j < NIG; ++j) {
         const int R = (wave * NIG + j) * RPG + g_rowin;
-        goff[j] = (unsigned)(R * (int)a.dy_pix_bytes + tco * BCO * ES + ((g_pos ^ row_swz<ES, RBG>(R)) << 4));
+        goff[j] = (unsigned)(R * (int)a.dy_pix_bytes) + wg_chunk_off(tco * BCO, g_pos ^ row_swz<ES, RBG>(R), a.dy_split, a.dy_lo);
       }
 #pragma unroll
       for (int j = 0; j < NIX; ++j) {
@@ -409,7 +421,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
           xn[j] = (int)n; xp[j] = (int)p; xq[j] = (int)(rem - p * a.div_w.d);
           if constexpr (XM == 1) { xp[j] += dy_off; xq[j] += dx_off; }  // the SHIFTED coordinates are what is tracked and tested
         }
-        xchunk[j] = (unsigned)(tci * BCI * ES + ((x_pos ^ row_swz<ES, RBX>(R)) << 4));
+        xchunk[j] = wg_chunk_off(tci * BCI, x_pos ^ row_swz<ES, RBX>(R), a.x_split, a.x_lo);
         if constexpr (XM >= 1) xchunk[j] += (unsigned)(R * (int)a.x_pix_bytes);  // the lane's constant row offset
       }
       if constexpr (XM == 3) {
@@ -1126,7 +1138,7 @@ static bool use_wgrad_ws2(int esize, long long M, int cout, int cin, int taps) {
 template <typename Tr, bool DET = false>
 int dispatch_wgrad(const WgradArgs& a, hipStream_t s) {
   if constexpr (Tr::ES == 2) {
-    if (use_wgrad256(Tr::ES, a.M, a.cout, a.cin, a.taps, a.tpb, a.stride, a.W)) return launch_wgrad256<Tr, DET>(a, s);
+    if (!a.x_split && use_wgrad256(Tr::ES, a.M, a.cout, a.cin, a.taps, a.tpb, a.stride, a.W)) return launch_wgrad256<Tr, DET>(a, s);
     if (use_wgrad_ws2(Tr::ES, a.M, a.cout, a.cin, a.taps)) return launch_wgrad_ws2<Tr, DET>(a, s);
   }
   const bool co128 = a.cout % 128 == 0, ci128 = a.cin % 128 == 0;
@@ -1139,7 +1151,7 @@ int dispatch_wgrad(const WgradArgs& a, hipStream_t s) {
 // Pixel ranges (split-K parts) the dispatcher will cut this problem into: the same plan functions the launchers use.
 template <typename Tr>
 long long wgrad_live_ranges(WgradArgs a) {
-  if (use_wgrad256(Tr::ES, a.M, a.cout, a.cin, a.taps, a.tpb, a.stride, a.W)) return plan_wgrad256(a);
+  if (!a.x_split && use_wgrad256(Tr::ES, a.M, a.cout, a.cin, a.taps, a.tpb, a.stride, a.W)) return plan_wgrad256(a);
   if (use_wgrad_ws2(Tr::ES, a.M, a.cout, a.cin, a.taps)) return plan_wgrad_ws2(a);
   const bool co128 = a.cout % 128 == 0, ci128 = a.cin % 128 == 0;
   if (co128 && ci128) return plan_wgrad<Tr, 128, 128>(a);
@@ -1175,13 +1187,32 @@ int fill_wgrad_args(const ps_conv_geom* g, const void* x, const void* dy, float*
   a.part_stride = (long long)a.cout * a.taps * a.cin;
   a.vtab = nullptr;
   a.vperiod = 1;
+  a.x_split = a.dy_split = ps_planes(g->dtype) == 2;
+  a.x_lo = a.dy_lo = 0;
   return PS_OK;
 }
 
+// the 16-bit type whose kernels serve a geometry (split formats: their plane type)
+int base_dtype(int dtype) { return dtype == PS_BF16X3 ? PS_BF16 : dtype == PS_F16X3 ? PS_F16 : dtype; }
+
 long long live_ranges_of(const ps_conv_geom* g, const WgradArgs& a) {
-  if (g->dtype == PS_BF16) return wgrad_live_ranges<WTraitsBF16>(a);
-  if (g->dtype == PS_F16) return wgrad_live_ranges<WTraitsF16>(a);
+  const int dt = base_dtype(g->dtype);
+  if (dt == PS_BF16) return wgrad_live_ranges<WTraitsBF16>(a);
+  if (dt == PS_F16) return wgrad_live_ranges<WTraitsF16>(a);
   return wgrad_live_ranges<WTraitsF32>(a);
+}
+
+// the launches of one weight gradient: one for the plain types; x_hi dy_hi, x_hi dy_lo, x_lo dy_hi for the split ones (all accumulate into dw)
+template <typename F>
+int for_each_plane_pair(const ps_conv_geom* g, WgradArgs& a, F&& launch) {
+  if (ps_planes(g->dtype) == 1) return launch(a);
+  static const int pairs[3][2] = {{0, 0}, {0, 1}, {1, 0}};
+  for (const auto& pr : pairs) {
+    a.x_lo = pr[0];
+    a.dy_lo = pr[1];
+    if (int rc = launch(a)) return rc;
+  }
+  return PS_OK;
 }
 
 }  // namespace
@@ -1202,7 +1233,9 @@ void ps_debug_reset_wgrad(void) {
 extern "C" int ps_conv_wgrad_variant(const ps_conv_geom* g) {
   if (!g || !ps_conv_supported(g)) return -1;
   const long long ho = (g->h - 1) / g->stride + 1, wo = (g->w - 1) / g->stride + 1;
-  if (use_wgrad256(ps_esize(g->dtype), (long long)g->n * ho * wo, g->cout, g->cin, g->ksize * g->ksize, g->tiles_per_block, g->stride, g->w)) return 2;
+  if (ps_planes(g->dtype) == 1 &&
+      use_wgrad256(ps_esize(g->dtype), (long long)g->n * ho * wo, g->cout, g->cin, g->ksize * g->ksize, g->tiles_per_block, g->stride, g->w))
+    return 2;
   return use_wgrad_ws2(ps_esize(g->dtype), (long long)g->n * ho * wo, g->cout, g->cin, g->ksize * g->ksize) ? 1 : 0;
 }
 
@@ -1212,9 +1245,12 @@ extern "C" int ps_conv2d_wgrad(const ps_conv_geom* g, const void* x, const void*
   WgradArgs a{};
   if (int rc = fill_wgrad_args(g, x, dy, dw, a, "conv2d_wgrad")) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (g->dtype == PS_BF16) return dispatch_wgrad<WTraitsBF16>(a, s);
-  if (g->dtype == PS_F16) return dispatch_wgrad<WTraitsF16>(a, s);
-  return dispatch_wgrad<WTraitsF32>(a, s);
+  const int dt = base_dtype(g->dtype);
+  return for_each_plane_pair(g, a, [&](const WgradArgs& b) -> int {
+    if (dt == PS_BF16) return dispatch_wgrad<WTraitsBF16>(b, s);
+    if (dt == PS_F16) return dispatch_wgrad<WTraitsF16>(b, s);
+    return dispatch_wgrad<WTraitsF32>(b, s);
+  });
 }
 
 extern "C" int64_t ps_conv2d_wgrad_det_workspace_bytes(const ps_conv_geom* g) {
@@ -1232,11 +1268,14 @@ extern "C" int ps_conv2d_wgrad_det(const ps_conv_geom* g, const void* x, const v
   if (int rc = fill_wgrad_args(g, x, dy, dw, a, "conv2d_wgrad_det")) return rc;
   const long long live = live_ranges_of(g, a);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const int dt = base_dtype(g->dtype);
   if (live <= 1) {
-    // one pixel range: every element of dw receives exactly ONE addition, which is the same in every run -- the atomic kernels as they are
-    if (g->dtype == PS_BF16) return dispatch_wgrad<WTraitsBF16>(a, s);
-    if (g->dtype == PS_F16) return dispatch_wgrad<WTraitsF16>(a, s);
-    return dispatch_wgrad<WTraitsF32>(a, s);
+    // one pixel range: every element of dw receives exactly ONE addition per launch, in launch order -- the atomic kernels as they are
+    return for_each_plane_pair(g, a, [&](const WgradArgs& b) -> int {
+      if (dt == PS_BF16) return dispatch_wgrad<WTraitsBF16>(b, s);
+      if (dt == PS_F16) return dispatch_wgrad<WTraitsF16>(b, s);
+      return dispatch_wgrad<WTraitsF32>(b, s);
+    });
   }
   const long long need = live * a.part_stride * 4;
   PS_REQUIRE(workspace && ps_aligned16(workspace) && workspace_bytes >= need,
@@ -1244,14 +1283,17 @@ extern "C" int ps_conv2d_wgrad_det(const ps_conv_geom* g, const void* x, const v
              (long long)workspace_bytes, workspace);
   PS_REQUIRE(a.part_stride * 4 < (1LL << 31), "conv2d_wgrad_det: weight tensor larger than 2 GiB");
   a.part = static_cast<float*>(workspace);
-  int rc;
-  if (g->dtype == PS_BF16) rc = dispatch_wgrad<WTraitsBF16, true>(a, s);
-  else if (g->dtype == PS_F16) rc = dispatch_wgrad<WTraitsF16, true>(a, s);
-  else rc = dispatch_wgrad<WTraitsF32, true>(a, s);
-  if (rc != PS_OK) return rc;
-  const long long n4 = a.part_stride / 4;  // cin is a multiple of 32: whole float4s
-  const unsigned blocks = (unsigned)std::min<long long>((n4 + 255) / 256, 8LL * ps_num_cus());
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.part, dw, n4, (int)live, n4);
-  PS_CHECK_LAUNCH("wgrad_reduce");
-  return PS_OK;
+  // (split types: each of the three launches fills the workspace and is reduced into dw before the next one reuses it)
+  return for_each_plane_pair(g, a, [&](const WgradArgs& b) -> int {
+    int rc;
+    if (dt == PS_BF16) rc = dispatch_wgrad<WTraitsBF16, true>(b, s);
+    else if (dt == PS_F16) rc = dispatch_wgrad<WTraitsF16, true>(b, s);
+    else rc = dispatch_wgrad<WTraitsF32, true>(b, s);
+    if (rc != PS_OK) return rc;
+    const long long n4 = b.part_stride / 4;  // cin is a multiple of 32: whole float4s
+    const unsigned blocks = (unsigned)std::min<long long>((n4 + 255) / 256, 8LL * ps_num_cus());
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, b.part, dw, n4, (int)live, n4);
+    PS_CHECK_LAUNCH("wgrad_reduce");
+    return (int)PS_OK;
+  });
 }

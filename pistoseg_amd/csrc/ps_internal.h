@@ -69,9 +69,9 @@ static inline unsigned ps_persistent_grid(long long nitems, int nb, int tpb) {
 
 static inline int ps_esize(int dtype) { return dtype == PS_F32 ? 4 : 2; }
 static inline bool ps_dtype_ok(int dtype) { return dtype == PS_F32 || dtype == PS_BF16 || dtype == PS_F16; }
-// the convolutions (forward / data gradient) also take the split-bf16 format; ps_planes = stored bf16 planes per logical channel
+// the convolutions also take the split 16-bit formats; ps_planes = stored 16-bit values per logical channel (hi + lo)
 static inline bool ps_conv_dtype_ok(int dtype) { return ps_dtype_ok(dtype) || dtype == PS_BF16X3 || dtype == PS_F16X3; }
-static inline int ps_planes(int dtype) { return (dtype == PS_BF16X3 || dtype == PS_F16X3) ? 3 : 1; }
+static inline int ps_planes(int dtype) { return (dtype == PS_BF16X3 || dtype == PS_F16X3) ? 2 : 1; }
 static inline bool ps_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- device helpers -------------------------------------------------------------------------

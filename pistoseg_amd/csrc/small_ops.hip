@@ -998,8 +998,8 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // Row-wise format conversion between f32 and the activation / weight storage formats: rows of c logical channels, 8 per thread,
 // arbitrary row pitches (channel slices of wider buffers).  f32 -> {bf16, f16, split}; {bf16, f16, split} -> f32.
-// Split (PS_BF16X3 / PS_F16X3): three bf16 / fp16 planes of c channels per row; pattern 0 = [hi | lo | hi] (activations), 1 = [hi | hi | lo] (weights);
-// hi = bf16(v) RNE, lo = bf16(v - hi); reading back: hi + lo (the lo plane is plane 1 or 2 by pattern).
+// Split (PS_BF16X3 / PS_F16X3): 2 c stored 16-bit channels per row in blocks of 32 logical channels, [hi(32) | lo(32)]; hi = round16(v) RNE,
+// lo = round16(v - hi); reading back: hi + lo.  Activations and weights share the layout (`pattern` is accepted and ignored).
 // ------------------------------------------------------------------------------------------------
 template <int SRC, int DST>
 __global__ __launch_bounds__(256) void convert_rows_kernel(const unsigned char* __restrict__ src, long long ld_src, unsigned char* __restrict__ dst,
@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(const unsigned char* 
   const long long total = rows * c8;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long r = i / c8;
-    const int c = (int)(i - r * c8) * 8, cch = c8 * 8;
+    const int c = (int)(i - r * c8) * 8;
     float v[8];
     if constexpr (SRC == PS_F32) {
       ps_load8<float>(reinterpret_cast<const float*>(src) + r * ld_src + c, v);
@@ -1017,10 +1017,10 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(const unsigned char* 
       ps_load8<_Float16>(reinterpret_cast<const _Float16*>(src) + r * ld_src + c, v);
     } else {
       typedef typename std::conditional<SRC == PS_F16X3, _Float16, __bf16>::type PT;
-      const PT* p = reinterpret_cast<const PT*>(src) + r * ld_src + c;
+      const PT* p = reinterpret_cast<const PT*>(src) + r * ld_src + ((c >> 5) << 6) + (c & 31);
       float lo[8];
       ps_load8<PT>(p, v);
-      ps_load8<PT>(p + (pattern ? 2 : 1) * cch, lo);
+      ps_load8<PT>(p + 32, lo);
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] += lo[k];
     }
@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(const unsigned char* 
       ps_store8<_Float16>(reinterpret_cast<_Float16*>(dst) + r * ld_dst + c, v);
     } else {
       typedef typename std::conditional<DST == PS_F16X3, _Float16, __bf16>::type PT;
-      PT* p = reinterpret_cast<PT*>(dst) + r * ld_dst + c;
+      PT* p = reinterpret_cast<PT*>(dst) + r * ld_dst + ((c >> 5) << 6) + (c & 31);
       float hi[8], lo[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -1040,8 +1040,7 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(const unsigned char* 
         lo[k] = v[k] - hi[k];
       }
       ps_store8<PT>(p, hi);
-      ps_store8<PT>(p + cch, pattern ? hi : lo);
-      ps_store8<PT>(p + 2 * cch, pattern ? lo : hi);
+      ps_store8<PT>(p + 32, lo);
     }
   }
 }
@@ -1053,6 +1052,7 @@ extern "C" int ps_convert_rows(const void* src, int32_t src_fmt, int64_t ld_src,
   PS_REQUIRE((src_fmt == PS_F32) != (dst_fmt == PS_F32), "convert_rows: exactly one side must be f32 (got %d -> %d)", src_fmt, dst_fmt);
   PS_REQUIRE(ps_conv_dtype_ok(src_fmt) && ps_conv_dtype_ok(dst_fmt) && (pattern == 0 || pattern == 1), "convert_rows: bad format / pattern");
   PS_REQUIRE(c % 8 == 0 && ld_src >= ps_planes(src_fmt) * (int64_t)c && ld_dst >= ps_planes(dst_fmt) * (int64_t)c, "convert_rows: c=%d must be a multiple of 8 and fit the pitches", c);
+  PS_REQUIRE((ps_planes(src_fmt) == 1 && ps_planes(dst_fmt) == 1) || c % 32 == 0, "convert_rows: split formats store blocks of 32 channels (c=%d)", c);
   PS_REQUIRE(ps_aligned16(src) && ps_aligned16(dst) && (ld_src * ps_esize(src_fmt)) % 16 == 0 && (ld_dst * ps_esize(dst_fmt)) % 16 == 0, "convert_rows: misaligned");
   if (rows == 0) return PS_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -127,9 +127,12 @@ def _geom(spec: ConvSpec, dtype: int, n: int, h: int, w: int, ldc_x: int, ldc_y:
     return ConvGeom(dtype, n, h, w, spec.cin, spec.cout, spec.ksize, spec.stride, spec.dilation, ldc_x, ldc_y, int(tpb), int(shared), int(reserved))
 
 
+SPLIT_WIDTH = 2  # stored 16-bit channels per logical channel of a split tensor (hi + lo)
+
+
 def _conv_dt(t: Tensor, split: bool) -> int:
-    """C-ABI dtype of a conv launch on activation tensor t: `split` marks bf16 / fp16 tensors holding the three planes [hi | lo | hi]
-    (PS_BF16X3 / PS_F16X3)."""
+    """C-ABI dtype of a conv launch on activation tensor t: `split` marks bf16 / fp16 tensors in the split layout (PS_BF16X3 / PS_F16X3: 2 C
+    stored channels, blocks of 32 logical channels as [hi(32) | lo(32)])."""
     if split:
         assert t.dtype in (torch.bfloat16, torch.float16), "split tensors are bf16 or fp16 planes"
         return PS_BF16X3 if t.dtype == torch.bfloat16 else PS_F16X3
@@ -156,10 +159,10 @@ def _epilogue(mode=PS_EPI_NONE, add0=None, out_raw=None, scale=None, shift=None,
 def conv2d_fwd(spec: ConvSpec, x: Tensor, w_fwd: Tensor, *, add0=None, out_raw=None, bn_scale=None, bn_shift=None, drop=None,
                out_act=None, relu=False, split: bool = False, opts: Optional[LaunchOpts] = None) -> None:
     """y = conv(x, W) [+ add0]; out_raw <- y; out_act <- max(y*scale+shift, 0)*drop (if out_act given).
-    split: every activation tensor holds three bf16 planes per logical channel and w_fwd is [cout][taps][3 cin] (PS_BF16X3)."""
+    split: every activation tensor is in the split layout (2 stored channels per logical one) and w_fwd is [cout][taps][2 cin] (PS_BF16X3 / PS_F16X3)."""
     _require_gpu(x, w_fwd)
     n, h, w, c = x.shape
-    pl = 3 if split else 1
+    pl = SPLIT_WIDTH if split else 1
     assert c == pl * spec.cin and w_fwd.numel() == pl * spec.cout * spec.cin * spec.ksize**2 and w_fwd.dtype == x.dtype
     mode = PS_EPI_BNRELU if out_act is not None else PS_EPI_NONE
     ref = out_act if out_act is not None else out_raw
@@ -178,7 +181,7 @@ def conv2d_dgrad(spec: ConvSpec, dy: Tensor, w_dgrad: Tensor, x_hw, *, add0=None
     _require_gpu(dy, w_dgrad)
     n = dy.shape[0]
     h, w = x_hw
-    assert dy.shape[3] == (3 if split else 1) * spec.cout and tuple(dy.shape[1:3]) == spec.out_hw(h, w) and w_dgrad.dtype == dy.dtype
+    assert dy.shape[3] == (SPLIT_WIDTH if split else 1) * spec.cout and tuple(dy.shape[1:3]) == spec.out_hw(h, w) and w_dgrad.dtype == dy.dtype
     mode = PS_EPI_RELUBWD if out is not None else PS_EPI_NONE
     ref = out if out is not None else out_raw
     g = _geom(spec, _conv_dt(dy, split), n, h, w, _ldc(ref), _ldc(dy), opts)
@@ -260,25 +263,20 @@ def release_workspaces() -> None:
 
 
 def conv2d_wgrad(spec: ConvSpec, x: Tensor, dy: Tensor, dw: Tensor, deterministic: Optional[bool] = None, split: bool = False,
-                 opts: Optional[LaunchOpts] = None, _flops_share: float = 1.0) -> None:
+                 opts: Optional[LaunchOpts] = None) -> None:
     """dw[cout][kh][kw][cin] (f32, channels-last OIHW storage) += sum_pixels dy * x@tap.  deterministic (default: opts.deterministic, then the
     module switch DETERMINISTIC): no atomics, bit-identical from run to run.
-    split: x / dy hold the planes [hi | lo | hi]: dw += x_hi dy_hi + x_hi dy_lo + x_lo dy_hi as three bf16 launches on plane slices (the weight
-    gradient contracts over PIXELS, so the planes cannot ride along the K axis as they do in the forward / data-gradient kernels)."""
-    if split:
-        ci, co = spec.cin, spec.cout
-        assert x.shape[3] == 3 * ci and dy.shape[3] == 3 * co
-        for xs, ds in ((x[..., :ci], dy[..., :co]), (x[..., :ci], dy[..., co:2 * co]), (x[..., ci:2 * ci], dy[..., :co])):
-            conv2d_wgrad(spec, xs, ds, dw, deterministic, False, opts, _flops_share=1.0 / 3.0)  # (each carries a third of the algorithmic FLOPs)
-        return
+    split: x / dy are split tensors: dw += x_hi dy_hi + x_hi dy_lo + x_lo dy_hi, three launches of the 16-bit kernels inside the one C-ABI call
+    (the weight gradient contracts over PIXELS, so hi and lo cannot share a K-line as they do in the forward / data-gradient kernels)."""
     _require_gpu(x, dy, dw)
     n, h, w, c = x.shape
-    assert c == spec.cin and dy.shape[3] == spec.cout and dw.dtype == torch.float32 and x.dtype == dy.dtype
+    pl = SPLIT_WIDTH if split else 1
+    assert c == pl * spec.cin and dy.shape[3] == pl * spec.cout and dw.dtype == torch.float32 and x.dtype == dy.dtype
     assert dw.numel() == spec.cout * spec.cin * spec.ksize**2
-    g = _geom(spec, _dt(x), n, h, w, _ldc(x), _ldc(dy), opts)
+    g = _geom(spec, _conv_dt(x, split), n, h, w, _ldc(x), _ldc(dy), opts)
     lib = _lib.load()
     mo = n * dy.shape[1] * dy.shape[2]
-    flops = 2.0 * mo * spec.cout * spec.cin * spec.ksize**2 * _flops_share
+    flops = 2.0 * mo * spec.cout * spec.cin * spec.ksize**2  # (algorithmic)
     if deterministic is None and opts is not None:
         deterministic = opts.deterministic
     if deterministic_enabled(deterministic):
@@ -330,8 +328,8 @@ def copy_rows(src: Tensor, dst: Tensor) -> None:
 
 def convert_rows(src: Tensor, dst: Tensor, c: int, *, src_split: bool = False, dst_split: bool = False, weights: bool = False) -> None:
     """Row-wise conversion between f32 and a storage format (ps_convert_rows): src / dst are [..., C'] views with unit channel stride whose
-    leading dims are densely packed rows of pitch stride(-2); c = logical channels.  f32 -> bf16 / fp16 / split planes and back.
-    weights: the split layout is [hi | hi | lo] (weights) instead of [hi | lo | hi] (activations)."""
+    leading dims are densely packed rows of pitch stride(-2); c = logical channels.  f32 -> bf16 / fp16 / split layout and back.
+    (weights: kept for call-site readability; activations and weights share the split layout.)"""
     _require_gpu(src, dst)
     assert src.stride(-1) == 1 and dst.stride(-1) == 1
     rows = src.numel() // src.shape[-1]
@@ -349,7 +347,7 @@ def convert_rows(src: Tensor, dst: Tensor, c: int, *, src_split: bool = False, d
 
     sf = _conv_dt(src, True) if src_split else _dt(src)
     df = _conv_dt(dst, True) if dst_split else _dt(dst)
-    assert src.shape[-1] == (3 if src_split else 1) * c and dst.shape[-1] == (3 if dst_split else 1) * c
+    assert src.shape[-1] == (SPLIT_WIDTH if src_split else 1) * c and dst.shape[-1] == (SPLIT_WIDTH if dst_split else 1) * c
     lib = _lib.load()
     _lib.check(lib.ps_convert_rows(src.data_ptr(), sf, pitch(src), dst.data_ptr(), df, pitch(dst), rows, c, int(weights), _stream()), "ps_convert_rows")
 

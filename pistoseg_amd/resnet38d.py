@@ -7,9 +7,10 @@ nn.BatchNorm2d children are *parameter holders only*: the arithmetic runs as a f
 launches (pistoseg_amd/ops.py -> libpistoseg_hip.so):
 
   * activations are channels-last [N,H,W,C] in the compute dtype (bf16 / fp16, or f32 for the exact parity path) -- or, with
-    precision="bf16x3", SPLIT bf16: three planes [hi | lo | hi] of C channels per pixel (value = hi + lo, 16 mantissa bits) against
-    weights split [hi | hi | lo], so that the same 16-bit MFMA kernels compute x_hi w_hi + x_lo w_hi + x_hi w_lo with f32 accumulation:
-    the reference's fp32 results (resnet38d.py:156-188) to 1e-4 at a third of the bf16 rate instead of a sixteenth (exact-f32 MFMA);
+    precision="bf16x3", SPLIT bf16: value = hi + lo (16 significant bits), stored as 2 C bf16 channels per pixel in blocks of 32 logical
+    channels [hi(32) | lo(32)], weights alike; the 16-bit MFMA kernels stage them like plain tensors and multiply every K-line three
+    times (x_hi w_hi + x_hi w_lo + x_lo w_hi, f32 accumulation): the reference's fp32 results (resnet38d.py:156-188) to 1e-4 at a
+    third of the bf16 MFMA work instead of sixteen times (exact-f32 MFMA);
     precision="fp16x3" is the same on fp16 planes (22 instead of 16 significant bits per value, fp16's range, loss-scaled gradients);
   * every conv writes, from its epilogue, the NEXT BatchNorm+ReLU(+Dropout2d) already applied, plus the raw
     residual stream only where an identity shortcut will read it (pre-activation net: BN/ReLU are
@@ -109,8 +110,8 @@ class Net(nn.Module):
         super().__init__()
         assert precision in ("bf16", "fp16", "fp32", "bf16x3", "fp16x3")
         self.precision = precision
-        self.split = precision in ("bf16x3", "fp16x3")  # activations / gradients as bf16 planes [hi | lo | hi] (ops.conv2d_fwd(split=True), PS_BF16X3)
-        self.cm = 3 if self.split else 1    # stored channels per logical channel
+        self.split = precision in ("bf16x3", "fp16x3")  # activations / gradients in the split layout (ops.conv2d_fwd(split=True), PS_BF16X3 / PS_F16X3)
+        self.cm = ops.SPLIT_WIDTH if self.split else 1  # stored channels per logical channel
         self.launch = ops.LaunchOpts()      # this model's launch options (tiles_per_block / gpu_shared / deterministic), passed to every conv launch
         # measurement hook (bench.py's instrumented step): run a ONE-stream backward with the launch schedule of the two-stream one (gpu_shared set
         # for the backward's duration), so that per-kernel times are exclusive AND describe the dispatches of the timed step
@@ -218,12 +219,12 @@ class Net(nn.Module):
         assert flat.is_contiguous()
         if self.precision == "fp32" or f32:
             return flat
-        if self.split:  # [cout][kh][kw][hi | hi | lo] of cin channels each, re-derived from the f32 master whenever it changed
+        if self.split:  # [cout][kh][kw][cin in the split layout], re-derived from the f32 master whenever it changed
 
             def make_split():
                 cout, kh, kw, cin = flat.shape
-                out = torch.empty((cout, kh, kw, 3 * cin), device=w.device, dtype=self.compute_dtype)
-                ops.convert_rows(flat.reshape(cout * kh * kw, cin), out.view(cout * kh * kw, 3 * cin), cin, dst_split=True, weights=True)
+                out = torch.empty((cout, kh, kw, self.cm * cin), device=w.device, dtype=self.compute_dtype)
+                ops.convert_rows(flat.reshape(cout * kh * kw, cin), out.view(cout * kh * kw, self.cm * cin), cin, dst_split=True, weights=True)
                 return out
 
             return self._cached("wf:" + key, (w,), make_split)
@@ -249,15 +250,15 @@ class Net(nn.Module):
         w = conv.weight
         cout, cin, k, _ = w.shape
         if (f32 and self.precision != "fp32") or self.split:
-            # transposed in f32, then (split path) cut into planes [hi | hi | lo] along cout; re-derived lazily when the master changes
+            # transposed in f32, then (split path) split along cout; re-derived lazily when the master changes
 
             def make_f32():
                 t = torch.empty((cin, k, k, cout), device=w.device, dtype=torch.float32)
                 ops.weight_transpose(self.w_fwd(conv, key, f32=True), t, cout, k * k, cin)
                 if f32:
                     return t
-                out = torch.empty((cin, k, k, 3 * cout), device=w.device, dtype=self.compute_dtype)
-                ops.convert_rows(t.view(cin * k * k, cout), out.view(cin * k * k, 3 * cout), cout, dst_split=True, weights=True)
+                out = torch.empty((cin, k, k, self.cm * cout), device=w.device, dtype=self.compute_dtype)
+                ops.convert_rows(t.view(cin * k * k, cout), out.view(cin * k * k, self.cm * cout), cout, dst_split=True, weights=True)
                 return out
 
             return self._cached(("wd32:" if f32 else "wd:") + key, (w,), make_f32)
@@ -298,7 +299,7 @@ class Net(nn.Module):
         cout, cin, c2 = w1.shape[0], w1.shape[1], w2.shape[1]
 
         def make():
-            m = self.cm  # (split path: [hi | hi | lo] of conv_branch1, then [hi | hi | lo] of conv_branch2b2 -- the order of the activation planes)
+            m = self.cm  # (split path: conv_branch1's split channels, then conv_branch2b2's -- the order of the activation buffer [a | a3])
             out = torch.empty((cout, m * (cin + c2)), device=w1.device, dtype=self.compute_dtype)
             ops.copy_rows(self.w_fwd(unit.conv_branch1, name + ".conv_branch1").reshape(cout, m * cin), out[:, :m * cin])
             ops.copy_rows(self.w_fwd(unit.conv_branch2b2, name + ".conv_branch2b2").reshape(cout, m * c2), out[:, m * cin:])
@@ -313,11 +314,12 @@ class Net(nn.Module):
         cout, cin, c4 = w1.shape[0], w1.shape[1], w2.shape[0]
 
         def make_split():
-            out = torch.empty((cin, 3 * (cout + c4)), device=w1.device, dtype=self.compute_dtype)
-            for conv, cname, lo, co in ((unit.conv_branch1, ".conv_branch1", 0, cout), (unit.conv_branch2a, ".conv_branch2a", 3 * cout, c4)):
+            m = self.cm
+            out = torch.empty((cin, m * (cout + c4)), device=w1.device, dtype=self.compute_dtype)
+            for conv, cname, lo, co in ((unit.conv_branch1, ".conv_branch1", 0, cout), (unit.conv_branch2a, ".conv_branch2a", m * cout, c4)):
                 t = torch.empty((cin, co), device=w1.device, dtype=torch.float32)
                 ops.weight_transpose(self.w_fwd(conv, name + cname, f32=True), t, co, 1, cin)
-                ops.convert_rows(t, out[:, lo:lo + 3 * co], co, dst_split=True, weights=True)
+                ops.convert_rows(t, out[:, lo:lo + m * co], co, dst_split=True, weights=True)
             return out
 
         if self.split:

@@ -84,7 +84,7 @@ class ResNet38dSeg(resnet38d.Net):
     def max_tiles_per_launch(self, h: int, w: int) -> int:
         """Largest batch one forward plan can take: its biggest tensor (conv1a's 64-channel output at full resolution) must stay
         below 2 GiB, the range of the kernels' buffer descriptors (ps_conv2d_fwd rejects larger problems)."""
-        esize = {"fp32": 4, "bf16x3": 6, "fp16x3": 6}.get(self.precision, 2)
+        esize = {"fp32": 4, "bf16x3": 4, "fp16x3": 4}.get(self.precision, 2)
         return max(1, ((1 << 31) - 1) // (h * w * 64 * esize))
 
     def new_grad_buffers(self, device) -> Dict[str, Tensor]:

@@ -1,5 +1,6 @@
-"""GPU parity of the split-bf16 ("bf16x3", PS_BF16X3) path: tensors stored as bf16 planes [hi | lo | hi] (value = hi + lo), weights as
-[hi | hi | lo], every product computed as x_hi w_hi + x_lo w_hi + x_hi w_lo on the 16-bit MFMA kernels with f32 accumulation.  It exists
+"""GPU parity of the split 16-bit paths ("bf16x3" / "fp16x3", PS_BF16X3 / PS_F16X3): a value is hi + lo, tensors and weights store blocks of 32
+logical channels as [hi(32) | lo(32)] (one 128-byte K-line), every product is x_hi w_hi + x_hi w_lo + x_lo w_hi on the 16-bit MFMA kernels with
+f32 accumulation.  It exists
 to meet the reference's fp32 arithmetic (models/resnet38d.py:156-188) -- north_star: fp32 logits within 1e-4 relative, mask indices
 bit-exact -- at 16-bit MFMA speed / 3 instead of the exact-f32 MFMA's 1/16.  Checked here against torch-CPU fp32 ops on the SAME
 split-representable operands (so only the dropped lo*lo term, accumulation order and the output's hi+lo rounding differ): 1e-4 relative
@@ -29,15 +30,17 @@ def split_repr(t, dt=BF):
 
 
 def planes(t, weights=False, dt=BF):
-    """f32 [..., C] -> 16-bit [..., 3C]: [hi | lo | hi] (activations) or [hi | hi | lo] (weights)."""
+    """f32 [..., C] -> 16-bit [..., 2C] in the split layout: blocks of 32 logical channels as [hi(32) | lo(32)] (activations and weights alike)."""
     hi = t.to(dt)
     lo = (t - hi.float()).to(dt)
-    return torch.cat([hi, hi, lo] if weights else [hi, lo, hi], dim=-1).contiguous()
+    sh, c = t.shape[:-1], t.shape[-1]
+    return torch.stack([hi.reshape(*sh, c // 32, 32), lo.reshape(*sh, c // 32, 32)], dim=-2).reshape(*sh, 2 * c).contiguous()
 
 
 def merge(p, weights=False):
-    c = p.shape[-1] // 3
-    return p[..., :c].float() + p[..., (2 * c if weights else c):(3 * c if weights else 2 * c)].float()
+    sh, c2 = p.shape[:-1], p.shape[-1]
+    b = p.reshape(*sh, c2 // 64, 2, 32).float()
+    return (b[..., 0, :] + b[..., 1, :]).reshape(*sh, c2 // 2)
 
 
 def nhwc(t):
@@ -52,15 +55,15 @@ def test_convert_rows_split_planes_and_casts(weights, dt):
     from pistoseg_amd import ops
 
     g = torch.Generator().manual_seed(11)
-    rows, c = 37, 72
+    rows, c = 37, 96
     src = torch.randn(rows, c, generator=g) * torch.logspace(-6, 6 if dt == BF else 3, rows).view(-1, 1)  # (fp16 planes: |v| <= 65504)
-    wide = torch.full((rows, 3 * c + 24), 7.0, dtype=dt, device=D)
-    ops.convert_rows(src.to(D), wide[:, 8:8 + 3 * c], c, dst_split=True, weights=weights)
-    assert torch.equal(wide[:, 8:8 + 3 * c].cpu(), planes(src, weights, dt))
-    assert bool((wide[:, :8] == 7.0).all()) and bool((wide[:, 8 + 3 * c:] == 7.0).all())  # nothing outside the slice is touched
+    wide = torch.full((rows, 2 * c + 24), 7.0, dtype=dt, device=D)
+    ops.convert_rows(src.to(D), wide[:, 8:8 + 2 * c], c, dst_split=True, weights=weights)
+    assert torch.equal(wide[:, 8:8 + 2 * c].cpu(), planes(src, weights, dt))
+    assert bool((wide[:, :8] == 7.0).all()) and bool((wide[:, 8 + 2 * c:] == 7.0).all())  # nothing outside the slice is touched
     if not weights:
         back = torch.empty(rows, c, device=D)
-        ops.convert_rows(wide[:, 8:8 + 3 * c], back, c, src_split=True)
+        ops.convert_rows(wide[:, 8:8 + 2 * c], back, c, src_split=True)
         assert torch.equal(back.cpu(), split_repr(src, dt))
         assert rel_err(back.cpu(), src) < 2.0 ** -16
         if dt == HF:  # 22 significant bits while lo is a normal fp16 number, 2^-25 absolute below
@@ -75,7 +78,7 @@ def test_convert_rows_split_planes_and_casts(weights, dt):
         assert torch.equal(up.cpu(), low.cpu().float())
 
 
-# (n, h, w, cin, cout, k, stride, dilation), which kernel family the geometry selects for the FORWARD (K is 3 cin wide on this path)
+# (n, h, w, cin, cout, k, stride, dilation), which kernel family the geometry selects for the FORWARD (split GEMMs stay on the wave-specialised kernel)
 SPLIT_CASES = [
     ((2, 13, 10, 64, 128, 3, 2, 1), None),      # small / ragged: the 4-wave kernels
     ((2, 13, 10, 128, 128, 3, 1, 1), None),
@@ -86,7 +89,7 @@ SPLIT_CASES = [
     ((17, 32, 32, 64, 512, 3, 1, 4), "halo"),   # 256-pixel tiles (maps of 256 x 256 inputs)
     ((37, 28, 28, 256, 512, 1, 1, 1), "ws2"),
     ((42, 56, 56, 128, 256, 3, 2, 1), "ws2"),   # stride-2 3x3: the data gradient runs as four parity-class launches
-    ((33, 28, 28, 704, 1024, 1, 1, 1), "gemm256"),  # K = 3 x 704 = 2112 >= 2048: the 256 x 256 tile GEMM kernel, ragged last pixel tile
+    ((33, 28, 28, 1024, 1024, 1, 1, 1), "ws2"),  # a GEMM the plain types send to conv_gemm256_kernel: split types keep the wave-specialised one
 ]
 
 
@@ -94,7 +97,7 @@ SPLIT_CASES = [
 @pytest.mark.parametrize("case,family", SPLIT_CASES)
 def test_split_conv_fwd_dgrad_wgrad_match_fp32_cpu(case, family, dt):
     """Forward with the full epilogue (residual add, raw output, BN + ReLU + dropout output), data gradient with the ReLU-mask epilogue and a
-    second addend, weight gradient (three bf16 launches on plane slices): all within 1e-4 of torch-CPU fp32 on the same split-representable
+    second addend, weight gradient (three launches of the 16-bit kernels on the hi / lo halves): all within 1e-4 of torch-CPU fp32 on the same split-representable
     operands (resnet38d.py:16-21,38-41,64,86)."""
     import ctypes as C
 
@@ -103,8 +106,8 @@ def test_split_conv_fwd_dgrad_wgrad_match_fp32_cpu(case, family, dt):
     n, h, w, cin, cout, k, s_, d = case
     spec = ops.ConvSpec(cin, cout, k, s_, d)
     if family is not None:
-        g_ = ops._geom(spec, _lib.PS_BF16X3 if dt == BF else _lib.PS_F16X3, n, h, w, 3 * cin, 3 * cout)
-        want = {"halo": (7,), "ws2": (4, 5), "gemm256": (8,)}[family]
+        g_ = ops._geom(spec, _lib.PS_BF16X3 if dt == BF else _lib.PS_F16X3, n, h, w, 2 * cin, 2 * cout)
+        want = {"halo": (7,), "ws2": (4, 5)}[family]
         assert int(_lib.load().ps_conv_variant(C.byref(g_), 0)) in want
     SR = lambda t: split_repr(t, dt)
     PL = lambda t, weights=False: planes(t, weights, dt)
@@ -126,21 +129,20 @@ def test_split_conv_fwd_dgrad_wgrad_match_fp32_cpu(case, family, dt):
 
     ho, wo = spec.out_hw(h, w)
     xd = PL(nhwc(x.detach())).to(D)
-    wf = PL(wt.detach().permute(0, 2, 3, 1).contiguous(), weights=True).to(D)  # [cout][kh][kw][hi | hi | lo]
-    wd = PL(wt.detach().permute(1, 2, 3, 0).contiguous(), weights=True).to(D)  # [cin][kh][kw][hi | hi | lo]
+    wf = PL(wt.detach().permute(0, 2, 3, 1).contiguous(), weights=True).to(D)  # [cout][kh][kw][cin, split]
+    wd = PL(wt.detach().permute(1, 2, 3, 0).contiguous(), weights=True).to(D)  # [cin][kh][kw][cout, split]
     nan = float("nan")
-    out_raw = torch.full((n, ho, wo, 3 * cout), nan, device=D, dtype=dt)
+    out_raw = torch.full((n, ho, wo, 2 * cout), nan, device=D, dtype=dt)
     # the activated output as a channel slice of a wider buffer (the fused bottleneck's [a | a3] layout)
-    wide = torch.full((n, ho, wo, 3 * cout + 3 * 64), nan, device=D, dtype=dt)
-    out_act = wide[..., 3 * 64:]
+    wide = torch.full((n, ho, wo, 2 * cout + 2 * 64), nan, device=D, dtype=dt)
+    out_act = wide[..., 2 * 64:]
     ops.conv2d_fwd(spec, xd, wf, add0=PL(nhwc(res)).to(D), out_raw=out_raw, bn_scale=scale.to(D), bn_shift=shift.to(D), drop=drop.to(D),
                    out_act=out_act, split=True)
     assert rel_err(merge(out_raw.cpu()), nhwc((y + res).detach())) < TOL
     assert rel_err(merge(out_act.cpu()), nhwc(act.detach())) < TOL
-    assert torch.equal(out_raw[..., :cout], out_raw[..., 2 * cout:])  # both hi planes written
-    assert bool(torch.isnan(wide[..., :3 * 64].float()).all())         # nothing outside the slice touched
+    assert bool(torch.isnan(wide[..., :2 * 64].float()).all())         # nothing outside the slice touched
     gyd = PL(nhwc(gy)).to(D)
-    gx = torch.full((n, h, w, 3 * cin), nan, device=D, dtype=dt)
+    gx = torch.full((n, h, w, 2 * cin), nan, device=D, dtype=dt)
     ops.conv2d_dgrad(spec, gyd, wd, (h, w), mask_src=PL(nhwc(mask_src)).to(D), bn_scale=sc2.to(D), add1=PL(nhwc(add1)).to(D), out=gx, split=True)
     assert rel_err(merge(gx.cpu()), nhwc(gx_ref)) < TOL
     dw = torch.zeros((cout, k, k, cin), device=D, dtype=torch.float32)
@@ -154,8 +156,8 @@ def test_split_conv_rejects_narrow_channel_strides():
     from pistoseg_amd import _lib, ops
 
     spec = ops.ConvSpec(64, 64, 1)
-    x = torch.zeros((1, 4, 4, 192), device=D, dtype=torch.bfloat16)
-    wf = torch.zeros((64, 1, 1, 192), device=D, dtype=torch.bfloat16)
-    y = torch.zeros((1, 4, 4, 64), device=D, dtype=torch.bfloat16)  # one plane only: must be refused, not overrun
+    x = torch.zeros((1, 4, 4, 128), device=D, dtype=torch.bfloat16)
+    wf = torch.zeros((64, 1, 1, 128), device=D, dtype=torch.bfloat16)
+    y = torch.zeros((1, 4, 4, 64), device=D, dtype=torch.bfloat16)  # room for the hi halves only: must be refused, not overrun
     with pytest.raises(_lib.PsError):
         ops.conv2d_fwd(spec, x, wf, out_raw=y, split=True)
