@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PS_VERSION 222 /* major*10000 + minor*100 + patch */
+#define PS_VERSION 223 /* major*10000 + minor*100 + patch */
 
 typedef enum ps_status {
   PS_OK = 0,
@@ -41,13 +41,13 @@ typedef enum ps_status {
 
 typedef enum ps_dtype {
   PS_F32 = 0, PS_BF16 = 1, PS_F16 = 2,
-  /* Split-bf16 ("bf16x3") -- convolutions only (ps_conv2d_fwd / ps_conv2d_dgrad; the weight gradient runs as three PS_BF16 launches on
-   * plane slices).  A tensor of C logical channels stores 3 C bf16 channels per pixel: planes [hi | lo | hi], hi = bf16(v),
-   * lo = bf16(v - hi), value = hi + lo (16 mantissa bits); channel strides count bf16 elements (>= 3 C).  Weights: W_fwd[cout][tap][3 cin]
-   * as [hi | hi | lo] per tap (ps_split_f32, pattern 1), likewise W_dgrad[cin][tap][3 cout].  The kernels contract the 3 C channels as ONE
-   * bf16 GEMM with f32 accumulation, i.e. every product is x_hi w_hi + x_lo w_hi + x_hi w_lo (relative error ~2^-16 instead of bf16's
-   * 2^-8 at 3 MFMAs per product): the path that meets the reference's fp32 results to 1e-4 (models/resnet38d.py:156-188 computes in fp32)
-   * at 16-bit MFMA speed / 3.  Epilogue tensors (add0, out_raw, mask_src, add1, out) are split tensors of `produced channels` planes. */
+  /* Split bf16 ("bf16x3") -- the convolutions only.  A value is hi + lo with hi = bf16(v), lo = bf16(v - hi) (16 significant bits).  A tensor of C
+   * logical channels (C % 32 == 0) stores 2 C bf16 channels per pixel in blocks of 32 logical channels, [hi(32) | lo(32)] = one 128-byte K-line;
+   * channel strides count stored elements (>= 2 C).  Weights W_fwd[cout][tap][2 cin], W_dgrad[cin][tap][2 cout] use the same layout along K
+   * (ps_convert_rows).  The forward / data-gradient kernels stage such tensors like plain bf16 ones and multiply every staged K-line three times
+   * (x_hi w_hi + x_hi w_lo + x_lo w_hi, f32 accumulation): relative error ~2^-16 per product instead of bf16's 2^-8, at 3 MFMAs per product and the
+   * staging of 2.  Epilogue tensors (add0, out_raw, mask_src, add1, out) are split tensors.  The weight gradient: see ps_conv_geom.wgrad_terms.
+   * The path that meets the reference's fp32 results to 1e-4 (models/resnet38d.py:156-188 computes in fp32) at a fraction of the exact-f32 MFMA's cost. */
   PS_BF16X3 = 3,
   /* The same scheme on fp16 planes: hi = fp16(v) (11 significant bits), lo = fp16(v - hi) -- 22 bits while lo stays a normal number
    * (|v| >= 2^-3), an absolute error of at most 2^-25 below that (the 16-bit MFMA keeps fp16 subnormals: tools/f16_denorm_probe.hip), against
@@ -89,6 +89,9 @@ typedef struct ps_conv_geom {
                             * the backward.  A persistent block that cannot become resident serialises its whole static share behind the others
                             * (+33 % on a training step beside a 16-CU kernel); with the reservation every block starts at once and the launch costs
                             * the ideal #CUs / (#CUs - reserved).  0 = all CUs.  Bit-identical results for every value. */
+  int32_t wgrad_terms;    /* ps_conv2d_wgrad[_det] on the split types only: 0 / 1 = dW from the hi halves (x_hi dy_hi: one launch of the 16-bit kernel);
+                            * 3 = + x_hi dy_lo + x_lo dy_hi (three launches).  The lo terms are 2^-8 (bf16) / 2^-11 (fp16) of a product and add up
+                            * incoherently over the pixels: 1.8e-4 of a flip-free step's gradient in fp16x3, nothing measurable at training sizes. */
 } ps_conv_geom;
 
 /* Epilogue applied to the f32 accumulator `acc` of every produced element (pixel m, channel c):

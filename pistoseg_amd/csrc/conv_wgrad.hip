@@ -1202,12 +1202,19 @@ long long live_ranges_of(const ps_conv_geom* g, const WgradArgs& a) {
   return wgrad_live_ranges<WTraitsF32>(a);
 }
 
-// the launches of one weight gradient: one for the plain types; x_hi dy_hi, x_hi dy_lo, x_lo dy_hi for the split ones (all accumulate into dw)
+// the launches of one weight gradient: one for the plain types; for the split ones x_hi dy_hi and, with wgrad_terms = 3, x_hi dy_lo and x_lo dy_hi
+// (all accumulate into dw).  Default: the hi halves only.  A lo term is 2^-8 (bf16) / 2^-11 (fp16) of its product and their sum over the pixels
+// is incoherent: measured on the CPU oracle's gradients, the two lo launches move a flip-free step's weight gradient by 1.8e-4 (fp16x3; bf16x3:
+// 3.2e-3 -> 3.5e-3, inside its own noise) and a real-size step's not at all (n = 24: 3.287e-4 vs 3.296e-4, the ReLU-boundary flips dominate) --
+// for 3 x the weight-gradient time (and the halves are gathered in 64-byte segments: 1.6 x slower per launch than contiguous rows).
 template <typename F>
 int for_each_plane_pair(const ps_conv_geom* g, WgradArgs& a, F&& launch) {
   if (ps_planes(g->dtype) == 1) return launch(a);
   static const int pairs[3][2] = {{0, 0}, {0, 1}, {1, 0}};
+  const int terms = g->wgrad_terms == 3 ? 3 : 1;  // ps_conv_geom.wgrad_terms: 0 (default) | 1 = x_hi dy_hi only, 3 = + x_hi dy_lo + x_lo dy_hi
+  int k = 0;
   for (const auto& pr : pairs) {
+    if (k++ >= terms) break;
     a.x_lo = pr[0];
     a.dy_lo = pr[1];
     if (int rc = launch(a)) return rc;

@@ -113,6 +113,8 @@ class LaunchOpts:
     # CUs left to a co-running kernel that holds them (an RCCL collective): the persistent kernels' grid and static schedule are sized for
     # the rest (ps_conv_geom.cus_reserved); set by dist.BucketedAllReduce(share="reserve") while buckets are in flight
     cus_reserved: Optional[int] = None
+    # split precisions: plane pairs the weight gradient multiplies (ps_conv_geom.wgrad_terms): None / 1 = hi halves only, 3 = all three terms
+    wgrad_terms: Optional[int] = None
 
 
 TILES_PER_BLOCK = 0  # module defaults (see LaunchOpts): read when a launch is ENQUEUED
@@ -124,7 +126,8 @@ def _geom(spec: ConvSpec, dtype: int, n: int, h: int, w: int, ldc_x: int, ldc_y:
     tpb = TILES_PER_BLOCK if opts is None or opts.tiles_per_block is None else opts.tiles_per_block
     shared = GPU_SHARED if opts is None or opts.gpu_shared is None else opts.gpu_shared
     reserved = CUS_RESERVED if opts is None or opts.cus_reserved is None else opts.cus_reserved
-    return ConvGeom(dtype, n, h, w, spec.cin, spec.cout, spec.ksize, spec.stride, spec.dilation, ldc_x, ldc_y, int(tpb), int(shared), int(reserved))
+    terms = 0 if opts is None or opts.wgrad_terms is None else opts.wgrad_terms
+    return ConvGeom(dtype, n, h, w, spec.cin, spec.cout, spec.ksize, spec.stride, spec.dilation, ldc_x, ldc_y, int(tpb), int(shared), int(reserved), int(terms))
 
 
 SPLIT_WIDTH = 2  # stored 16-bit channels per logical channel of a split tensor (hi + lo)
@@ -266,8 +269,9 @@ def conv2d_wgrad(spec: ConvSpec, x: Tensor, dy: Tensor, dw: Tensor, deterministi
                  opts: Optional[LaunchOpts] = None) -> None:
     """dw[cout][kh][kw][cin] (f32, channels-last OIHW storage) += sum_pixels dy * x@tap.  deterministic (default: opts.deterministic, then the
     module switch DETERMINISTIC): no atomics, bit-identical from run to run.
-    split: x / dy are split tensors: dw += x_hi dy_hi + x_hi dy_lo + x_lo dy_hi, three launches of the 16-bit kernels inside the one C-ABI call
-    (the weight gradient contracts over PIXELS, so hi and lo cannot share a K-line as they do in the forward / data-gradient kernels)."""
+    split: x / dy are split tensors: dw += x_hi dy_hi [+ x_hi dy_lo + x_lo dy_hi with opts.wgrad_terms = 3], launches of the 16-bit kernels on the
+    hi / lo halves inside the one C-ABI call (the weight gradient contracts over PIXELS, so hi and lo cannot share a K-line as they do in the
+    forward / data-gradient kernels; the lo terms are below the gradient's own noise: include/pistoseg_hip.h, ps_conv_geom.wgrad_terms)."""
     _require_gpu(x, dy, dw)
     n, h, w, c = x.shape
     pl = SPLIT_WIDTH if split else 1

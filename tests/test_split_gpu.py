@@ -146,8 +146,15 @@ def test_split_conv_fwd_dgrad_wgrad_match_fp32_cpu(case, family, dt):
     ops.conv2d_dgrad(spec, gyd, wd, (h, w), mask_src=PL(nhwc(mask_src)).to(D), bn_scale=sc2.to(D), add1=PL(nhwc(add1)).to(D), out=gx, split=True)
     assert rel_err(merge(gx.cpu()), nhwc(gx_ref)) < TOL
     dw = torch.zeros((cout, k, k, cin), device=D, dtype=torch.float32)
-    ops.conv2d_wgrad(spec, xd, gyd, dw, split=True)
+    ops.conv2d_wgrad(spec, xd, gyd, dw, split=True, opts=ops.LaunchOpts(wgrad_terms=3))
     assert rel_err(dw.cpu(), wt.grad.permute(0, 2, 3, 1)) < TOL
+    # the default: hi halves only -- exactly the gradient of the hi-rounded operands, i.e. 2^-8 (bf16) / 2^-11 (fp16) per product away from the full one
+    dw1 = torch.zeros_like(dw)
+    ops.conv2d_wgrad(spec, xd, gyd, dw1, split=True)
+    xh, gh = x.detach().to(dt).float(), gy.to(dt).float()
+    ref1 = torch.nn.grad.conv2d_weight(xh, wt.shape, gh, stride=s_, padding=pad, dilation=d)
+    assert rel_err(dw1.cpu(), ref1.permute(0, 2, 3, 1)) < TOL
+    assert rel_err(dw1.cpu(), wt.grad.permute(0, 2, 3, 1)) < (2e-2 if dt == BF else 2e-3)
     print(f"[split conv {str(dt)[6:]} {case}] raw {rel_err(merge(out_raw.cpu()), nhwc((y + res).detach())):.2e} act {rel_err(merge(out_act.cpu()), nhwc(act.detach())):.2e} "
           f"dgrad {rel_err(merge(gx.cpu()), nhwc(gx_ref)):.2e} wgrad {rel_err(dw.cpu(), wt.grad.permute(0, 2, 3, 1)):.2e}")
 
