@@ -49,7 +49,7 @@ typedef enum ps_dtype {
    * staging of 2.  Epilogue tensors (add0, out_raw, mask_src, add1, out) are split tensors.  The weight gradient: see ps_conv_geom.wgrad_terms.
    * The path that meets the reference's fp32 results to 1e-4 (models/resnet38d.py:156-188 computes in fp32) at a fraction of the exact-f32 MFMA's cost. */
   PS_BF16X3 = 3,
-  /* The same scheme on fp16 planes: hi = fp16(v) (11 significant bits), lo = fp16(v - hi) -- 22 bits while lo stays a normal number
+  /* The same layout and products with fp16 halves: hi = fp16(v) (11 significant bits), lo = fp16(v - hi) -- 22 bits while lo stays a normal number
    * (|v| >= 2^-3), an absolute error of at most 2^-25 below that (the 16-bit MFMA keeps fp16 subnormals: tools/f16_denorm_probe.hip), against
    * the bf16 split's 2^-16 relative.  Range is fp16's: |v| <= 65504, and gradients need the loss scale of the PS_F16 path. */
   PS_F16X3 = 4
@@ -172,8 +172,8 @@ typedef struct ps_wt_item {
 int ps_weight_transpose_batched(int32_t src_dtype, int32_t dst_dtype, int32_t n_items, const ps_wt_item* items, void* stream);
 /* Row-wise conversion between f32 and a storage format (exactly one side is PS_F32): rows of c logical channels (c % 8 == 0), pitches
  * ld_src / ld_dst in ELEMENTS of the respective side (channel slices of wider buffers are fine).  f32 -> PS_BF16 / PS_F16 (RNE cast),
- * f32 -> PS_BF16X3 (three bf16 planes of c channels: pattern 0 = [hi | lo | hi], the activation layout; pattern 1 = [hi | hi | lo], the weight
- * layout; hi = bf16(v), lo = bf16(v - hi)) and back (16-bit -> f32 exactly; split -> hi + lo).
+ * f32 -> PS_BF16X3 / PS_F16X3 (c % 32 == 0; 2 c stored 16-bit channels per row in blocks [hi(32) | lo(32)], hi = round16(v), lo = round16(v - hi);
+ * activations and weights alike, `pattern` is ignored and kept for ABI stability) and back (16-bit -> f32 exactly; split -> hi + lo).
  * replaces: nothing in the reference (it computes in fp32 throughout, models/resnet38d.py:156-188); this is the edge between the split /
  * 16-bit conv stack and the f32 head, loss and RFM kernels (models/revise_net.py:50-75), and the weight layout maker of the split path. */
 int ps_convert_rows(const void* src, int32_t src_fmt, int64_t ld_src, void* dst, int32_t dst_fmt, int64_t ld_dst, int64_t rows, int32_t c,
