@@ -211,6 +211,69 @@ __device__ __forceinline__ int ps_xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
+// ------------------------------------------------------------------------------------------------
+// In-kernel tile queue of the persistent kernels (launch option `tile_queue`).  The FIRST item of block b is static
+// (ps_xcd_remap(b, G): the first G items, exactly the first round of the static schedule); the R = nitems - G items behind them are
+// handed out by tickets.  They are cut into chunks of 32 consecutive items, chunk c belonging to CLASS c % 8 -- the items the static
+// schedule gives to the blocks that share `blockIdx % 8` (= an XCD and its L2) -- and every class has its own ticket counter: a
+// block draws from its own class while that lasts (same L2 locality as the static schedule, order of the raster kept) and then
+// steals from the others.  ctr[0..7]: tickets per class, ctr[8]: blocks that have left; the last block to leave zeroes all nine
+// (launches that share a counter block are ordered by their stream).
+// ONE wave of the block draws, one item ahead and without waiting: ps_q_draw_begin issues the atomic (and a look at all eight
+// counters) when an item starts, ps_q_resolve turns the returned ticket into an item several K-steps later and the wave publishes it
+// through an LDS mailbox in front of a block barrier; every other wave reads the mailbox behind that barrier.  The only blocking
+// memory operations are the steals (a class that looked non-empty), i.e. only where the static schedule would have left a CU idle.
+constexpr int PS_Q_CHUNK_SHIFT = 5;
+__device__ __forceinline__ int ps_q_count(int R, int x) {  // items of class x among the R queued items
+  const int r = (R & 255) - (x << PS_Q_CHUNK_SHIFT);
+  return ((R >> 8) << PS_Q_CHUNK_SHIFT) + (r < 0 ? 0 : r > 32 ? 32 : r);
+}
+__device__ __forceinline__ int ps_q_item(int G, int x, unsigned k) {  // k-th item of class x
+  return G + (int)((((k >> PS_Q_CHUNK_SHIFT) << 3) + (unsigned)x) << PS_Q_CHUNK_SHIFT) + (int)(k & 31u);
+}
+__device__ __forceinline__ void ps_q_draw_begin(unsigned* ctr, int x, int lane, unsigned& ticket, unsigned& peek) {
+  ticket = 0;
+  peek = 0;
+  if (lane == 0) ticket = __hip_atomic_fetch_add(ctr + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane < 8) peek = __hip_atomic_load(ctr + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wave-uniform: the next item of this block, or -1 when every class is exhausted
+__device__ __forceinline__ int ps_q_resolve(unsigned* ctr, int x, int lane, int G, int nitems, unsigned ticket, unsigned peek) {
+  const int R = nitems - G;
+  const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+  if ((int)k < ps_q_count(R, x)) return ps_q_item(G, x, k);
+  // own class exhausted.  Counters only grow: a class that looked empty stays empty, one that did not is asked (blocking).
+  unsigned m = (unsigned)__builtin_amdgcn_ballot_w64(lane < 8 && (int)peek < ps_q_count(R, lane)) & 0xffu & ~(1u << x);
+  while (m) {
+    const unsigned rot = ((m >> x) | (m << (8 - x))) & 0xffu;  // the classes behind x first (its neighbours in the raster)
+    const int y = (x + __builtin_ctz(rot)) & 7;
+    unsigned t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(ctr + y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+    if ((int)t < ps_q_count(R, y)) return ps_q_item(G, y, t);
+    m &= ~(1u << y);
+  }
+  return -1;
+}
+// a block leaves (all of its draws have returned): the last one re-arms the counters for the next launch that uses them
+__device__ __forceinline__ void ps_q_block_done(unsigned* ctr, int lane, int nblocks) {
+  if (lane == 0) {
+    const unsigned d = __hip_atomic_fetch_add(ctr + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (d == (unsigned)nblocks - 1u) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) __hip_atomic_store(ctr + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+// the mailbox: four ints of LDS at `mbox`; entry (seq & 3) holds the item of the block's seq-th item (seq >= 1)
+__device__ __forceinline__ int ps_q_mbox_read(const unsigned char* mbox, int seq) {
+  return __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(mbox + ((seq & 3) << 2)));
+}
+__device__ __forceinline__ void ps_q_mbox_write(unsigned char* mbox, int seq, int item, int lane) {
+  if (lane == 0) *reinterpret_cast<volatile int*>(mbox + ((seq & 3) << 2)) = item;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // Work split of the persistent kernels.  tpb <= 0: ONE batch -- block b takes items remap(b), remap(b) + nblocks, ... (a block
 // lives for the whole launch: best when the GPU is ours alone).  tpb > 0: blocks come in batches of nb (= #CUs); a batch covers
 // nb * tpb consecutive items and each of its blocks takes tpb of them, so the hardware dispatcher re-balances every tpb items when
