@@ -72,7 +72,8 @@ def parse():
     ap.add_argument("--grad-payload", default="fp32", choices=["fp32", "bf16"],
                     help="N > 1: wire format of the gradient exchange (bf16: buckets cast, all-reduced, widened back: half the xGMI bytes)")
     ap.add_argument("--share", default="batch", help="N > 1: how the conv launches make room for the collectives while buckets are in flight: "
-                                                     "'batch' (tiles_per_block = 1) or 'reserve[:CUS]' (cus_reserved, default 32)")
+                                                     "'batch' (tiles_per_block = 1), 'reserve[:CUS]' (cus_reserved, default 32), 'queue' (tile_queue: in-kernel ticket queues) "
+                                                     "or 'reserve+queue[:CUS]'")
     ap.add_argument("--cpu-tiles", type=int, default=8, help="tiles per CPU-baseline step (SURVEY 8d: bs=8, 1 warm-up + 3 timed)")
     ap.add_argument("--workload", default="seg", choices=["seg", "rfm", "infer2", "infer4"],
                     help="seg: BASELINE configs[1]/[4] (segmentation_train.py step, the headline metric); rfm: configs[3], the stage-3 step "
@@ -87,7 +88,7 @@ def parse():
 
 def share_args(args):
     mode, _, cus = args.share.partition(":")
-    assert mode in ("batch", "reserve"), args.share
+    assert mode in ("batch", "reserve", "queue", "reserve+queue"), args.share
     return dict(grad_payload=args.grad_payload, share=mode, reserved_cus=int(cus) if cus else 32)
 
 

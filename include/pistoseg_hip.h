@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PS_VERSION 223 /* major*10000 + minor*100 + patch */
+#define PS_VERSION 224 /* major*10000 + minor*100 + patch */
 
 typedef enum ps_status {
   PS_OK = 0,
@@ -92,6 +92,10 @@ typedef struct ps_conv_geom {
   int32_t wgrad_terms;    /* ps_conv2d_wgrad[_det] on the split types only: 0 / 1 = dW from the hi halves (x_hi dy_hi: one launch of the 16-bit kernel);
                             * 3 = + x_hi dy_lo + x_lo dy_hi (three launches).  The lo terms are 2^-8 (bf16) / 2^-11 (fp16) of a product and add up
                             * incoherently over the pixels: 1.8e-4 of a flip-free step's gradient in fp16x3, nothing measurable at training sizes. */
+  int32_t tile_queue;     /* launch option of the persistent kernels: 1 = a block's first work item is static, every further one is drawn from
+                            * per-XCD ticket counters one item ahead (ps_internal.h: ps_q_*), so blocks that start late or share their CU with
+                            * another kernel take fewer items instead of delaying the launch.  Replaces tiles_per_block / cus_reserved where the
+                            * co-running kernel's footprint is not known in advance.  0 = the static schedule.  Bit-identical results. */
 } ps_conv_geom;
 
 /* Epilogue applied to the f32 accumulator `acc` of every produced element (pixel m, channel c):

@@ -31,7 +31,7 @@ class ConvGeom(C.Structure):
         ("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
         ("cin", C.c_int32), ("cout", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32),
         ("dilation", C.c_int32), ("ldc_x", C.c_int32), ("ldc_y", C.c_int32), ("tiles_per_block", C.c_int32),
-        ("gpu_shared", C.c_int32), ("cus_reserved", C.c_int32), ("wgrad_terms", C.c_int32),
+        ("gpu_shared", C.c_int32), ("cus_reserved", C.c_int32), ("wgrad_terms", C.c_int32), ("tile_queue", C.c_int32),
     ]
 
 

@@ -13,7 +13,10 @@
 //     operand, so a lane's 4 accumulator registers are 4 consecutive couts of ONE pixel; the cout rows
 //     are permuted while staging so that each lane ends up with 16 contiguous couts -> 16-byte stores.
 #include "ps_internal.h"
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 #ifndef PS_READ_PER
 #define PS_READ_PER 2  // MFMAs between two fragment reads of the consumers' software pipeline (A/B builds: tools/ab_build.py)
@@ -43,6 +46,8 @@ struct IgemmArgs {
   int nb, tpb;                // persistent kernels: blocks per batch (#CUs), tiles per block (0 = one batch), see ps_block_items
   int shared;                 // host side only (ps_conv_geom.gpu_shared): another stream fills this launch's partial last round -- no tail launch
   int reserved;               // host side only (ps_conv_geom.cus_reserved): CUs left to a co-running kernel; the persistent grids use the rest
+  int use_queue;              // host side only (ps_conv_geom.tile_queue): the persistent kernels draw their tiles from a ticket queue
+  unsigned* queue;            // <.., Q = true> kernels: this launch's ticket counters (ps_queue_slot)
   // stride-2 data gradient, one launch per output parity class (conv_igemm_ws2_kernel<.., SPLIT>): the produced grid Ho x Wo is the
   // class's sub-grid, pixel (p', q') of it is pixel (oy + 2p', ox + 2q') of the full Hf x Wf gradient, and only the taps in tap_mask
   // (those that hit dy at integer positions for this parity) are staged and multiplied.  epi_M = rows of the full tensor.
@@ -1797,7 +1802,12 @@ __device__ unsigned long long g_halo_stamps[256 * 4 * 6];  // [block][consumer w
 // WI = cout fragments per consumer wave: 4 = the 128-cout tile; 2 = a 64-cout HALF tile (8 KiB of weights per K-step, half the MFMAs):
 // the tiles of a launch's partial last round are issued as half tiles by a second launch (see the dispatcher: a 3.5-round layer leaves
 // half the chip idle for a whole round; as half tiles the same work occupies every CU for ~0.6 of a round).
-template <typename Tr, int TW, int NW = 3, int WI = 4>  // TW = 28 (maps of 224-pixel tiles: 28 / 56 / 112 wide) or 32 (256-pixel tiles: 32 / 64 / 128 wide); NW = weight ring depth
+// Q: tiles behind the block's first one come from the launch's ticket queue (a.queue; ps_internal.h) instead of the static schedule: consumer
+// wave 0 draws tile s + 1 when tile s starts and publishes it in front of the barrier of K-step nst - 7 (nst = 9 klines >= 18 K-steps per tile: the
+// dispatcher sends one-K-line problems to the static kernel); the loaders' cursors cross into tile s + 1 from K-step nst - 6 on.  As LATE as that
+// allows on purpose: collecting the ticket is a vmcnt(0) in a wave whose memory queue still holds the previous tile's epilogue stores, and while
+// the memory system is busy those take microseconds (collected at K-step 8 the queue cost 2-6 % on the 3x3 layers of a training step).
+template <typename Tr, int TW, int NW = 3, int WI = 4, bool Q = false>  // TW = 28 (maps of 224-pixel tiles: 28 / 56 / 112 wide) or 32 (256-pixel tiles: 32 / 64 / 128 wide); NW = weight ring depth
 __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs a) {
   typedef typename Tr::elem T [[maybe_unused]];
   static_assert(TW == 28 || TW == 32, "tile width");
@@ -1808,15 +1818,35 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
   static_assert(WJ == 9 || WJ == 10, "window DMAs per loader wave");
   static_assert(NW >= 3 && NW <= 5 && 2 * WIN_BYTES + NW * B_BYTES <= 160 * 1024, "LDS budget");
   constexpr int W_OFF = 2 * WIN_BYTES;
+  constexpr int MB_OFF = W_OFF + NW * B_BYTES;  // Q: the mailbox (16 bytes behind the weight ring)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int first, G, ntiles;  // this block's tiles: first, first + G, ... < ntiles
-  ps_block_items(blockIdx.x, gridDim.x, a.ntm * a.ntn, a.nb, a.tpb, first, G, ntiles);
+  int first, G, ntiles;  // this block's tiles: first, first + G, ... < ntiles  (Q: first, then whatever the queue hands out)
+  [[maybe_unused]] unsigned q_tk = 0;  // Q, consumer wave 0: the ticket in flight
+  [[maybe_unused]] bool q_peek = false; // Q (wave-uniform): whether the next draw also looks at the other classes' counters
+  if constexpr (Q) {
+    // EVERY tile comes from the queue, the first one too: a block that becomes resident late (its CU was held by another kernel) finds the
+    // queue drained and leaves, instead of adding a whole tile to the launch's critical path.  The first ticket is drawn here, at the
+    // very top, and collected behind the waves' tile-independent set-up (one extra block barrier).
+    G = 0;
+    first = -1;
+    ntiles = a.ntm * a.ntn;
+    q_peek = ps_q_count(ntiles, blockIdx.x & 7) <= 64;
+#ifndef PS_Q_STATIC_TICKETS
+    if (wave == 0) ps_q_draw_begin(a.queue, blockIdx.x & 7, lane, q_peek, q_tk);
+#endif
+  } else {
+    ps_block_items(blockIdx.x, gridDim.x, a.ntm * a.ntn, a.nb, a.tpb, first, G, ntiles);
+  }
   const int nwin = 3 * a.klines;             // windows (K-line, ty) per tile, three K-steps each
-  const int my_tiles = (ntiles - first + G - 1) / G;
-  const int total_steps = my_tiles * nwin * 3;
+  const int my_tiles = Q ? 1 : (ntiles - first + G - 1) / G;
+  // Q: the loaders' three countdowns (windows, weight steps, consumed steps) count what is KNOWN to exist -- the first tile, plus one tile
+  // every time the window cursor learns from the mailbox that there is a next one -- so every test below reads the same in both modes (and
+  // hipcc proves the same things about them: the steady-state path must stay free of per-issue end tests)
+  const int total_steps = Q ? nwin * 3 : my_tiles * nwin * 3;
+  [[maybe_unused]] const unsigned mbox = ps_q_mbox_addr(smem + MB_OFF);
   const int H = a.Hs, W = a.Ws, NH = a.M / W;  // stride 1: produced grid == source grid; NH = global rows n*H + p
   const int ncb = W / TW;                    // column blocks per row (W is a multiple of TW)
   const int dabs = a.dstep < 0 ? -a.dstep : a.dstep;
@@ -1838,10 +1868,20 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
       tcol[j] = t < WP ? t - dabs : -(1 << 20);
     }
     const int lane_off = srow * W * (int)a.pix_bytes + chunk_off;
+    if constexpr (Q) {  // the block's first tile (published by consumer wave 0 in front of this barrier)
+      __builtin_amdgcn_s_barrier();
+      first = ps_q_mbox_read(mbox, 0);
+      if (first < 0) return;
+    }
     // --- cursor of the next WINDOW to stage: (tile, K-line, ty).  Window row wr of tap row ty serves exactly ONE produced row,
     // global row R0 + wr: it holds source row p + (ty-1)*dstep of the SAME image, or zeros (vertical padding; produced rows
     // past the tensor's end; rows that would come from the neighbouring image when a tile straddles two images).
-    int a_tile = first, a_kl = 0, a_ty = 0, a_buf = 0, a_left = my_tiles * nwin;
+    int a_tile = first, a_kl = 0, a_ty = 0, a_buf = 0, a_left = Q ? nwin : my_tiles * nwin;
+    // Q: the cursors cross a tile boundary in the order windows (K-step nst - 6), weights (nst - NW), and the windows do not cross the next one
+    // before the weights have crossed this one: ONE mailbox read per tile, handed down in a register
+    [[maybe_unused]] int a_seq = 0, q_next = -1;
+    int c_left = total_steps;  // consumed steps left (Q: that are known of)
+    int b_tile = first, b_kl = 0, b_tap = 0, b_slot = 0, b_left = total_steps;  // cursor of the next WEIGHT tile to stage (see below)
     int a_R0 = 0, a_X0 = 0, prow = 0;  // prow: image row p of the produced row this lane's window row serves (per tile)
     auto window_tile_setup = [&](int tile) {
       int tm, tn;
@@ -1872,14 +1912,22 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
         a_ty = 0;
         if (++a_kl == a.klines) {
           a_kl = 0;
-          a_tile += G;
+          if constexpr (Q) {
+            a_tile = q_next = ps_q_mbox_read(mbox, ++a_seq);
+            if (a_tile >= 0) {
+              a_left = nwin;
+              b_left += nwin * 3;  // (declared below)
+              c_left += nwin * 3;
+            }
+          } else {
+            a_tile += G;
+          }
           if (a_left) window_tile_setup(a_tile);
         }
       }
       return true;
     };
     // --- cursor of the next WEIGHT tile to stage: (tile, K-line, tap)
-    int b_tile = first, b_kl = 0, b_tap = 0, b_slot = 0, b_left = total_steps;
     unsigned woff[WPW];
     auto weights_setup = [&](int tile) {
       int tm, tn;
@@ -1909,7 +1957,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
         b_tap = 0;
         if (++b_kl == a.klines) {
           b_kl = 0;
-          b_tile += G;
+          if constexpr (Q) {
+            b_tile = q_next;
+          } else {
+            b_tile += G;
+          }
           if (b_left) weights_setup(b_tile);
         }
       }
@@ -1946,7 +1998,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
     // `s_waitcnt` through a 5-level compare tree (a switch over 18 literals) -- ~40 scalar instructions and half a dozen branches more
     // per K-step than this form.
     constexpr int ALLOW01 = WPW * (NW - 2) + WJ, ALLOW2 = WPW * ((NW - 2) < 2 ? (NW - 2) : 2);
-    for (int gs = 0; gs < total_steps;) {
+    for (int gs = 0; Q ? c_left > 0 : gs < total_steps;) {
       if (r == 0 && b_left >= 3 && a_left >= 1) {
         issue_weights();
         issue_window();
@@ -1962,6 +2014,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
         after_win = 2;
         win_pending = false;
         gs += 3;
+        if constexpr (Q) c_left -= 3;
         continue;
       }
       if (issue_weights()) { ++w_issued; ++after_win; }   // weights of step gs + NW - 1
@@ -1981,6 +2034,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
       __builtin_amdgcn_s_barrier();
       r = (r == 2) ? 0 : r + 1;
       ++gs;
+      if constexpr (Q) --c_left;
     }
     return;
   }
@@ -2002,6 +2056,23 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
     const int c = wm * (TW / 2) + 2 * mi + (frow >> 3) + dabs;  // window column of the centre tap
     xa[mi] = c * 1024 + tr * 128 + ((g ^ tr) << 4);
   }
+  if constexpr (Q) {
+    if (wave == 0) {
+#ifdef PS_Q_STATIC_TICKETS
+      ps_q_mbox_write(mbox, 0, (int)blockIdx.x < ntiles ? ps_xcd_remap(blockIdx.x, gridDim.x) : -1);
+#else
+      ps_q_mbox_write(mbox, 0, ps_q_resolve(a.queue, blockIdx.x & 7, lane, 0, ntiles, q_tk, q_peek));
+#endif
+    }
+    __builtin_amdgcn_s_barrier();
+    first = ps_q_mbox_read(mbox, 0);
+    if (first < 0) {
+#ifndef PS_Q_STATIC_TICKETS
+      if (wave == 0) ps_q_block_done(a.queue, lane, gridDim.x);
+#endif
+      return;
+    }
+  }
   __builtin_amdgcn_s_barrier();  // window 0 / weights of step 0 visible
 
   int cur = 0, wbuf = 0;
@@ -2010,7 +2081,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
   PS_STAMP(st_prev);
   const unsigned long long st_c0 = st_prev, st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  for (int tile = first; tile < ntiles; tile += G) {
+  [[maybe_unused]] int q_seq = 0;
+  for (int tile = first; Q ? tile >= 0 : tile < ntiles; tile = Q ? ps_q_mbox_read(mbox, ++q_seq) : tile + G) {
+    if constexpr (Q) {
+#ifndef PS_Q_STATIC_TICKETS  // (diagnostic build: the queue's code paths fed with the static schedule -- no atomics; what the restructuring alone costs)
+      if (wave == 0) ps_q_draw_begin(a.queue, blockIdx.x & 7, lane, q_peek, q_tk);  // the ticket of this block's tile q_seq + 1: in flight until K-step nst - 7
+#endif
+    }
     f32x4 acc[MI][WI];
 #ifndef PS_HALO_MFMA32_TIMING
 #pragma unroll
@@ -2124,6 +2201,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
     kstep(0, true);
     int tx = 1;
     for (int s = 1; s < 3 * nwin; ++s) {
+      if constexpr (Q) {
+#ifdef PS_Q_STATIC_TICKETS
+        if (s == 3 * nwin - 7 && wave == 0) ps_q_mbox_write(mbox, q_seq + 1, tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : -1);
+#else
+        if (s == 3 * nwin - 7 && wave == 0)
+          ps_q_mbox_write(mbox, q_seq + 1, ps_q_resolve(a.queue, blockIdx.x & 7, lane, G, ntiles, q_tk, q_peek));
+#endif
+      }
       kstep(tx, false);
       if (++tx == 3) { tx = 0; wbuf ^= 1; }
     }
@@ -2148,6 +2233,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
     conv_epilogue<typename Tr::epi, MI, WI, 1>(a, acc, rb * TR * W + (tm - rb * ncb) * TW + wm * (TW / 2), tn * BN + wn * WN, lane);
 #ifdef PS_HALO_STAMPS
     PS_STAMP(st_prev);  // the epilogue is not part of segment 0 of the next tile's first step
+#endif
+  }
+  if constexpr (Q) {
+#ifndef PS_Q_STATIC_TICKETS
+    if (wave == 0) ps_q_block_done(a.queue, lane, gridDim.x);  // (every draw of this block has returned: the last one was resolved in the last tile)
 #endif
   }
 #ifdef PS_HALO_STAMPS
@@ -2216,6 +2306,7 @@ int check_geom(const ps_conv_geom* g) {
   PS_REQUIRE(g->tiles_per_block >= 0 && g->tiles_per_block <= 4096, "conv: tiles_per_block %d out of range", g->tiles_per_block);
   PS_REQUIRE(g->gpu_shared == 0 || g->gpu_shared == 1, "conv: gpu_shared %d (0 or 1)", g->gpu_shared);
   PS_REQUIRE(g->cus_reserved >= 0 && g->cus_reserved <= 4096, "conv: cus_reserved %d out of range", g->cus_reserved);
+  PS_REQUIRE(g->tile_queue == 0 || g->tile_queue == 1, "conv: tile_queue %d (0 or 1)", g->tile_queue);
   const int es = ps_esize(g->dtype);
   PS_REQUIRE((g->cin * es) % 128 == 0 && (g->cout * es) % 128 == 0,
              "conv: cin=%d cout=%d must be multiples of %d channels", g->cin, g->cout, 128 / es);
@@ -2413,6 +2504,19 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s, bool allow_gemm256 = true) {
         if (g_halo_tail && a.tpb == 0 && !a.shared && T > b.nb && R > 0 && 2 * R <= b.nb && R % b.ntn == 0 && a.Cd % 64 == 0) tail_ptiles = (int)(R / b.ntn);
       }
       b.ntm -= tail_ptiles;
+      // tile_queue: only where there is something to hand out (more tiles than blocks) and a tile is long enough to draw one ahead
+      if constexpr (sizeof(typename Tr::elem) == 2) {
+        if (a.use_queue && (long long)b.ntm * b.ntn > b.nb && b.klines >= 2) {
+          b.queue = ps_queue_slot(s);
+          PS_REQUIRE(b.queue != nullptr, "conv: no ticket counters (hipMalloc failed)");
+          const dim3 qgrid((unsigned)b.nb);
+          if (tw == 28) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 3, 4, true>), qgrid, dim3(512), 2 * 9 * 4096 + 3 * 16384 + 16, s, b);
+          else hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32, 3, 4, true>), qgrid, dim3(512), 2 * 10 * 4096 + 3 * 16384 + 16, s, b);
+          PS_CHECK_LAUNCH("conv_igemm_halo<queue>");
+          goto halo_tail;
+        }
+      }
+      {
       const dim3 hgrid(ps_persistent_grid((long long)b.ntm * b.ntn, b.nb, b.tpb));
       if (tw == 28) {
 #ifdef PS_DEBUG_HOOKS
@@ -2429,6 +2533,8 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s, bool allow_gemm256 = true) {
         hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32, 3>), hgrid, dim3(512), 2 * 10 * 4096 + 3 * 16384, s, b);
       }
       PS_CHECK_LAUNCH("conv_igemm_halo");
+      }
+    halo_tail:
       if constexpr (sizeof(typename Tr::elem) == 2) {
         if (tail_ptiles > 0) {
           IgemmArgs c = b;
@@ -2485,6 +2591,31 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s, bool allow_gemm256 = true) {
 }
 
 }  // namespace
+
+// Ticket counters of the queue-mode launches: per (device, stream) a ring of counter blocks (nine counters, one 128-byte line each), zeroed once; every launch takes the next
+// block of its stream's ring.  A launch leaves its block zeroed (ps_q_block_done) and launches of one stream run in order, so a block is
+// never shared by two launches in flight.
+unsigned* ps_queue_slot(hipStream_t stream) {
+  constexpr int kSlots = 256, kDwords = PS_Q_SLOT_DWORDS;
+  struct Ring { unsigned* base; unsigned next; };
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, Ring> rings;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = rings.find({dev, stream});
+  if (it == rings.end()) {
+    unsigned* d = nullptr;
+    if (hipMalloc(&d, kSlots * kDwords * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(d, 0, kSlots * kDwords * sizeof(unsigned)) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    it = rings.emplace(std::make_pair(dev, stream), Ring{d, 0u}).first;
+  }
+  Ring& r = it->second;
+  unsigned* p = r.base + (size_t)(r.next % kSlots) * kDwords;
+  ++r.next;
+  return p;
+}
+
 
 #ifdef PS_DEBUG_HOOKS
 extern "C" void ps_debug_set_glds(int on) { g_use_glds = on; }  // 0 | 1 | 2
@@ -2613,6 +2744,8 @@ extern "C" int ps_conv2d_fwd(const ps_conv_geom* g, const void* x, const void* w
   a.tpb = g->tiles_per_block;
   a.shared = g->gpu_shared;
   a.reserved = g->cus_reserved;
+  a.use_queue = g->tile_queue;
+  a.queue = nullptr;
   if (int rc = set_extents(a, (long long)g->n * g->h * g->w * a.pix_bytes, (long long)g->cout * a.wrow_bytes, es)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (g->dtype == PS_BF16X3) return dispatch_bn<TraitsBF16X3>(a, s);
@@ -2687,6 +2820,8 @@ extern "C" int ps_conv2d_dgrad(const ps_conv_geom* g, const void* dy, const void
   a.tpb = g->tiles_per_block;
   a.shared = g->gpu_shared;
   a.reserved = g->cus_reserved;
+  a.use_queue = g->tile_queue;
+  a.queue = nullptr;
   if (int rc = set_extents(a, (long long)g->n * a.Hs * a.Ws * a.pix_bytes, (long long)g->cin * a.wrow_bytes, es)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dgrad_s2_split_ok(g, epi))

@@ -38,6 +38,8 @@ struct WgradArgs {
   int ablate;                  // timing experiments only (results WRONG): 1 = no atomics, 2 = plain stores instead of atomics
   int nb, tpb;                 // persistent kernel: blocks per batch (#CUs), items per block (0 = one batch), see ps_block_items
   int reserved;                // host side only (ps_conv_geom.cus_reserved): CUs left to a co-running kernel
+  int use_queue;               // host side only (ps_conv_geom.tile_queue)
+  unsigned* queue;             // conv_wgrad_ws2_kernel<.., Q = true>: this launch's ticket counters (ps_queue_slot)
   int cig, cog;                // item order: cin / cout tiles per group of consecutive items (see decode_item)
   float* part;                 // deterministic mode (DET kernels): workspace [pixel range][cout][taps][cin] f32 for the partial sums
   long long part_stride;       // elements per pixel range = cout * taps * cin
@@ -339,7 +341,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //      64-bit mask of valid LANES; a K-step costs one 32-byte scalar load (issued in front of the dY pieces, which hide its latency) and ONE
 //      v_cndmask per X piece instead of 11 VALU instructions per row (4 instead of 44 per wave and K-step: the loaders' issue stream is
 //      part of the K-step's critical path)
-template <bool F16, int XM, bool DET = false>
+// Q: items behind the block's first one come from the launch's ticket queue (a.queue; ps_internal.h).  Consumer wave 0 draws item s + 1 when item
+// s starts -- right behind item s - 1's atomics in its memory queue -- and publishes it in front of the barrier of the item's K-step len - 6: the
+// loaders cross into item s + 1 when they stage item s's last K-step, two K-steps ahead of the consumers.  As late as that allows: collecting
+// the ticket is a vmcnt(0), i.e. it also waits for those atomics, which take many microseconds to drain while other blocks add to the same rows.
+// The host selects Q only where every item has at least PS_WGRAD_QMIN K-steps.
+constexpr int PS_WGRAD_QMIN = 32;
+template <bool F16, int XM, bool DET = false, bool Q = false>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs a) {
   constexpr int ES = 2, KP = 64, BCO = 256, BCI = 128;
   constexpr int RBG = BCO * ES, RBX = BCI * ES;             // 512 / 256 bytes per LDS row
@@ -357,8 +365,22 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
   // on the memory side of L2 for a 100 MB working set)
   const int per = (a.ksteps + a.splits - 1) / a.splits;           // K-steps per pixel range
   const int live = (a.ksteps + per - 1) / per;                    // ranges that get work
-  int first, G, nitems;  // this block's items: first, first + G, ... < nitems
-  ps_block_items(blockIdx.x, gridDim.x, a.tiles_co * a.tiles_ci * a.taps * live, a.nb, a.tpb, first, G, nitems);
+  int first, G, nitems;  // this block's items: first, first + G, ... < nitems  (Q: first, then whatever the queue hands out)
+  [[maybe_unused]] unsigned q_tk = 0;   // Q, consumer wave 0: the ticket in flight
+  [[maybe_unused]] bool q_peek = false;  // Q (wave-uniform): whether the next draw also looks at the other classes' counters
+  if constexpr (Q) {
+    // EVERY item comes from the queue, the first one too (see conv_igemm_halo_kernel): drawn here, collected behind the waves' item-independent set-up
+    G = 0;
+    first = -1;
+    nitems = a.tiles_co * a.tiles_ci * a.taps * live;
+    q_peek = ps_q_count(nitems, blockIdx.x & 7) <= 64;
+#ifndef PS_Q_STATIC_TICKETS
+    if (wave_all == 0) ps_q_draw_begin(a.queue, blockIdx.x & 7, lane, q_peek, q_tk);
+#endif
+  } else {
+    ps_block_items(blockIdx.x, gridDim.x, a.tiles_co * a.tiles_ci * a.taps * live, a.nb, a.tpb, first, G, nitems);
+  }
+  [[maybe_unused]] const unsigned mbox = ps_q_mbox_addr(smem + 3 * STAGE);  // Q: the mailbox (16 bytes behind the ring)
   // item -> (ci tile, co tile, tap, pixel range), pixel range slowest (co-running blocks share their dY / X chunks in L2).  Inside a
   // range the order is [cig cin tiles][taps][cog cout tiles][other cin groups][other cout groups] (plan_wgrad_ws2): the ~32 consecutive
   // items that run together on one XCD then need few DISTINCT dY / X rows per K-step -- the taps of a (cin, cout) tile pair read the same dY
@@ -374,11 +396,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
     ks0 = item * per;
     ks1 = min(a.ksteps, ks0 + per);
   };
-  // total K-steps of this block's items (ranges are equal except the last)
+  // total K-steps of this block's items (ranges are equal except the last); Q: not known in advance
   int total_steps = 0;
-  for (int it = first; it < nitems; it += G) {
-    const int sp = it / (a.tiles_ci * a.tiles_co * a.taps);
-    total_steps += min(a.ksteps, (sp + 1) * per) - sp * per;
+  if constexpr (!Q) {
+    for (int it = first; it < nitems; it += G) {
+      const int sp = it / (a.tiles_ci * a.tiles_co * a.taps);
+      total_steps += min(a.ksteps, (sp + 1) * per) - sp * per;
+    }
   }
 
   if (wave_all >= 4) {
@@ -429,8 +453,15 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
         vrow = a.vtab + ((long long)tap * a.vperiod * 4 + wave) * 4;
       }
     };
+    if constexpr (Q) {  // the block's first item (published by consumer wave 0 in front of this barrier)
+      __builtin_amdgcn_s_barrier();
+      item = ps_q_mbox_read(mbox, 0);
+      if (item < 0) return;
+    }
     item_setup(item);
     int slot = 0, issued = 0;
+    [[maybe_unused]] int l_seq = 0;        // Q: items this cursor has left behind
+    [[maybe_unused]] bool l_done = false;  // Q: the last K-step of the block's last item has been staged
     // stages the next K-step of the flat sequence: exactly NLD loads per wave.  The caller guarantees issued < total_steps (the loaders'
     // issue stream is on the K-step's critical path, ~0.1 % of the kernel per scalar instruction: no per-step end test, no selector test in
     // the product build)
@@ -492,13 +523,36 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
       }
       ++issued;
       slot = (slot == 2) ? 0 : slot + 1;
-      if (++ks == ks_end && issued < total_steps) {
-        item += G;
-        item_setup(item);
+      if constexpr (Q) {
+        if (++ks == ks_end) {
+          item = ps_q_mbox_read(mbox, ++l_seq);
+          if (item >= 0) item_setup(item);
+          else l_done = true;
+        }
+      } else {
+        if (++ks == ks_end && issued < total_steps) {
+          item += G;
+          item_setup(item);
+        }
       }
     };
     // Steps 0 and 1, then one step per barrier while there are steps left to stage (the wait leaves the newest step's NLD pieces in
     // flight), then the drain: nothing to stage, everything must have landed.
+    if constexpr (Q) {  // every block has an item, every item more than two K-steps
+      issue_next();
+      issue_next();
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // step 0 visible
+      while (!l_done) {
+        issue_next();
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
+      return;
+    }
     if (total_steps > 0) issue_next();  // (a block without work stages nothing; it still meets the consumers' first barrier)
     if (total_steps > 1) {
       issue_next();
@@ -587,12 +641,35 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
       for (int j = 0; j < NI; ++j) mfma1(acc[i][j], af[i], bf[j]);
   };
 
+  if constexpr (Q) {
+    if (wave == 0) {
+#ifdef PS_Q_STATIC_TICKETS
+      ps_q_mbox_write(mbox, 0, (int)blockIdx.x < nitems ? ps_xcd_remap(blockIdx.x, gridDim.x) : -1);
+#else
+      ps_q_mbox_write(mbox, 0, ps_q_resolve(a.queue, blockIdx.x & 7, lane, 0, nitems, q_tk, q_peek));
+#endif
+    }
+    __builtin_amdgcn_s_barrier();
+    first = ps_q_mbox_read(mbox, 0);
+    if (first < 0) {
+#ifndef PS_Q_STATIC_TICKETS
+      if (wave == 0) ps_q_block_done(a.queue, lane, gridDim.x);
+#endif
+      return;
+    }
+  }
   __builtin_amdgcn_s_barrier();  // step 0 visible
   int cur = 0;
   const long long wrow = (long long)a.taps * a.cin;
-  for (int item = first; item < nitems; item += G) {
+  [[maybe_unused]] int q_seq = 0;
+  for (int item = first; Q ? item >= 0 : item < nitems; item = Q ? ps_q_mbox_read(mbox, ++q_seq) : item + G) {
     int tci, tco, tap, ks0, ks1;
     decode(item, tci, tco, tap, ks0, ks1);
+    if constexpr (Q) {
+#ifndef PS_Q_STATIC_TICKETS  // (diagnostic build: the queue's code paths fed with the static schedule, no atomics)
+      if (wave == 0) ps_q_draw_begin(a.queue, blockIdx.x & 7, lane, q_peek, q_tk);  // the ticket of this block's item q_seq + 1: in flight until K-step ks1 - 6
+#endif
+    }
     f32x4 acc[MI][NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -610,6 +687,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
       cur = (cur == 2) ? 0 : cur + 1;
     }
     for (int ks = ks0 + 1; ks < ks1; ++ks) {
+      if constexpr (Q) {
+#ifdef PS_Q_STATIC_TICKETS
+        if (ks == ks1 - 6 && wave == 0) ps_q_mbox_write(mbox, q_seq + 1, item + (int)gridDim.x < nitems ? item + (int)gridDim.x : -1);
+#else
+        if (ks == ks1 - 6 && wave == 0) ps_q_mbox_write(mbox, q_seq + 1, ps_q_resolve(a.queue, blockIdx.x & 7, lane, G, nitems, q_tk, q_peek));
+#endif
+      }
       const unsigned char* st = smem + cur * STAGE;
       half(std::true_type{}, st, 0, af0, bf0, af1, bf1, acc);  // this step's first half is read behind the previous step's second-half MFMAs
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -655,6 +739,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
           else asm volatile("" ::"v"(o[jp]));
         }
       }
+  }
+  if constexpr (Q) {
+#ifndef PS_Q_STATIC_TICKETS
+    if (wave == 0) ps_q_block_done(a.queue, lane, gridDim.x);  // (every draw of this block has returned: the last one was resolved in its last item)
+#endif
   }
 }
 
@@ -1065,6 +1154,20 @@ int launch_wgrad_ws2(WgradArgs a, hipStream_t s) {
   const long long items = (long long)a.tiles_co * a.tiles_ci * a.taps * live;
   const unsigned grid = ps_persistent_grid(items, a.nb, a.tpb);
   const size_t lds = 3 * 64 * (256 + 128) * 2;
+  // tile_queue: the stride-1 layers (XM 2 / 3), where there is something to hand out and every item (the last pixel range is the shortest) is
+  // long enough to draw one item ahead
+  if (a.use_queue && a.stride == 1 && items > a.nb) {
+    const long long per = (a.ksteps + a.splits - 1) / a.splits, last = a.ksteps - (live - 1) * per;
+    const bool vt = a.taps == 9 && g_wgrad_vtab && (a.vtab = wgrad_valid_table(a.H, a.W, a.dil, &a.vperiod)) != nullptr;
+    if (std::min(per, last) >= PS_WGRAD_QMIN && (a.taps == 1 || vt)) {
+      a.queue = ps_queue_slot(s);
+      PS_REQUIRE(a.queue != nullptr, "wgrad: no ticket counters (hipMalloc failed)");
+      if (a.taps == 1) hipLaunchKernelGGL((conv_wgrad_ws2_kernel<Tr::F16, 2, DET, true>), dim3((unsigned)a.nb), dim3(512), lds + 16, s, a);
+      else hipLaunchKernelGGL((conv_wgrad_ws2_kernel<Tr::F16, 3, DET, true>), dim3((unsigned)a.nb), dim3(512), lds + 16, s, a);
+      PS_CHECK_LAUNCH("conv_wgrad_ws2<queue>");
+      return PS_OK;
+    }
+  }
   if (a.stride == 1 && a.taps == 1) hipLaunchKernelGGL((conv_wgrad_ws2_kernel<Tr::F16, 2, DET>), dim3(grid), dim3(512), lds, s, a);
   else if (a.stride == 1 && a.taps == 9 && g_wgrad_vtab && (a.vtab = wgrad_valid_table(a.H, a.W, a.dil, &a.vperiod)) != nullptr)
     hipLaunchKernelGGL((conv_wgrad_ws2_kernel<Tr::F16, 3, DET>), dim3(grid), dim3(512), lds, s, a);
@@ -1175,6 +1278,8 @@ int fill_wgrad_args(const ps_conv_geom* g, const void* x, const void* dy, float*
   a.cin = g->cin; a.cout = g->cout;
   a.tpb = g->tiles_per_block;
   a.reserved = g->cus_reserved;
+  a.use_queue = g->tile_queue;
+  a.queue = nullptr;
   a.x_pix_bytes = (long long)g->ldc_x * es;
   a.dy_pix_bytes = (long long)g->ldc_y * es;
   a.div_hw = make_fastdiv((uint32_t)(a.Ho * a.Wo));

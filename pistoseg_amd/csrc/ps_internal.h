@@ -217,12 +217,12 @@ __device__ __forceinline__ int ps_xcd_remap(int bid, int nwg) {
 // handed out by tickets.  They are cut into chunks of 32 consecutive items, chunk c belonging to CLASS c % 8 -- the items the static
 // schedule gives to the blocks that share `blockIdx % 8` (= an XCD and its L2) -- and every class has its own ticket counter: a
 // block draws from its own class while that lasts (same L2 locality as the static schedule, order of the raster kept) and then
-// steals from the others.  ctr[0..7]: tickets per class, ctr[8]: blocks that have left; the last block to leave zeroes all nine
+// steals from the others.  Nine counters per launch (tickets per class, blocks that have left); the last block to leave zeroes all nine
 // (launches that share a counter block are ordered by their stream).
-// ONE wave of the block draws, one item ahead and without waiting: ps_q_draw_begin issues the atomic (and a look at all eight
-// counters) when an item starts, ps_q_resolve turns the returned ticket into an item several K-steps later and the wave publishes it
+// ONE wave of the block draws, one item ahead and without waiting: ps_q_draw_begin issues the atomic when an item starts, ps_q_resolve turns the returned ticket into an item several K-steps later and the wave publishes it
 // through an LDS mailbox in front of a block barrier; every other wave reads the mailbox behind that barrier.  The only blocking
 // memory operations are the steals (a class that looked non-empty), i.e. only where the static schedule would have left a CU idle.
+unsigned* ps_queue_slot(hipStream_t stream);  // host: this launch's counter block (conv_igemm.hip); nullptr if the pool cannot be allocated
 constexpr int PS_Q_CHUNK_SHIFT = 5;
 __device__ __forceinline__ int ps_q_count(int R, int x) {  // items of class x among the R queued items
   const int r = (R & 255) - (x << PS_Q_CHUNK_SHIFT);
@@ -231,24 +231,44 @@ __device__ __forceinline__ int ps_q_count(int R, int x) {  // items of class x a
 __device__ __forceinline__ int ps_q_item(int G, int x, unsigned k) {  // k-th item of class x
   return G + (int)((((k >> PS_Q_CHUNK_SHIFT) << 3) + (unsigned)x) << PS_Q_CHUNK_SHIFT) + (int)(k & 31u);
 }
-__device__ __forceinline__ void ps_q_draw_begin(unsigned* ctr, int x, int lane, unsigned& ticket, unsigned& peek) {
-  ticket = 0;
-  peek = 0;
-  if (lane == 0) ticket = __hip_atomic_fetch_add(ctr + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (lane < 8) peek = __hip_atomic_load(ctr + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Counter layout: class x's tickets at ctr[x * PS_Q_STRIDE] -- one 128-byte line per class: 256 blocks draw at nearly the same time, and
+// atomics on ONE line are served one after the other (the first version kept all nine counters in 64 bytes and added 1 / 0 to all eight class
+// counters per draw: +3-6 % on the 3x3 layers of a training step) -- and the blocks-done count at ctr[8 * PS_Q_STRIDE].
+constexpr int PS_Q_STRIDE = 32;
+constexpr int PS_Q_SLOT_DWORDS = 9 * PS_Q_STRIDE;
+// ONE atomic instruction per draw, one VGPR (`tk`): lane 0 takes a ticket of the own class; when the class is about to run out (`peek`,
+// wave-uniform: the previous ticket was within 64 of its end -- two rounds of the class's blocks) lanes 8..15 add 0 to the eight class counters,
+// i.e. read them: the look that decides where to steal.  Draws in the body of a launch are therefore single-lane atomics on the class's own
+// line.  The address is lane-dependent on purpose: on a wave-uniform address hipcc's atomic optimiser folds the lanes into one atomic plus a
+// readfirstlane of its result, i.e. a wait right behind the instruction.  `tk` must not be read before ps_q_resolve (it is in flight).
+__device__ __forceinline__ void ps_q_draw_begin(unsigned* ctr, int x, int lane, bool peek, unsigned& tk) {
+  // (an opaque zero in the offset: a loop-invariant per-lane ADDRESS would be hoisted out of the item loop -- two registers that the
+  // weight-gradient kernel does not have; spilled, their reload's vmcnt(0) waits for the previous item's atomics at every draw)
+  int z;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+  if (lane == 0 || (peek && lane >= 8 && lane < 16))
+    tk = __hip_atomic_fetch_add(ctr + (((lane < 8 ? lane + x : lane) & 7) * PS_Q_STRIDE + z), lane == 0 ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// wave-uniform: the next item of this block, or -1 when every class is exhausted
-__device__ __forceinline__ int ps_q_resolve(unsigned* ctr, int x, int lane, int G, int nitems, unsigned ticket, unsigned peek) {
-  const int R = nitems - G;
-  const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
-  if ((int)k < ps_q_count(R, x)) return ps_q_item(G, x, k);
+// wave-uniform: the next item of this block, or -1 when every class is exhausted; `peek` in: whether the draw looked at the other classes,
+// out: whether the next draw should
+__device__ __forceinline__ int ps_q_resolve(unsigned* ctr, int x, int lane, int G, int nitems, unsigned tk, bool& peek) {
+  const int R = nitems - G, nx = ps_q_count(R, x);
+  const unsigned k = (unsigned)__builtin_amdgcn_readfirstlane((int)tk);
+  if ((int)k < nx) {
+    peek = (int)k + 64 >= nx;
+    return ps_q_item(G, x, k);
+  }
   // own class exhausted.  Counters only grow: a class that looked empty stays empty, one that did not is asked (blocking).
-  unsigned m = (unsigned)__builtin_amdgcn_ballot_w64(lane < 8 && (int)peek < ps_q_count(R, lane)) & 0xffu & ~(1u << x);
+  if (!peek) {  // (it ran out earlier than the previous ticket suggested: look now)
+    if (lane >= 8 && lane < 16) tk = __hip_atomic_fetch_add(ctr + (lane & 7) * PS_Q_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    peek = true;
+  }
+  unsigned m = (unsigned)(__builtin_amdgcn_ballot_w64(lane >= 8 && lane < 16 && (int)tk < ps_q_count(R, lane & 7)) >> 8) & 0xffu & ~(1u << x);
   while (m) {
     const unsigned rot = ((m >> x) | (m << (8 - x))) & 0xffu;  // the classes behind x first (its neighbours in the raster)
     const int y = (x + __builtin_ctz(rot)) & 7;
     unsigned t = 0;
-    if (lane == 0) t = __hip_atomic_fetch_add(ctr + y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) t = __hip_atomic_fetch_add(ctr + y * PS_Q_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
     if ((int)t < ps_q_count(R, y)) return ps_q_item(G, y, t);
     m &= ~(1u << y);
@@ -258,20 +278,25 @@ __device__ __forceinline__ int ps_q_resolve(unsigned* ctr, int x, int lane, int 
 // a block leaves (all of its draws have returned): the last one re-arms the counters for the next launch that uses them
 __device__ __forceinline__ void ps_q_block_done(unsigned* ctr, int lane, int nblocks) {
   if (lane == 0) {
-    const unsigned d = __hip_atomic_fetch_add(ctr + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned d = __hip_atomic_fetch_add(ctr + 8 * PS_Q_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (d == (unsigned)nblocks - 1u) {
 #pragma unroll
-      for (int i = 0; i < 9; ++i) __hip_atomic_store(ctr + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = 0; i < 9; ++i) __hip_atomic_store(ctr + i * PS_Q_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
-// the mailbox: four ints of LDS at `mbox`; entry (seq & 3) holds the item of the block's seq-th item (seq >= 1)
-__device__ __forceinline__ int ps_q_mbox_read(const unsigned char* mbox, int seq) {
-  return __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(mbox + ((seq & 3) << 2)));
+// the mailbox: four ints of LDS; entry (seq & 3) holds the block's seq-th item (seq >= 1).  `mb` = its LDS byte address (ps_q_mbox_addr).
+// Explicit DS instructions: a generic-pointer access compiles to a FLAT load, whose wait (vmcnt AND lgkmcnt) would drain a loader wave's DMA queue.
+__device__ __forceinline__ unsigned ps_q_mbox_addr(unsigned char* p) {
+  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)p;
 }
-__device__ __forceinline__ void ps_q_mbox_write(unsigned char* mbox, int seq, int item, int lane) {
-  if (lane == 0) *reinterpret_cast<volatile int*>(mbox + ((seq & 3) << 2)) = item;
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+__device__ __forceinline__ int ps_q_mbox_read(unsigned mb, int seq) {
+  int v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(mb + ((unsigned)(seq & 3) << 2)) : "memory");
+  return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ void ps_q_mbox_write(unsigned mb, int seq, int item) {  // wave-uniform item: every lane stores the same dword
+  asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(mb + ((unsigned)(seq & 3) << 2)), "v"(item) : "memory");
 }
 
 // Work split of the persistent kernels.  tpb <= 0: ONE batch -- block b takes items remap(b), remap(b) + nblocks, ... (a block

@@ -58,8 +58,13 @@ class BucketedAllReduce:
                      16-CU kernel, +1.5 % alone: profiles/r03_hog_step_probe.txt);
           "reserve": `cus_reserved = reserved_cus` -- the persistent grids and their static schedules are sized for the other CUs, every block
                      is resident at once and the launch costs the ideal #CUs / (#CUs - reserved) (profiles/r04_hog_step_probe.txt).  Set
-                     reserved_cus to the CUs the collective really holds (RCCL: its channel count, NCCL_MAX_NCHANNELS)."""
-        assert payload in ("fp32", "bf16") and share in ("batch", "reserve")
+                     reserved_cus to the CUs the collective really holds (RCCL: its channel count, NCCL_MAX_NCHANNELS);
+          "queue"  : `tile_queue = 1` -- the persistent kernels' blocks draw every tile / work item from per-XCD ticket counters, so a block that
+                     cannot become resident takes nothing instead of delaying the launch by its static share: no knowledge of the collective's
+                     size needed (+16 % beside a 16-CU kernel, like "batch", +27 % beside a 48-CU one; nothing alone);
+          "reserve+queue": both -- the reservation's +8-9 % while the collective fits into it, the queue's graceful +26 % (instead of the
+                     bare reservation's +51 %) when it does not (48 CUs held, 32 reserved): profiles/r04_hog_step_probe_queue.txt."""
+        assert payload in ("fp32", "bf16") and share in ("batch", "reserve", "queue", "reserve+queue")
         self.share, self.reserved_cus = share, reserved_cus
         self.flat, self.buckets, self.group = flat, buckets, group
         self.comm_stream = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None
@@ -75,10 +80,12 @@ class BucketedAllReduce:
     def _share_gpu(self, on: bool) -> None:
         if self.comm_stream is None or on == self._sharing or self.launch_opts is None:
             return
-        if self.share == "reserve":  # (both are per-launch arguments of the C-ABI: ps_conv_geom)
-            self.launch_opts.cus_reserved = self.reserved_cus if on else None
-        else:
+        if self.share == "batch":  # (all three are per-launch arguments of the C-ABI: ps_conv_geom)
             self.launch_opts.tiles_per_block = self.shared_tiles_per_block if on else None
+        if "reserve" in self.share:
+            self.launch_opts.cus_reserved = self.reserved_cus if on else None
+        if "queue" in self.share:
+            self.launch_opts.tile_queue = 1 if on else None
         self._sharing = on
 
     def begin_step(self) -> None:

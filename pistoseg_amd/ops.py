@@ -115,11 +115,15 @@ class LaunchOpts:
     cus_reserved: Optional[int] = None
     # split precisions: plane pairs the weight gradient multiplies (ps_conv_geom.wgrad_terms): None / 1 = hi halves only, 3 = all three terms
     wgrad_terms: Optional[int] = None
+    # 1 = the persistent kernels draw every work item behind a block's first one from per-XCD ticket counters (ps_conv_geom.tile_queue): blocks
+    # that start late or share their CU take fewer items; set by dist.BucketedAllReduce(share="queue"), or for good on a model whose GPU is shared
+    tile_queue: Optional[int] = None
 
 
 TILES_PER_BLOCK = 0  # module defaults (see LaunchOpts): read when a launch is ENQUEUED
 GPU_SHARED = 0
 CUS_RESERVED = 0
+TILE_QUEUE = 0
 
 
 def _geom(spec: ConvSpec, dtype: int, n: int, h: int, w: int, ldc_x: int, ldc_y: int, opts: Optional[LaunchOpts] = None) -> ConvGeom:
@@ -127,7 +131,9 @@ def _geom(spec: ConvSpec, dtype: int, n: int, h: int, w: int, ldc_x: int, ldc_y:
     shared = GPU_SHARED if opts is None or opts.gpu_shared is None else opts.gpu_shared
     reserved = CUS_RESERVED if opts is None or opts.cus_reserved is None else opts.cus_reserved
     terms = 0 if opts is None or opts.wgrad_terms is None else opts.wgrad_terms
-    return ConvGeom(dtype, n, h, w, spec.cin, spec.cout, spec.ksize, spec.stride, spec.dilation, ldc_x, ldc_y, int(tpb), int(shared), int(reserved), int(terms))
+    queue = TILE_QUEUE if opts is None or opts.tile_queue is None else opts.tile_queue
+    return ConvGeom(dtype, n, h, w, spec.cin, spec.cout, spec.ksize, spec.stride, spec.dilation, ldc_x, ldc_y, int(tpb), int(shared), int(reserved), int(terms),
+                    int(queue))
 
 
 SPLIT_WIDTH = 2  # stored 16-bit channels per logical channel of a split tensor (hi + lo)

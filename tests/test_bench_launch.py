@@ -47,7 +47,7 @@ def test_bench_multi_rank_control_flow_on_a_shared_gpu(workload):
     (PISTOSEG_BENCH_TEST_BACKEND: RCCL itself refuses two ranks on one device).  Checks the line's bookkeeping, not its numbers."""
     extra = []
     if workload == "seg+bf16+reserve":  # the second wire format and the CU reservation through the bench's own N > 1 path
-        workload, extra = "seg", ["--grad-payload", "bf16", "--share", "reserve:32"]
+        workload, extra = "seg", ["--grad-payload", "bf16", "--share", "reserve+queue:32"]
     argv = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--tile", "64", "--no-cpu-baseline", "--workload", workload, *extra]
     r = run_bench(*argv, env={"PISTOSEG_BENCH_TEST_BACKEND": "gloo"})
     assert r.returncode == 0, r.stderr[-3000:]
@@ -62,4 +62,4 @@ def test_bench_multi_rank_control_flow_on_a_shared_gpu(workload):
     if workload in ("seg", "rfm"):
         assert "roofline" in line and "cpu_baseline" not in line and "test_backend" in line
     if extra:
-        assert line["config"]["grad_payload"] == "bf16" and line["config"]["share"] == "reserve:32" and line["final_loss"] == line["final_loss"]
+        assert line["config"]["grad_payload"] == "bf16" and line["config"]["share"] == "reserve+queue:32" and line["final_loss"] == line["final_loss"]

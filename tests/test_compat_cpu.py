@@ -221,6 +221,16 @@ def test_launch_options_are_per_model_state_and_reach_the_geometry(monkeypatch):
     assert ops._geom(spec, 1, 2, 28, 28, 512, 512, net.launch).cus_reserved == 32 and ops._geom(spec, 1, 2, 28, 28, 512, 512, other.launch).cus_reserved == 0
     red._share_gpu(False)
     assert net.launch.cus_reserved is None
+    # ... or, share="queue" / "reserve+queue", its tile_queue: the persistent kernels' blocks draw their tiles from ticket counters
+    for mode, res in (("queue", None), ("reserve+queue", 32)):
+        red = BucketedAllReduce(torch.zeros(8), [("b7", 0, 8)], None, launch_opts=net.launch, share=mode, reserved_cus=32)
+        red.comm_stream = object()
+        red._share_gpu(True)
+        assert net.launch.tile_queue == 1 and net.launch.cus_reserved == res and net.launch.tiles_per_block is None and other.launch.tile_queue is None
+        gq = ops._geom(spec, 1, 2, 28, 28, 512, 512, net.launch)
+        assert gq.tile_queue == 1 and gq.cus_reserved == (res or 0) and ops._geom(spec, 1, 2, 28, 28, 512, 512, other.launch).tile_queue == 0
+        red._share_gpu(False)
+        assert net.launch.tile_queue is None and net.launch.cus_reserved is None
 
 
 def test_gpu_suite_order_puts_parity_before_selfchecks_before_control_flow():

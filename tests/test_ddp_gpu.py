@@ -76,8 +76,9 @@ def _run(rank, world, port, backend, kind, out):
             model.load_state_dict(ref_cpu.make_state_dict(3, False, seed=42))
             model = model.to(D)
             model.sample_dropout = sample
-            # "seg_bf16": the second wire format (buckets cast to bf16, summed, widened back) with CUs reserved for the collectives
-            extra = dict(grad_payload="bf16", share="reserve", reserved_cus=32) if kind == "seg_bf16" else {}
+            # "seg_bf16": the second wire format (buckets cast to bf16, summed, widened back) with CUs reserved for the collectives and the
+            # persistent kernels on their ticket queues while buckets are in flight
+            extra = dict(grad_payload="bf16", share="reserve+queue", reserved_cus=32) if kind == "seg_bf16" else {}
             tr = SegTrainer(model, lr=1e-3, weight_decay=0.05, ignore_index=3, process_group=pg, bucket_mb=64.0, track_iou=False, **extra)
             step = lambda: float(tr.train_step(inputs[0][sl].to(D), inputs[1][sl].to(D)))
         else:
@@ -185,19 +186,20 @@ def _rccl_world1(port, out):
         class _Opts:
             tiles_per_block = None
             cus_reserved = None
+            tile_queue = None
         opts = _Opts()
-        red16 = BucketedAllReduce(flat, red.buckets, dist.group.WORLD, launch_opts=opts, payload="bf16", share="reserve", reserved_cus=32)
+        red16 = BucketedAllReduce(flat, red.buckets, dist.group.WORLD, launch_opts=opts, payload="bf16", share="reserve+queue", reserved_cus=32)
         red16.begin_step()
         vals = torch.randn(3 * n, device="cuda")
         flat.copy_(vals)
         seen = []
         share = red16._share_gpu
-        red16._share_gpu = lambda on: (share(on), seen.append((on, opts.cus_reserved, opts.tiles_per_block)))[0]
+        red16._share_gpu = lambda on: (share(on), seen.append((on, opts.cus_reserved, opts.tiles_per_block, opts.tile_queue)))[0]
         red16.on_unit_done("fc8")
         red16.on_unit_done("b7")
         red16.finish()
         # (a finished bucket may hand the CUs back before the next one is launched: only the first and the last transition are fixed)
-        ok = ok and seen[0] == (True, 32, None) and seen[-1] == (False, None, None) and opts.cus_reserved is None
+        ok = ok and seen[0] == (True, 32, None, 1) and seen[-1] == (False, None, None, None) and opts.cus_reserved is None and opts.tile_queue is None
         ok = ok and bool(torch.equal(flat, vals.to(torch.bfloat16).float()))
         out.put(("ok" if ok else "values wrong (side stream ran ahead of the producer?)"))
         dist.destroy_process_group()

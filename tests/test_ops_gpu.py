@@ -1244,3 +1244,70 @@ def test_conv_halo_tail_as_half_tiles(case, dtype, library):
     tol = TOL[dtype]
     for a_, r_ in zip(split[0], (nhwc((y + res).detach()), nhwc(act.detach()), nhwc(gx_ref))):
         assert rel_err(a_.float().cpu(), r_) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [
+    # (n, h, w, cin, cout, k, d): halo (3x3) + the weight gradient's persistent kernel, more work items than CUs
+    (40, 28, 28, 256, 256, 3, 2),    # 280 tiles: almost everything is a block's first draw; 4 K-lines
+    (64, 28, 28, 128, 512, 3, 1),    # 896 tiles = 3.5 rounds (main launch from the queue + a static tail launch of half tiles); 2 K-lines: the shortest tile the queue serves
+    (23, 56, 56, 128, 256, 3, 1),    # two column blocks per row, ragged last tile
+    (17, 32, 32, 64, 512, 3, 4),     # 256-pixel tiles, ONE K-line: the dispatcher keeps the static kernel (nothing to compare, must still be identical)
+    (36, 28, 28, 512, 512, 1, 1),    # 1x1: the weight gradient's XM = 2 instantiation (the forward stays on the static ws2 kernel)
+])
+def test_tile_queue_launch_option_is_exact(case, dtype, library):
+    """ps_conv_geom.tile_queue = 1: every tile (halo kernel) / work item (weight gradient) is drawn from per-XCD ticket counters by the blocks
+    themselves instead of a static schedule.  Only the block that computes a tile changes: forward and data gradient are BIT-IDENTICAL to the
+    static schedule, the atomic weight gradient up to f32 ordering and the deterministic one bit for bit; the counters re-arm themselves
+    (many launches through one stream's ring of counter blocks, and two streams at once)."""
+    from pistoseg_amd import ops
+
+    D = dev()
+    n, h, w, cin, cout, k, d = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, h, w, cin, generator=g).to(D, dtype)
+    wt = torch.randn(cout, cin, k, k, generator=g) * 0.03
+    wf, wd = w_fwd_layout(wt).to(D, dtype), w_dgrad_layout(wt).to(D, dtype)
+    gy = torch.randn(n, h, w, cout, generator=g).to(D, dtype)
+    res = torch.randn(n, h, w, cout, generator=g).to(D, dtype)
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).to(D), (torch.randn(cout, generator=g) * 0.1).to(D)
+    spec = ops.ConvSpec(cin, cout, k, 1, d)
+
+    def run(det):
+        y, a = torch.empty((n, h, w, cout), device=D, dtype=dtype), torch.empty((n, h, w, cout), device=D, dtype=dtype)
+        ops.conv2d_fwd(spec, x, wf, add0=res, out_raw=y, bn_scale=scale, bn_shift=shift, out_act=a)
+        gx = torch.empty((n, h, w, cin), device=D, dtype=dtype)
+        ops.conv2d_dgrad(spec, gy, wd, (h, w), out_raw=gx)
+        dw = torch.zeros((cout, k, k, cin), device=D, dtype=torch.float32)
+        ops.conv2d_wgrad(spec, x, gy, dw, deterministic=det)
+        return y, a, gx, dw
+
+    try:
+        ops.TILE_QUEUE = 0
+        ref, ref_det = run(False), run(True)
+        ops.TILE_QUEUE = 1
+        got, got_det = run(False), run(True)
+        assert all(torch.equal(p, q) for p, q in zip(got[:3], ref[:3]))
+        assert rel_err(got[3].cpu(), ref[3].cpu()) < 1e-5
+        assert torch.equal(got_det[3], ref_det[3])  # a pixel range's partial sums do not depend on the block that made them
+        # counters re-arm: > 256 queue launches on this stream (its ring of counter blocks wraps), checked at intervals and at the end
+        bad = 0
+        for i in range(300):
+            y = torch.empty_like(ref[0])
+            ops.conv2d_fwd(spec, x, wf, add0=res, out_raw=y)
+            if i % 37 == 0 or i >= 297:
+                bad += int(not torch.equal(y, ref[0]))
+        assert bad == 0
+        # two streams draw from their own rings at the same time
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        outs = []
+        for s in (s1, s2, s1, s2):
+            with torch.cuda.stream(s):
+                gx = torch.empty((n, h, w, cin), device=D, dtype=dtype)
+                ops.conv2d_dgrad(spec, gy, wd, (h, w), out_raw=gx)
+                outs.append(gx)
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, ref[2]) for o in outs)
+    finally:
+        ops.TILE_QUEUE = 0

@@ -168,3 +168,38 @@ def test_split_conv_rejects_narrow_channel_strides():
     y = torch.zeros((1, 4, 4, 64), device=D, dtype=torch.bfloat16)  # room for the hi halves only: must be refused, not overrun
     with pytest.raises(_lib.PsError):
         ops.conv2d_fwd(spec, x, wf, out_raw=y, split=True)
+
+
+@pytest.mark.parametrize("dt", [BF, HF])
+def test_split_convs_through_the_tile_queue_are_bit_identical(dt):
+    """ps_conv_geom.tile_queue = 1 on the split types (halo kernel with three MFMA groups per K-line, weight gradient on the gathered hi halves):
+    same bits as the static schedule for forward and data gradient, f32 atomic ordering for the weight gradient."""
+    from pistoseg_amd import ops
+
+    n, h, w, cin, cout, k, d = 24, 28, 28, 256, 512, 3, 2  # 84 pixel tiles x 4 cout tiles = 336 tiles
+    spec = ops.ConvSpec(cin, cout, k, 1, d)
+    g = torch.Generator().manual_seed(77)
+    PL = lambda t: planes(t, False, dt)
+    x = PL(torch.randn(n, h, w, cin, generator=g)).to(D)
+    wt = torch.randn(cout, cin, k, k, generator=g) * 0.02
+    wf, wd = PL(wt.permute(0, 2, 3, 1).contiguous()).to(D), PL(wt.flip(2, 3).permute(1, 2, 3, 0).contiguous()).to(D)
+    gy = PL(torch.randn(n, h, w, cout, generator=g)).to(D)
+
+    def run():
+        y = torch.empty((n, h, w, 2 * cout), device=D, dtype=dt)
+        ops.conv2d_fwd(spec, x, wf, out_raw=y, split=True)
+        gx = torch.empty((n, h, w, 2 * cin), device=D, dtype=dt)
+        ops.conv2d_dgrad(spec, gy, wd, (h, w), out_raw=gx, split=True)
+        dw = torch.zeros((cout, k, k, cin), device=D, dtype=torch.float32)
+        ops.conv2d_wgrad(spec, x, gy, dw, split=True)
+        return y, gx, dw
+
+    try:
+        ops.TILE_QUEUE = 0
+        ref = run()
+        ops.TILE_QUEUE = 1
+        got = run()
+    finally:
+        ops.TILE_QUEUE = 0
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    assert rel_err(got[2].cpu(), ref[2].cpu()) < 1e-5

@@ -1,5 +1,6 @@
 """Whole training steps beside a kernel that holds `hog` CUs (an RCCL all-reduce beside the backward): static persistent schedule
-(tiles_per_block 0) vs 1-2 tiles per block, with the weight gradients on the side stream (two kernels share the GPU anyway)."""
+(tiles_per_block 0) vs 1-2 tiles per block vs a reserved-CU grid vs the in-kernel ticket queue, with the weight gradients on the side
+stream (two kernels share the GPU anyway)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -32,12 +33,13 @@ def run(label):
     print(f"hog={hog:2d} CUs {label}: {best*1e3:6.2f} ms/step  {64/best:6.0f} tiles/s", flush=True)
 
 
-for hog in (0, 16, 32):
-    for tpb in (0, 2, 1):  # static persistent schedule | small batches of tiles that the dispatcher re-balances
-        ops.TILES_PER_BLOCK = tpb
-        run(f"tiles_per_block={tpb}")
-    ops.TILES_PER_BLOCK = 0
-    for res in (16, 32):   # grid and static schedule sized for #CUs - reserved (ps_conv_geom.cus_reserved)
-        ops.CUS_RESERVED = res
-        run(f"cus_reserved={res}  ")
-    ops.CUS_RESERVED = 0
+rows = [("static schedule          ", dict()),
+        ("tiles_per_block=1        ", dict(TILES_PER_BLOCK=1)),   # small batches of tiles that the dispatcher re-balances
+        ("cus_reserved=32          ", dict(CUS_RESERVED=32)),     # grid and static schedule sized for #CUs - reserved (ps_conv_geom.cus_reserved)
+        ("tile_queue=1             ", dict(TILE_QUEUE=1)),        # every tile / work item drawn from per-XCD ticket counters (ps_conv_geom.tile_queue)
+        ("cus_reserved=32 + queue  ", dict(CUS_RESERVED=32, TILE_QUEUE=1))]
+for hog in (0, 16, 32, 48):
+    for label, opts in rows:
+        for k, v in opts.items(): setattr(ops, k, v)
+        run(label)
+        for k in opts: setattr(ops, k, 0)

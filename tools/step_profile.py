@@ -1,4 +1,5 @@
-"""Per-launch table of one training step (HIP events around every conv launch):  python tools/step_profile.py [batch] [bf16|fp16] [classes]"""
+"""Per-launch table of one training step (HIP events around every conv launch):  python tools/step_profile.py [batch] [bf16|fp16] [classes]
+(PS_TILE_QUEUE=1 in the environment: the tile_queue launch option on every launch)"""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,6 +26,7 @@ def wrap(name):
     setattr(ops, name, f)
 for nm in ("conv2d_fwd", "conv2d_dgrad", "conv2d_wgrad"): wrap(nm)
 import pistoseg_amd.resnet38d, pistoseg_amd.seg_model
+ops.TILE_QUEUE = int(os.environ.get("PS_TILE_QUEUE", "0"))
 BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 PREC = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 CLASSES = int(sys.argv[3]) if len(sys.argv) > 3 else 3

@@ -51,11 +51,14 @@ def apply(v):
     lib.ps_debug_reset()  # every tunable back to the library default (one list, in the library)
     ops._geom = _geom
     if hasattr(model, "heads_f32"): model.heads_f32 = False
+    ops.TILE_QUEUE = 0
     if v != "base":
         for kv in v.split(","):
             k, val = kv.split("=")
             if k == "gpu_shared":
                 ops._geom = _geom if int(val) else _geom_unshared
+            elif k == "tile_queue":  # the launch option (ps_conv_geom.tile_queue), through the module default
+                ops.TILE_QUEUE = int(val)
             elif k == "heads_f32":  # --rfm: the RFM heads in f32 (1) or in the backbone's 16-bit type (0)
                 model.heads_f32 = bool(int(val))
             else:
