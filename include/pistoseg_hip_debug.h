@@ -73,6 +73,20 @@ void ps_debug_set_wgrad_raster(int v);
 /* 3x3 stride-1 weight gradients: 1 (default) = padding validity from the precomputed lane-mask table, 0 = per-row tracking in the loaders */
 void ps_debug_set_wgrad_vtab(int v);
 
+/* EXPERIMENT (r04; correct, not faster than the three launches it replaces: profiles/r04_front_fusion.txt).  conv1a + the first ResBlock's entry in ONE launch, for the uses in which conv1a's activation is not needed again (inference; training
+ * of the models that freeze b2, models/revise_net.py:27):
+ *   a      = max(conv1a(image) * scale0 + shift0, 0)            (3x3, 3 -> 64, stride 1, pad 1; never written to memory)
+ *   out_b1 = conv_branch1(a)                                    (1x1, stride 2, 64 -> 128, raw)            w_b1: [128][64]
+ *   out_2a = max(conv_branch2a(a) * scale1 + shift1, 0)         (3x3, stride 2, pad 1, 64 -> 128)          w_2a: [128][3][3][64]
+ * replaces: models/resnet38d.py:123,161-162 and ResBlock.forward :28-41 of b2 (x_bn_relu, branch1, the first conv of branch2 + its BN + ReLU).
+ * dtype PS_BF16 / PS_F16 (weights and outputs; image and conv1a weights f32, rounded to dtype like ps_conv1a_fwd does); image NCHW f32
+ * [n][3][h][w] with w = 224 or 256 and h even; outputs channels-last [n, h/2, w/2, >= 128] with the given channel strides.  Same arithmetic
+ * as ps_conv1a_fwd followed by the two ps_conv2d_fwd launches, up to the summation order inside conv1a. */
+int ps_debug_conv_front_s2_supported(int32_t dtype, int32_t n, int32_t h, int32_t w);
+int ps_debug_conv_front_s2(int32_t dtype, int32_t n, int32_t h, int32_t w, const float* image, const float* w1a, const float* scale0,
+                     const float* shift0, const void* w_b1, const void* w_2a, void* out_b1, int32_t ldc_b1, const float* scale1,
+                     const float* shift1, void* out_2a, int32_t ldc_2a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -172,6 +172,8 @@ DEBUG_PROTOTYPES = {
     "ps_debug_reset": (None, []),
     "ps_debug_set_wgrad_raster": (None, [C.c_int]),
     "ps_debug_set_wgrad_vtab": (None, [C.c_int]),
+    "ps_debug_conv_front_s2_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "ps_debug_conv_front_s2": (C.c_int, [C.c_int32] * 4 + [C.c_void_p] * 7 + [C.c_int32] + [C.c_void_p] * 3 + [C.c_int32, C.c_void_p]),
 }
 
 DEBUG_LIB_PATH = os.environ.get("PISTOSEG_HIP_DEBUG_LIB") or os.path.join(HERE, "libpistoseg_hip_debug.so")  # override: A/B builds

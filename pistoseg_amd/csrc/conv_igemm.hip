@@ -2250,6 +2250,181 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
 }
 
 #ifdef PS_DEBUG_HOOKS
+// ------------------------------------------------------------------------------------------------
+// EXPERIMENT, debug library only (r04; built, bit-identical to the three launches it replaces, measured NO faster and therefore not used
+// by the model: profiles/r04_front_fusion.txt).  The front of the net in one launch: conv1a (3x3, 3 -> 64, stride 1, pad 1, NCHW f32 image)
+// + the first ResBlock's BN + ReLU (the activation `a`), consumed in place by that block's two stride-2 convolutions -- shortcut =
+// conv_branch1(a) (1x1 s2, raw) and a2 = relu(bn(conv_branch2a(a))) (3x3 s2, pad 1) -- models/resnet38d.py:123,161-162 + ResBlock.forward
+// :28-41 of b2.  `a` ([N, H, W, 64]: 411 MB at bs = 64, the net's largest tensor) is never written to HBM; it exists one row at a time in LDS.
+// Applicable where `a` is not needed again: inference, and training of the models that freeze b2 (revise_net.py:27, the segmentation model).
+//   block = ONE output row (n, oy): Wo = 16 NF output pixels x 128 + 128 produced channels; 4 waves = 4 cout groups of 32, each over the whole row;
+//   for r = 0..2 (rows 2 oy - 1 + r of `a`): phase 1 -- conv1a of the row's 2 Wo + 1 window pixels (columns -1 .. 2 Wo - 1) on the MFMA
+//   (K = 27 padded to 32: im2col operands gathered from the image rows staged in LDS as 16-bit values), BN + ReLU, zero outside the image,
+//   written to LDS as 64-channel rows in two column-parity planes (a stride-2 tap then reads CONSECUTIVE rows: conflict-free with the usual
+//   chunk ^ (row & 7) swizzle); phase 2 -- the three taps (r, 0..2) of the 3x3 stride-2 conv (+ the 1x1 on the centre tap, same pixel
+//   fragments), weights straight from global memory (L2-resident, 160 KB) into MFMA operands, one tap ahead.  Plain block barriers between
+//   the phases; two 4-wave blocks per CU (36 KiB of LDS each).
+//   Arithmetic as conv1a_lowp_kernel + the 16-bit conv kernels: image and conv1a weights rounded to the storage type, f32 accumulation,
+//   `a` rounded to the storage type before the stride-2 convs read it (what the unfused path stores).
+//   Measured (bs = 64, 224 x 224, bf16): 432 us against 148 + 74 + 208 us for conv1a, the 1x1 and the 3x3 stride-2 launches: every phase of a
+//   block is a chain of exposed latencies (image rows and weight fragments from L2, the im2col gather, seven barriers per output row) with only
+//   two blocks per CU to overlap them; a persistent variant with the constants in LDS and batched weight / image prefetches spilled 180
+//   registers (679 us).  What it needs is the other kernels' structure: loader waves that stage image rows and weight taps through LDS ahead of
+//   the MFMA waves, and `a` rows kept across output rows (two of three are recomputed here).
+struct FrontArgs {
+  const float* image;   // [N][3][H][W]
+  const float* w1a;     // [64][3][3][3]
+  const float* sc0;     // BN affine of `a` (64)
+  const float* sh0;
+  const unsigned char* w_b1;  // [128][64] 16-bit
+  const unsigned char* w_2a;  // [128][9][64] 16-bit
+  int N, H, W;
+  IgemmArgs eb1, e2a;   // epilogue descriptors of the two outputs (conv_epilogue reads epi, Wo, Ho, M, epi_M, Cd, m_off)
+};
+
+template <typename Tr, int NF>
+__global__ __launch_bounds__(256, 2) void conv_front_s2_kernel(const FrontArgs f) {
+  typedef typename Tr::elem T;
+  constexpr int WO = 16 * NF, WC = 2 * WO + 1, PLANE = WO + 1;   // window columns c = 0 .. 2 WO <-> image columns c - 1
+  constexpr int WIN_BYTES = 2 * PLANE * 128;                       // one `a` row: [column parity][index] rows of 64 channels
+  constexpr int IW = 2 * WO + 4;                                   // staged image columns jc = 0 .. 2 WO + 2 <-> image columns jc - 2
+  constexpr int IMG_OFF = WIN_BYTES;                               // ... followed by the staged image rows: 3 x 5 x IW 16-bit values
+  constexpr int PF = (WC + 15) / 16;                               // window pixel fragments per row
+  constexpr int MI = NF;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15, g = lane >> 4;
+  const int Ho = f.H / 2;
+  const int img_n = blockIdx.x / Ho, oy = blockIdx.x - img_n * Ho;
+  auto to_bits = [](float v) -> unsigned {
+    if constexpr (std::is_same<T, __bf16>::value) return ps_f32_to_bf16(v);
+    else return ps_f32_to_f16(v);
+  };
+  // ---- the five image rows 2 oy - 2 .. 2 oy + 2 (zero outside the image), three channels, as 16-bit values
+  for (int i = tid; i < 3 * 5 * IW; i += 256) {
+    const int ch = i / (5 * IW), rem = i - ch * 5 * IW, j = rem / IW, jc = rem - j * IW;
+    const int iy = 2 * oy - 2 + j, ix = jc - 2;
+    float v = 0.f;
+    if ((unsigned)iy < (unsigned)f.H && (unsigned)ix < (unsigned)f.W) v = f.image[(((long long)img_n * 3 + ch) * f.H + iy) * f.W + ix];
+    reinterpret_cast<unsigned short*>(smem + IMG_OFF)[i] = (unsigned short)to_bits(v);
+  }
+  // ---- conv1a weights as MFMA A operands: fragment i = couts 16 i .. 16 i + 15, lane (row n16, K group g) holds K = 8 g .. 8 g + 7 of
+  // k = c * 9 + ky * 3 + kx (27 real, zero above); and the lane's 8 constant byte offsets into the staged image
+  u32x4 w1f[4];
+  int koff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 8 * g + j, kc = k < 27 ? k : 0;
+    const int c = kc / 9, ky = (kc - 9 * c) / 3, kx = kc - 9 * c - 3 * ky;
+    koff[j] = ((c * 5 + ky) * IW + kx) * 2;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned h[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 8 * g + j;
+      h[j] = k < 27 ? to_bits(f.w1a[(16 * i + n16) * 27 + k]) : 0u;
+    }
+    w1f[i] = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+  }
+  // BN affine of `a` for this lane's couts 16 i + 4 g + e
+  float sc0[4][4], sh0[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 a4 = *reinterpret_cast<const float4*>(f.sc0 + 16 * i + 4 * g), b4 = *reinterpret_cast<const float4*>(f.sh0 + 16 * i + 4 * g);
+    sc0[i][0] = a4.x; sc0[i][1] = a4.y; sc0[i][2] = a4.z; sc0[i][3] = a4.w;
+    sh0[i][0] = b4.x; sh0[i][1] = b4.y; sh0[i][2] = b4.z; sh0[i][3] = b4.w;
+  }
+  // ---- phase 2 role: cout group `wave` (32 couts: two fragments in the epilogue's channel order) over the row's NF pixel fragments
+  const int n0 = 32 * wave;
+  f32x4 acc2[MI][2], acc1[MI][2];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc2[mi][i] = acc1[mi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // weight fragment (i, kh) of tap t: row rho = n16 is cout n0 + 8 (rho >> 2) + 4 i + (rho & 3), K elements kh * 32 + 8 g .. + 7
+  const int wrow = n0 + 8 * (n16 >> 2) + (n16 & 3);
+  auto load_w2 = [&](int t, u32x4 (&wf)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+        wf[i][kh] = *reinterpret_cast<const u32x4*>(f.w_2a + (((long long)(wrow + 4 * i) * 9 + t) * 64 + kh * 32 + 8 * g) * 2);
+  };
+  u32x4 wb1[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) wb1[i][kh] = *reinterpret_cast<const u32x4*>(f.w_b1 + ((long long)(wrow + 4 * i) * 64 + kh * 32 + 8 * g) * 2);
+  u32x4 wcur[2][2], wnxt[2][2];
+  load_w2(0, wcur);
+  __syncthreads();  // image rows staged
+  for (int r = 0; r < 3; ++r) {
+    // ---- phase 1: `a` row 2 oy - 1 + r into the window (wave w takes fragments w, w + 4, ...)
+    const bool row_ok = (unsigned)(2 * oy - 1 + r) < (unsigned)f.H;
+    for (int pf = wave; pf < PF; pf += 4) {
+      const int c = 16 * pf + n16;                      // window column of this lane's pixel (image column c - 1)
+      const int cc = c < WC ? c : WC - 1;
+      const unsigned char* base = smem + IMG_OFF + (r * IW + cc) * 2;
+      unsigned h[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h[j] = *reinterpret_cast<const unsigned short*>(base + koff[j]);
+      if (g == 3) { h[3] = h[4] = h[5] = h[6] = h[7] = 0u; }  // K = 27 .. 31
+      const u32x4 xf = u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+      const bool ok = row_ok && c >= 1 && c < WC && c - 1 < f.W;
+      const int R = (c & 1) * PLANE + (c >> 1);         // LDS row of the pixel: [parity][index]
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+        Tr::mma(w1f[i], xf, d);                         // d[e] = cout 16 i + 4 g + e of pixel n16
+        unsigned q[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] = ok ? to_bits(fmaxf(d[e] * sc0[i][e] + sh0[i][e], 0.f)) : 0u;
+        if (c < WC) {
+          const int chunk = 2 * i + (g >> 1);           // 16-byte chunk of couts 16 i + 4 g .. + 3, its 8-byte half g & 1
+          *reinterpret_cast<uint2*>(smem + R * 128 + ((chunk ^ (R & 7)) << 4) + (g & 1) * 8) = uint2{q[0] | (q[1] << 16), q[2] | (q[3] << 16)};
+        }
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: taps (r, 0..2); the 1x1 conv rides on the centre tap
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int t = r * 3 + kx;
+      if (t < 8) load_w2(t + 1, wnxt);
+      const int Rb = (kx & 1) * PLANE + (kx >> 1) + n16;  // window row of output pixel n16 for this tap
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        u32x4 xf[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int R = Rb + 16 * mi;
+          xf[mi] = *reinterpret_cast<const u32x4*>(smem + R * 128 + (((kh * 4 + g) ^ (R & 7)) << 4));
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            Tr::mma(wcur[i][kh], xf[mi], acc2[mi][i]);
+            if (r == 1 && kx == 1) Tr::mma(wb1[i][kh], xf[mi], acc1[mi][i]);
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) wcur[i][kh] = wnxt[i][kh];
+    }
+    __syncthreads();  // the window may be overwritten
+  }
+  // ---- epilogues: a2 = relu(bn(acc2)) and the raw shortcut, the row's pixels (n, oy, 0 .. Wo - 1)
+  const int mbase = (img_n * Ho + oy) * WO;
+  conv_epilogue<T, MI, 2, 0>(f.e2a, acc2, mbase, n0, lane);
+  conv_epilogue<T, MI, 2, 0>(f.eb1, acc1, mbase, n0, lane);
+}
+#endif  // PS_DEBUG_HOOKS
+
+#ifdef PS_DEBUG_HOOKS
 constexpr bool kDebugBuild = true;
 #else
 constexpr bool kDebugBuild = false;
@@ -2833,3 +3008,43 @@ extern "C" int ps_conv2d_dgrad(const ps_conv_geom* g, const void* dy, const void
   if (g->dtype == PS_F16) return dispatch_bn<TraitsF16>(a, s);
   return dispatch_bn<TraitsF32>(a, s);
 }
+
+// ---- (debug library) conv1a + BN + ReLU + the first ResBlock's two stride-2 convolutions in one launch (conv_front_s2_kernel)
+#ifdef PS_DEBUG_HOOKS
+extern "C" int ps_debug_conv_front_s2_supported(int32_t dtype, int32_t n, int32_t h, int32_t w) {
+  return (dtype == PS_BF16 || dtype == PS_F16) && n > 0 && h > 0 && h % 2 == 0 && (w == 224 || w == 256) && (long long)n * (h / 2) * (w / 2) < (1LL << 24) ? 1 : 0;
+}
+
+extern "C" int ps_debug_conv_front_s2(int32_t dtype, int32_t n, int32_t h, int32_t w, const float* image, const float* w1a, const float* scale0,
+                                const float* shift0, const void* w_b1, const void* w_2a, void* out_b1, int32_t ldc_b1, const float* scale1,
+                                const float* shift1, void* out_2a, int32_t ldc_2a, void* stream) {
+  PS_REQUIRE(ps_debug_conv_front_s2_supported(dtype, n, h, w), "conv_front_s2: dtype %d, %d x %d x %d unsupported (bf16 / fp16; width 224 or 256; even height)", dtype, n, h, w);
+  PS_REQUIRE(image && w1a && scale0 && shift0 && w_b1 && w_2a && out_b1 && out_2a && scale1 && shift1, "conv_front_s2: null pointer");
+  PS_REQUIRE(ldc_b1 >= 128 && ldc_2a >= 128 && ldc_b1 % 8 == 0 && ldc_2a % 8 == 0, "conv_front_s2: channel strides");
+  PS_REQUIRE(ps_aligned16(w_b1) && ps_aligned16(w_2a) && ps_aligned16(out_b1) && ps_aligned16(out_2a) && ps_aligned16(scale0) && ps_aligned16(shift0), "conv_front_s2: misaligned");
+  FrontArgs f{};
+  f.image = image; f.w1a = w1a; f.sc0 = scale0; f.sh0 = shift0;
+  f.w_b1 = static_cast<const unsigned char*>(w_b1);
+  f.w_2a = static_cast<const unsigned char*>(w_2a);
+  f.N = n; f.H = h; f.W = w;
+  const int ho = h / 2, wo = w / 2;
+  for (IgemmArgs* e : {&f.eb1, &f.e2a}) {
+    e->Ho = ho; e->Wo = wo; e->M = e->epi_M = n * ho * wo; e->Cd = 128; e->m_off = 0;
+  }
+  f.eb1.epi.mode = PS_EPI_NONE; f.eb1.epi.out_raw = out_b1; f.eb1.epi.ldc_raw = ldc_b1;
+  f.e2a.epi.mode = PS_EPI_BNRELU; f.e2a.epi.scale = scale1; f.e2a.epi.shift = shift1; f.e2a.epi.out = out_2a; f.e2a.epi.ldc_out = ldc_2a;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)(n * ho));
+  const int nf = wo / 16;
+  const size_t lds = (size_t)2 * (wo + 1) * 128 + (size_t)3 * 5 * (2 * wo + 4) * 2;
+  if (dtype == PS_BF16) {
+    if (nf == 7) hipLaunchKernelGGL((conv_front_s2_kernel<TraitsBF16, 7>), grid, dim3(256), lds, s, f);
+    else hipLaunchKernelGGL((conv_front_s2_kernel<TraitsBF16, 8>), grid, dim3(256), lds, s, f);
+  } else {
+    if (nf == 7) hipLaunchKernelGGL((conv_front_s2_kernel<TraitsF16, 7>), grid, dim3(256), lds, s, f);
+    else hipLaunchKernelGGL((conv_front_s2_kernel<TraitsF16, 8>), grid, dim3(256), lds, s, f);
+  }
+  PS_CHECK_LAUNCH("conv_front_s2");
+  return PS_OK;
+}
+#endif  // PS_DEBUG_HOOKS

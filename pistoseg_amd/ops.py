@@ -377,6 +377,25 @@ def cast_f32_lowp(src: Tensor, dst: Tensor) -> None:
     _lib.check(lib.ps_cast_f32_lowp(src.data_ptr(), dst.data_ptr(), _dt(dst), src.numel(), _stream()), "ps_cast_f32_lowp")
 
 
+def conv_front_s2(x_nchw: Tensor, w1a: Tensor, scale0: Tensor, shift0: Tensor, w_b1: Tensor, w_2a: Tensor, out_b1: Tensor, scale1: Tensor,
+                  shift1: Tensor, out_2a: Tensor) -> None:
+    """EXPERIMENT (debug library only: `_lib.use_debug_library()` first; correct, not faster than the launches it replaces).  conv1a + BN + ReLU
+    and the first ResBlock's two stride-2 convs (1x1 shortcut, raw; 3x3 + BN + ReLU) in one launch: conv1a's activation is never written
+    (ps_debug_conv_front_s2; resnet38d.py:123,161-162 + ResBlock.forward :28-41).  w_b1 [128][1][1][64], w_2a [128][3][3][64] in the outputs'
+    16-bit type; outputs channels-last [n, h/2, w/2, 128] (channel slices of wider buffers are fine)."""
+    _require_gpu(x_nchw, w1a, w_b1, w_2a, out_b1, out_2a)
+    n, _, h, w = x_nchw.shape
+    assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and w1a.dtype == torch.float32 and w1a.numel() == 64 * 27
+    assert w_b1.dtype == w_2a.dtype == out_b1.dtype == out_2a.dtype and w_b1.numel() == 128 * 64 and w_2a.numel() == 128 * 9 * 64
+    assert out_b1.shape == out_2a.shape == (n, h // 2, w // 2, 128)
+    lib = _lib.load()
+    assert hasattr(lib, "ps_debug_conv_front_s2"), "conv_front_s2 lives in the debug library (_lib.use_debug_library())"
+    assert lib.ps_debug_conv_front_s2_supported(_dt(out_2a), n, h, w)
+    _lib.check(lib.ps_debug_conv_front_s2(_dt(out_2a), n, h, w, x_nchw.data_ptr(), w1a.data_ptr(), scale0.data_ptr(), shift0.data_ptr(), w_b1.data_ptr(),
+                                          w_2a.data_ptr(), out_b1.data_ptr(), _ldc(out_b1), scale1.data_ptr(), shift1.data_ptr(), out_2a.data_ptr(),
+                                          _ldc(out_2a), _stream()), "ps_debug_conv_front_s2")
+
+
 def conv1a_fwd(x_nchw: Tensor, w_oihw: Tensor, bn_scale: Optional[Tensor], bn_shift: Optional[Tensor], out_act: Optional[Tensor],
                out_raw: Optional[Tensor] = None) -> None:
     _require_gpu(x_nchw, w_oihw)

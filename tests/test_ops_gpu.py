@@ -1311,3 +1311,46 @@ def test_tile_queue_launch_option_is_exact(case, dtype, library):
         assert all(torch.equal(o, ref[2]) for o in outs)
     finally:
         ops.TILE_QUEUE = 0
+
+
+@debug_only
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n,h,w", [(2, 224, 224), (3, 34, 224), (1, 256, 256), (2, 6, 256)])
+def test_conv_front_fused_conv1a_and_stride2_convs(n, h, w, dtype, library):
+    """EXPERIMENT kept in the debug library (correct, not faster: profiles/r04_front_fusion.txt).  ps_debug_conv_front_s2: conv1a + BN + ReLU + the first ResBlock's 1x1 and 3x3 stride-2 convs in one launch (conv1a's activation never
+    leaves LDS) against (i) torch-CPU on identically rounded operands -- image, conv1a weights, the activation `a` and both weight sets
+    rounded to the storage type, f32 accumulation, as the unfused kernels do -- and (ii) the unfused launches themselves (resnet38d.py:123,161-162,
+    ResBlock.forward :28-41): image borders (conv1a's zero padding, the stride-2 conv's zero padding of `a`), ragged heights, both tile widths."""
+    from pistoseg_amd import ops
+
+    D = dev()
+    q = quant(dtype)
+    g = torch.Generator().manual_seed(n * 1000 + h + w)
+    x = torch.randn(n, 3, h, w, generator=g)
+    w1a = torch.randn(64, 3, 3, 3, generator=g) * 0.3
+    sc0, sh0 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    wb1 = q(torch.randn(128, 64, 1, 1, generator=g) * 0.15)
+    w2a = q(torch.randn(128, 64, 3, 3, generator=g) * 0.06)
+    sc1, sh1 = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.2
+    a = q(F.relu(F.conv2d(q(x), q(w1a), padding=1) * sc0.view(1, -1, 1, 1) + sh0.view(1, -1, 1, 1)))
+    ref_b1 = F.conv2d(a, wb1, stride=2)
+    ref_2a = F.relu(F.conv2d(a, w2a, stride=2, padding=1) * sc1.view(1, -1, 1, 1) + sh1.view(1, -1, 1, 1))
+    xd = x.to(D)
+    wide = torch.full((n, h // 2, w // 2, 128 + 64), float("nan"), device=D, dtype=dtype)  # out_2a as a channel slice of a wider buffer
+    out_2a, out_b1 = wide[..., 64:], torch.full((n, h // 2, w // 2, 128), float("nan"), device=D, dtype=dtype)
+    ops.conv_front_s2(xd, w1a.to(D), sc0.to(D), sh0.to(D), w_fwd_layout(wb1).to(D, dtype), w_fwd_layout(w2a).to(D, dtype), out_b1, sc1.to(D), sh1.to(D), out_2a)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(wide[..., :64]).all())  # nothing outside the slice is touched
+    tol = 2e-2 if dtype == torch.bfloat16 else 3e-3  # one storage rounding of the outputs + the few `a` values that round the other way
+    assert rel_err(out_b1.float().cpu(), nhwc(ref_b1)) < tol and rel_err(out_2a.float().cpu(), nhwc(ref_2a)) < tol
+    # the unfused launches
+    ad = torch.empty((n, h, w, 64), device=D, dtype=dtype)
+    ops.conv1a_fwd(xd, w1a.to(D), sc0.to(D), sh0.to(D), ad)
+    u_b1, u_2a = torch.empty_like(out_b1), torch.empty((n, h // 2, w // 2, 128), device=D, dtype=dtype)
+    ops.conv2d_fwd(ops.ConvSpec(64, 128, 1, 2, 1), ad, w_fwd_layout(wb1).to(D, dtype), out_raw=u_b1)
+    ops.conv2d_fwd(ops.ConvSpec(64, 128, 3, 2, 1), ad, w_fwd_layout(w2a).to(D, dtype), bn_scale=sc1.to(D), bn_shift=sh1.to(D), out_act=u_2a)
+    assert rel_err(out_b1.float().cpu(), u_b1.float().cpu()) < tol and rel_err(out_2a.float().cpu(), u_2a.float().cpu()) < tol
+    # most elements agree bit for bit (the rest are storage-rounding neighbours: conv1a's K = 27 sum runs in a different order)
+    same = float((out_2a == u_2a).float().mean())
+    print(f"[front {dtype} {n}x{h}x{w}] identical to the unfused launches: {same:.4f} of a2, max rel err vs CPU {rel_err(out_2a.float().cpu(), nhwc(ref_2a)):.2e}")
+    assert same > 0.9
