@@ -656,3 +656,60 @@ def test_forward_and_data_gradient_launches_are_bit_reproducible():
         ops.conv2d_dgrad(spec, gy, wd, (28, 28), out_raw=gx)
         outs.append(gx)
     assert all(torch.equal(o, outs[0]) for o in outs[1:])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16x3"])
+def test_seg_trainer_multi_step_trajectory_matches_oracle_adamw(precision):
+    """The whole training loop, not one step: SegTrainer (forward, CE, backward, fused AdamW through the C-ABI; the split path re-derives its
+    weight planes from the f32 master every step, fp16x3 runs under its loss scale) against the CPU oracle driven by torch.optim.AdamW with the same
+    hyper-parameters (segmentation_module.py:86-90), four steps on the same batch with fixed dropout masks.  Losses per step and the
+    accumulated weight update of every trainable tensor.  (Adam normalises the update: an element whose gradient is ~0 moves by ~lr in a
+    direction that rounding decides, so the update is compared by direction, the loss by value.)"""
+    from pistoseg_amd.trainer import SegTrainer
+
+    # (lr: Adam's first steps move EVERY weight by ~lr; on this synthetic initialisation 1e-3 sends the loss to 1e6 at the second step and 1e-4 to 33 -- on
+    # the device and in the oracle alike -- trajectories on which a rounding error grows tenfold per step)
+    c, n, s, steps, LR = 3, 2, 64, 4, 2e-5
+    sd = ref_cpu.make_state_dict(c, False, seed=42)
+    model = build(c, precision, sd)
+    g = torch.Generator().manual_seed(91)
+    x, *_ = make_inputs(n, s, 4, 108)
+    target = torch.randint(0, 4, (n, s, s), generator=g)  # 3 = ignore_index
+    drop = {}
+    for k, v in model.sample_dropout(n, D).items():
+        p = 0.3 if k.startswith("b6") else 0.5
+        drop[k] = (torch.rand(v.shape, generator=g) >= p).float() / (1 - p)
+    model.sample_dropout = lambda n_, dev_: {k: v.to(dev_) for k, v in drop.items()}
+    tr = SegTrainer(model, lr=LR, weight_decay=0.05, ignore_index=3, track_iou=False, loss_scale=65536.0 if precision == "fp16x3" else None)
+    w0 = tr.p_flat.clone()
+    losses = [float(tr.train_step(x.to(D), target.to(D))) for _ in range(steps)]
+    if hasattr(tr, "settle"):
+        tr.settle()
+    assert tr.skipped_steps == 0
+
+    sd_ref = {k: v.clone() for k, v in sd.items()}
+    tk = ref_cpu.trainable_keys(sd_ref)
+    for k in tk:
+        sd_ref[k].requires_grad_(True)
+    opt = torch.optim.AdamW([sd_ref[k] for k in tk], lr=LR, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8)
+    ref_losses = []
+    for _ in range(steps):
+        opt.zero_grad()
+        loss = ref_cpu.seg_ce_loss(ref_cpu.seg_forward(sd_ref, x, drop), target, 3)
+        loss.backward()
+        opt.step()
+        ref_losses.append(float(loss.detach()))
+    tol = 1e-5 if precision == "fp32" else 1e-4  # first step; every further step may multiply an earlier difference (ReLU boundaries, Adam's normalisation)
+    for k, (a, b) in enumerate(zip(losses, ref_losses)):
+        assert abs(a - b) < tol * 4 ** k * abs(b), (k, losses, ref_losses)
+    assert ref_losses[-1] < ref_losses[0]  # (the steps do something)
+    worst = 1.0
+    for k in tk:
+        o, cnt = tr.offsets[k]
+        shape = sd[k].shape  # OIHW; the arena holds [cout][kh][kw][cin]
+        dev_upd = (tr.p_flat[o:o + cnt] - w0[o:o + cnt]).cpu().view(shape[0], shape[2], shape[3], shape[1]).permute(0, 3, 1, 2).double()
+        ref_upd = (sd_ref[k].detach() - sd[k]).double()
+        cos = float((dev_upd * ref_upd).sum() / (dev_upd.norm() * ref_upd.norm()))
+        worst = min(worst, cos)
+        assert cos > (0.995 if precision == "fp32" else 0.98), (k, cos)
+    print(f"[{precision}] {steps}-step trajectory: losses {['%.6f' % v for v in losses]} vs oracle {['%.6f' % v for v in ref_losses]}, worst update cosine {worst:.5f}")
