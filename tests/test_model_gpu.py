@@ -486,6 +486,36 @@ def test_seg_trainer_deterministic_runs_are_bit_identical(precision, n, s):
     assert e < 5e-2
 
 
+def test_seg_trainer_deterministic_steps_are_bit_identical_under_the_tile_queue():
+    """The `tile_queue` launch option (every tile / work item of the persistent kernels drawn from ticket counters instead of a static
+    schedule; what `share="queue"` switches on beside a collective) only changes WHICH block computes a tile: with deterministic weight
+    gradients three whole training steps at a batch where the halo kernel and the weight gradient really draw (24 tiles of 224 x 224:
+    336 tiles, 500+ weight-gradient items per launch) leave every weight bit for bit where the static schedule leaves it -- on both streams
+    of the two-stream backward."""
+    from pistoseg_amd.trainer import SegTrainer
+
+    def run(queue):
+        torch.manual_seed(0)
+        sd = ref_cpu.make_state_dict(3, False, seed=42)
+        model = build(3, "bf16", sd)
+        g = torch.Generator().manual_seed(5)
+        drops = model.sample_dropout(24, D)
+        fixed = {k: (torch.rand(v.shape, generator=g) >= 0.5).float().to(D) * 2 for k, v in drops.items()}
+        model.sample_dropout = lambda n_, dev_: fixed
+        tr = SegTrainer(model, lr=1e-4, track_iou=False, deterministic=True)
+        model.launch.tile_queue = 1 if queue else None
+        x = torch.randn(24, 3, 224, 224, generator=g).to(D)
+        y = torch.randint(0, 4, (24, 224, 224), generator=g).to(D)
+        losses = [float(tr.train_step(x, y)) for _ in range(3)]
+        torch.cuda.synchronize()
+        return losses, tr.p_flat.clone()
+
+    la, pa = run(False)
+    lb, pb = run(True)
+    assert la == lb, (la, lb)
+    assert torch.equal(pa, pb)
+
+
 def test_bench_batch_bf16_logits_vs_oracle():
     """BASELINE configs[1] says "logits checked vs CPU": the exact batch `bench.py` trains on (bs=64, 224x224, seed 1234, He-init weights
     seed 42, bf16 storage / f32 accumulate) goes through the model in one launch sequence; tiles 0 and 37 are compared with the CPU
