@@ -1207,7 +1207,11 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_ws_kernel(const IgemmArgs a
 //   * the loaders run two K-steps ahead (counted vmcnt), so a DMA has two barrier intervals (~2 x 1024 cycles) to land.
 // BM = 224 (7-fragment waves) makes 28x28-derived pixel counts tile exactly: 64 x 784 = 224 x 224.
 // ------------------------------------------------------------------------------------------------
-template <typename Tr, int BM, bool SPLIT = false>  // SPLIT: one parity class of a stride-2 data gradient (IgemmArgs::tap_mask ...)
+// Q: every tile comes from the launch's ticket queue (a.queue; ps_internal.h, conv_igemm_halo_kernel).  Tiles here can be as short as two
+// K-steps, so consumer wave 0 draws TWO tiles ahead: the tickets of tiles 0 and 1 at the top of the kernel, the ticket of tile s + 2 when tile s
+// starts, collected and published in front of tile s's LAST barrier -- a whole tile before the loaders (two K-steps ahead of the consumers)
+// cross into tile s + 2.  Four mailbox entries: s + 1, s + 2 and the one being read.
+template <typename Tr, int BM, bool SPLIT = false, bool Q = false>  // SPLIT: one parity class of a stride-2 data gradient (IgemmArgs::tap_mask ...)
 __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs a) {
   typedef typename Tr::elem T [[maybe_unused]];
   constexpr int BN = 128, MI = BM / 32, WI = 4, WM = 16 * MI, WN = 64;
@@ -1224,11 +1228,26 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
   // the consumers are still in the epilogue, and the epilogue's global stores drain behind the next tile's main loop (with
   // one block per CU and equal tiles, every CU reaches its epilogue at the same time: as separate blocks the stores of a
   // whole round -- tens of MB -- were exposed at HBM speed before any CU could start its next tile).
-  int first, G, ntiles;  // this block's tiles: first, first + G, ... < ntiles
-  ps_block_items(blockIdx.x, gridDim.x, a.ntm * a.ntn, a.nb, a.tpb, first, G, ntiles);
+  int first, G, ntiles;  // this block's tiles: first, first + G, ... < ntiles  (Q: whatever the queue hands out)
+  [[maybe_unused]] unsigned q_tk = 0, q_tk1 = 0;  // Q, consumer wave 0: the ticket in flight (two at the top of the kernel)
+  [[maybe_unused]] bool q_pk = false;             // ... and whether that draw also looks at the other classes' counters (wave-uniform)
+  [[maybe_unused]] const unsigned mbox = ps_q_mbox_addr(smem + 3 * STAGE);
+  if constexpr (Q) {
+    static_assert(!SPLIT, "the parity-class launches keep the static schedule");
+    G = 0;
+    first = -1;
+    ntiles = a.ntm * a.ntn;
+    q_pk = ps_q_count(ntiles, blockIdx.x & 7) <= 96;
+    if (wave == 0) {
+      ps_q_draw_begin(a.queue, blockIdx.x & 7, lane, q_pk, q_tk);
+      ps_q_draw_begin(a.queue, blockIdx.x & 7, lane, q_pk, q_tk1);
+    }
+  } else {
+    ps_block_items(blockIdx.x, gridDim.x, a.ntm * a.ntn, a.nb, a.tpb, first, G, ntiles);
+  }
   const int ntap = SPLIT ? __builtin_popcount(a.tap_mask) : a.taps;
   const int nsteps = ntap * a.klines;
-  const int my_tiles = (ntiles - first + G - 1) / G;  // >= 1
+  const int my_tiles = Q ? 1 : (ntiles - first + G - 1) / G;  // >= 1
   const int total_steps = my_tiles * nsteps;
 
   if (wave >= 4) {
@@ -1291,7 +1310,14 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
       tap = 0; kl = 0; wk = SPLIT ? tap_id(0) * a.klines * 128 : 0;
       tap_offsets(0);
     };
+    if constexpr (Q) {  // the block's first tile (published by consumer wave 0 in front of this barrier)
+      __builtin_amdgcn_s_barrier();
+      first = ps_q_mbox_read(mbox, 0);
+      if (first < 0) return;
+    }
     int tile = first, slot = 0, issued = 0;
+    [[maybe_unused]] int l_seq = 0;        // Q: tiles this cursor has left behind
+    [[maybe_unused]] bool l_done = false;  // Q: the last K-step of the block's last tile has been staged
     tile_setup(tile);
     // stages the next K-step of the flat sequence (exactly NLD loads per wave); the caller guarantees issued < total_steps (no end test and,
     // in the product build, no selector test in the issue path: it is on the K-step's critical path)
@@ -1312,6 +1338,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
         if (++tap < ntap) {
           tap_offsets(tap);
           if constexpr (SPLIT) wk = tap_id(tap) * a.klines * 128;
+        } else if constexpr (Q) {
+          tile = ps_q_mbox_read(mbox, ++l_seq);
+          if (tile >= 0) tile_setup(tile);
+          else l_done = true;
         } else if (issued < total_steps) {
           tile += G;
           tile_setup(tile);
@@ -1323,6 +1353,21 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
       else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
     };
     // Steps 0 and 1, then one step per barrier while there are steps left to stage, then the drain (nothing to stage: everything landed).
+    if constexpr (Q) {  // (every tile has at least two K-steps: the dispatcher's condition)
+      issue_next();
+      issue_next();
+      wait_newest_in_flight();
+      __builtin_amdgcn_s_barrier();  // step 0 visible
+      while (!l_done) {
+        issue_next();
+        wait_newest_in_flight();
+        __builtin_amdgcn_s_barrier();
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
+      return;
+    }
     if (total_steps > 0) issue_next();  // (a block without work stages nothing; it still meets the consumers' first barrier)
     if (total_steps > 1) {
       issue_next();
@@ -1352,9 +1397,27 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
   const int sw = lane & 7;
   const int coff0 = (g ^ sw) << 4, coff1 = ((g + 4) ^ sw) << 4;
 
+  if constexpr (Q) {
+    if (wave == 0) {
+      bool pk0 = q_pk, pk1 = q_pk;
+      ps_q_mbox_write(mbox, 0, ps_q_resolve(a.queue, blockIdx.x & 7, lane, 0, ntiles, q_tk, pk0));
+      ps_q_mbox_write(mbox, 1, ps_q_resolve(a.queue, blockIdx.x & 7, lane, 0, ntiles, q_tk1, pk1));
+      q_pk = pk0 || pk1;
+    }
+    __builtin_amdgcn_s_barrier();
+    first = ps_q_mbox_read(mbox, 0);
+    if (first < 0) {
+      if (wave == 0) ps_q_block_done(a.queue, lane, gridDim.x);
+      return;
+    }
+  }
   __builtin_amdgcn_s_barrier();  // step 0 visible
   int cur = 0;
-  for (int tile = first; tile < ntiles; tile += G) {
+  [[maybe_unused]] int q_seq = 0;
+  for (int tile = first; Q ? tile >= 0 : tile < ntiles; tile = Q ? ps_q_mbox_read(mbox, ++q_seq) : tile + G) {
+    if constexpr (Q) {  // the ticket of this block's tile q_seq + 2: in flight until the tile's last K-step
+      if (wave == 0) ps_q_draw_begin(a.queue, blockIdx.x & 7, lane, q_pk, q_tk);
+    }
     f32x4 acc[MI][WI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -1414,6 +1477,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
       cur = (cur == 2) ? 0 : cur + 1;
     }
     for (int s = 1; s < nsteps; ++s) {
+      if constexpr (Q) {
+        if (s == nsteps - 1 && wave == 0)
+          ps_q_mbox_write(mbox, q_seq + 2, ps_q_resolve(a.queue, blockIdx.x & 7, lane, 0, ntiles, q_tk, q_pk));
+      }
       const unsigned char* st = smem + cur * STAGE;
       // this step's first K-half is read behind the previous step's outstanding MFMAs (plain: its second half; split: x_hi . w_lo)
       if constexpr (Tr::split) half(st, coff0, wf0, xf0, wf1, xf0, true);
@@ -1433,6 +1500,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
     int tm, tn;
     ps_tile_of_block(tile, a.ntn, a.ntm, tm, tn, a.supertile);
     conv_epilogue<typename Tr::epi, MI, WI, SPLIT ? 2 : 0>(a, acc, tm * BM + wm * WM, tn * BN + wn * WN, lane);
+  }
+  if constexpr (Q) {
+    if (wave == 0) ps_q_block_done(a.queue, lane, gridDim.x);  // (every draw of this block has returned: the last one was resolved in the last tile)
   }
 }
 
@@ -2732,6 +2802,18 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s, bool allow_gemm256 = true) {
     b.tpb = a.tpb;
     const dim3 pgrid(ps_persistent_grid((long long)b.ntm * b.ntn, b.nb, b.tpb));  // persistent: one block per CU (per batch)
     if constexpr (kLargeTiles) {
+      // tile_queue: where there is something to hand out and a tile has at least two K-steps
+      if constexpr (sizeof(typename Tr::elem) == 2) {
+        if (a.use_queue && (v == PS_CONV_WS2_256 || v == PS_CONV_WS2_224) && (long long)b.ntm * b.ntn > b.nb && a.taps * a.klines >= 2) {
+          b.queue = ps_queue_slot(s);
+          PS_REQUIRE(b.queue != nullptr, "conv: no ticket counters (hipMalloc failed)");
+          const dim3 qgrid((unsigned)b.nb);
+          if (v == PS_CONV_WS2_256) hipLaunchKernelGGL((conv_igemm_ws2_kernel<Tr, 256, false, true>), qgrid, dim3(512), 3 * (256 * 128 + 128 * 128) + 16, s, b);
+          else hipLaunchKernelGGL((conv_igemm_ws2_kernel<Tr, 224, false, true>), qgrid, dim3(512), 3 * (224 * 128 + 128 * 128) + 16, s, b);
+          PS_CHECK_LAUNCH("conv_igemm_ws2<queue>");
+          return PS_OK;
+        }
+      }
       if (v == PS_CONV_WS2_256) {
         hipLaunchKernelGGL((conv_igemm_ws2_kernel<Tr, 256>), pgrid, dim3(512), 3 * (256 * 128 + 128 * 128), s, b);
         PS_CHECK_LAUNCH("conv_igemm_ws2");

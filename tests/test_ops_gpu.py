@@ -1253,7 +1253,8 @@ def test_conv_halo_tail_as_half_tiles(case, dtype, library):
     (64, 28, 28, 128, 512, 3, 1),    # 896 tiles = 3.5 rounds (main launch from the queue + a static tail launch of half tiles); 2 K-lines: the shortest tile the queue serves
     (23, 56, 56, 128, 256, 3, 1),    # two column blocks per row, ragged last tile
     (17, 32, 32, 64, 512, 3, 4),     # 256-pixel tiles, ONE K-line: the dispatcher keeps the static kernel (nothing to compare, must still be identical)
-    (36, 28, 28, 512, 512, 1, 1),    # 1x1: the weight gradient's XM = 2 instantiation (the forward stays on the static ws2 kernel)
+    (36, 28, 28, 512, 512, 1, 1),    # 1x1: conv_igemm_ws2_kernel's queue (tiles of eight K-steps, drawn two ahead), the weight gradient's XM = 2 instantiation
+    (37, 28, 28, 128, 512, 1, 1),    # 1x1 with TWO K-steps per tile: the shortest tile the ws2 queue serves; ragged last pixel tile
 ])
 def test_tile_queue_launch_option_is_exact(case, dtype, library):
     """ps_conv_geom.tile_queue = 1: every tile (halo kernel) / work item (weight gradient) is drawn from per-XCD ticket counters by the blocks

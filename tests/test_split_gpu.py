@@ -171,12 +171,14 @@ def test_split_conv_rejects_narrow_channel_strides():
 
 
 @pytest.mark.parametrize("dt", [BF, HF])
-def test_split_convs_through_the_tile_queue_are_bit_identical(dt):
+@pytest.mark.parametrize("GEOM", [(24, 28, 28, 256, 512, 3, 2),    # halo kernel: 84 pixel tiles x 4 cout tiles = 336 tiles
+                                  (37, 28, 28, 256, 512, 1, 1)])   # a GEMM: the split types' conv_igemm_ws2_kernel, 130 x 4 = 520 tiles
+def test_split_convs_through_the_tile_queue_are_bit_identical(dt, GEOM):
     """ps_conv_geom.tile_queue = 1 on the split types (halo kernel with three MFMA groups per K-line, weight gradient on the gathered hi halves):
     same bits as the static schedule for forward and data gradient, f32 atomic ordering for the weight gradient."""
     from pistoseg_amd import ops
 
-    n, h, w, cin, cout, k, d = 24, 28, 28, 256, 512, 3, 2  # 84 pixel tiles x 4 cout tiles = 336 tiles
+    n, h, w, cin, cout, k, d = GEOM
     spec = ops.ConvSpec(cin, cout, k, 1, d)
     g = torch.Generator().manual_seed(77)
     PL = lambda t: planes(t, False, dt)
