@@ -71,7 +71,7 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="weight gradients on the launch stream instead of a second stream")
     ap.add_argument("--grad-payload", default="fp32", choices=["fp32", "bf16"],
                     help="N > 1: wire format of the gradient exchange (bf16: buckets cast, all-reduced, widened back: half the xGMI bytes)")
-    ap.add_argument("--share", default="batch", help="N > 1: how the conv launches make room for the collectives while buckets are in flight: "
+    ap.add_argument("--share", default="reserve+queue", help="N > 1: how the conv launches make room for the collectives while buckets are in flight: "
                                                      "'batch' (tiles_per_block = 1), 'reserve[:CUS]' (cus_reserved, default 32), 'queue' (tile_queue: in-kernel ticket queues) "
                                                      "or 'reserve+queue[:CUS]'")
     ap.add_argument("--cpu-tiles", type=int, default=8, help="tiles per CPU-baseline step (SURVEY 8d: bs=8, 1 warm-up + 3 timed)")

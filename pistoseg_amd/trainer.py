@@ -92,10 +92,12 @@ class SegTrainer(_ArenaMixin):
     def __init__(self, model: ResNet38dSeg, lr: float = 1e-3, weight_decay: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8,
                  ignore_index: Optional[int] = 3, process_group=None, bucket_mb: float = 48.0, track_iou: bool = True,
                  loss_scale: Optional[float] = None, overlap_wgrad: bool = True, deterministic: Optional[bool] = None, grad_payload: str = "fp32",
-                 share: str = "batch", reserved_cus: int = 32):
+                 share: str = "reserve+queue", reserved_cus: int = 32):
         """grad_payload: what the N > 1 gradient exchange puts on the wire -- "fp32" (SUM all-reduce of the f32 arena slices) or "bf16" (each
         bucket cast to bf16, all-reduced, widened back: half the xGMI bytes; see dist.BucketedAllReduce).  share / reserved_cus: how this model's
-        conv launches make room for the collectives while buckets are in flight ("batch": tiles_per_block = 1; "reserve": cus_reserved)."""
+        conv launches make room for the collectives while buckets are in flight ("batch": tiles_per_block = 1; "reserve": cus_reserved; "queue": tile_queue;
+        "reserve+queue", the default: both -- beside a kernel that holds 16 / 48 CUs a step costs + 9 % / + 25 % with it, + 14 % / + 29 % in batch mode, + 8 % /
+        + 50 % under the bare reservation: profiles/r04_hog_step_probe_queue.txt)."""
         assert next(model.parameters()).is_cuda, "move the model to the GPU first"
         self.model = model
         # `pl.Trainer(deterministic=True)` (segmentation_train.py:153-160): weight gradients without atomics (ps_conv2d_wgrad_det), so two
@@ -237,7 +239,7 @@ class RFMTrainer(_ArenaMixin):
 
     def __init__(self, model, lr: float = 0.01, wt_dec: float = 5e-4, max_step: int = 1000, power: float = 0.9, process_group=None,
                  bucket_mb: float = 48.0, loss_scale: Optional[float] = None, overlap_wgrad: bool = True, deterministic: Optional[bool] = None,
-                 grad_payload: str = "fp32", share: str = "batch", reserved_cus: int = 32):
+                 grad_payload: str = "fp32", share: str = "reserve+queue", reserved_cus: int = 32):
         from .revise_net import FCAT, Net
 
         assert isinstance(model, Net) and next(model.parameters()).is_cuda

@@ -40,14 +40,14 @@ def test_bench_gpus_2_launches_two_rccl_ranks_when_the_box_has_them():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload", ["seg", "rfm", "infer2", "infer4", "seg+bf16+reserve"])
+@pytest.mark.parametrize("workload", ["seg", "rfm", "infer2", "infer4", "seg+bf16+batch"])
 def test_bench_multi_rank_control_flow_on_a_shared_gpu(workload):
     """The N > 1 control flow of bench.py -- child torch.distributed.run launch, init, barrier-bracketed timing with MAX over ranks, the
     lockstep instrumented step (it contains collectives), teardown, ONE JSON line from rank 0 -- with two ranks sharing the test GPU over gloo
     (PISTOSEG_BENCH_TEST_BACKEND: RCCL itself refuses two ranks on one device).  Checks the line's bookkeeping, not its numbers."""
     extra = []
-    if workload == "seg+bf16+reserve":  # the second wire format and the CU reservation through the bench's own N > 1 path
-        workload, extra = "seg", ["--grad-payload", "bf16", "--share", "reserve+queue:32"]
+    if workload == "seg+bf16+batch":  # the second wire format and the older sharing mode through the bench's own N > 1 path (the default is reserve+queue)
+        workload, extra = "seg", ["--grad-payload", "bf16", "--share", "batch"]
     argv = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--tile", "64", "--no-cpu-baseline", "--workload", workload, *extra]
     r = run_bench(*argv, env={"PISTOSEG_BENCH_TEST_BACKEND": "gloo"})
     assert r.returncode == 0, r.stderr[-3000:]
@@ -59,7 +59,9 @@ def test_bench_multi_rank_control_flow_on_a_shared_gpu(workload):
         assert line["config"]["tiles_per_gpu"] == 4 and line["value"] > 0
     else:
         assert line["config"]["global_batch"] == 4 and line["value"] > 0
+    if workload in ("seg", "rfm") and not extra:
+        assert line["config"]["share"] == "reserve+queue"
     if workload in ("seg", "rfm"):
         assert "roofline" in line and "cpu_baseline" not in line and "test_backend" in line
     if extra:
-        assert line["config"]["grad_payload"] == "bf16" and line["config"]["share"] == "reserve+queue:32" and line["final_loss"] == line["final_loss"]
+        assert line["config"]["grad_payload"] == "bf16" and line["config"]["share"] == "batch" and line["final_loss"] == line["final_loss"]

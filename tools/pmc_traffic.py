@@ -33,9 +33,10 @@ for k in sorted(set(fe) | set(wr)):
     def api_launches(d):
         n = 0.0
         for name, v in d.items():
-            if "conv_igemm_halo_kernel" in name and name.rstrip().endswith(", 2>((anonymous namespace)::IgemmArgs)"):
+            # template arguments: halo <traits, tile width, ring depth, WI[, queue]>, ws2 <traits, pixel tile, SPLIT[, queue]>
+            if re.search(r"conv_igemm_halo_kernel<.*, \d+, \d+, 2(?:, (?:true|false))?>\(", name):
                 continue                       # tail dispatch of a launch already counted through its main dispatch
-            n += len(v) / 4.0 if ("conv_igemm_ws2_kernel" in name and "true>" in name) else len(v)
+            n += len(v) / 4.0 if re.search(r"conv_igemm_ws2_kernel<.*, \d+, true(?:, (?:true|false))?>\(", name) else len(v)
         return max(n, 1.0)
 
     launches = api_launches(f if f else w)
