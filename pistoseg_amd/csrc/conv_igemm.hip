@@ -2849,7 +2849,7 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s, bool allow_gemm256 = true) {
 
 }  // namespace
 
-// Ticket counters of the queue-mode launches: per (device, stream) a ring of counter blocks (nine counters, one 128-byte line each), zeroed once; every launch takes the next
+// Ticket counters of the queue-mode launches: per (device, stream) a ring of counter blocks (nine counters, one 128-byte line each), zeroed once (on that stream); every launch takes the next
 // block of its stream's ring.  A launch leaves its block zeroed (ps_q_block_done) and launches of one stream run in order, so a block is
 // never shared by two launches in flight.
 unsigned* ps_queue_slot(hipStream_t stream) {
@@ -2864,7 +2864,9 @@ unsigned* ps_queue_slot(hipStream_t stream) {
   if (it == rings.end()) {
     unsigned* d = nullptr;
     if (hipMalloc(&d, kSlots * kDwords * sizeof(unsigned)) != hipSuccess) return nullptr;
-    if (hipMemset(d, 0, kSlots * kDwords * sizeof(unsigned)) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    // zeroed ON THE LAUNCH STREAM: a null-stream hipMemset is not ordered with kernels on a non-blocking stream (torch's side streams), and
+    // recycled device memory is not zero -- the first launches of a new stream would draw from garbage counters
+    if (hipMemsetAsync(d, 0, kSlots * kDwords * sizeof(unsigned), stream) != hipSuccess) { (void)hipFree(d); return nullptr; }
     it = rings.emplace(std::make_pair(dev, stream), Ring{d, 0u}).first;
   }
   Ring& r = it->second;
