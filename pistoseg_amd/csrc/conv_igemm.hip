@@ -1207,10 +1207,12 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_ws_kernel(const IgemmArgs a
 //   * the loaders run two K-steps ahead (counted vmcnt), so a DMA has two barrier intervals (~2 x 1024 cycles) to land.
 // BM = 224 (7-fragment waves) makes 28x28-derived pixel counts tile exactly: 64 x 784 = 224 x 224.
 // ------------------------------------------------------------------------------------------------
-// Q: every tile comes from the launch's ticket queue (a.queue; ps_internal.h, conv_igemm_halo_kernel).  Tiles here can be as short as two
+// Q: every tile comes from the launch's ticket queue (a.queue; ps_internal.h, conv_igemm_halo_kernel).  Tiles here can be as short as three
 // K-steps, so consumer wave 0 draws TWO tiles ahead: the tickets of tiles 0 and 1 at the top of the kernel, the ticket of tile s + 2 when tile s
-// starts, collected and published in front of tile s's LAST barrier -- a whole tile before the loaders (two K-steps ahead of the consumers)
-// cross into tile s + 2.  Four mailbox entries: s + 1, s + 2 and the one being read.
+// starts, collected and published in front of tile s's LAST barrier, number (s + 1) n of the block (n = K-steps per tile).  The loaders stage two
+// K-steps ahead: they cross into tile s + 2 in their iteration (s + 2) n - 3, behind barrier (s + 2) n - 3 -- not earlier than the publication
+// iff n >= 3 (the dispatcher's condition; with n = 2 they would read the mailbox one barrier early).  Four mailbox entries: s + 1, s + 2 and the
+// one being read.
 template <typename Tr, int BM, bool SPLIT = false, bool Q = false>  // SPLIT: one parity class of a stride-2 data gradient (IgemmArgs::tap_mask ...)
 __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs a) {
   typedef typename Tr::elem T [[maybe_unused]];
@@ -1353,7 +1355,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
       else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
     };
     // Steps 0 and 1, then one step per barrier while there are steps left to stage, then the drain (nothing to stage: everything landed).
-    if constexpr (Q) {  // (every tile has at least two K-steps: the dispatcher's condition)
+    if constexpr (Q) {  // (every tile has at least three K-steps: the dispatcher's condition)
       issue_next();
       issue_next();
       wait_newest_in_flight();
@@ -2802,9 +2804,10 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s, bool allow_gemm256 = true) {
     b.tpb = a.tpb;
     const dim3 pgrid(ps_persistent_grid((long long)b.ntm * b.ntn, b.nb, b.tpb));  // persistent: one block per CU (per batch)
     if constexpr (kLargeTiles) {
-      // tile_queue: where there is something to hand out and a tile has at least two K-steps
+      // tile_queue: where there is something to hand out and a tile has at least THREE K-steps (the loaders stage two K-steps ahead: with
+      // two-step tiles they cross into tile s + 2 one barrier before the consumers publish it at the end of tile s)
       if constexpr (sizeof(typename Tr::elem) == 2) {
-        if (a.use_queue && (v == PS_CONV_WS2_256 || v == PS_CONV_WS2_224) && (long long)b.ntm * b.ntn > b.nb && a.taps * a.klines >= 2) {
+        if (a.use_queue && (v == PS_CONV_WS2_256 || v == PS_CONV_WS2_224) && (long long)b.ntm * b.ntn > b.nb && a.taps * a.klines >= 3) {
           b.queue = ps_queue_slot(s);
           PS_REQUIRE(b.queue != nullptr, "conv: no ticket counters (hipMalloc failed)");
           const dim3 qgrid((unsigned)b.nb);

@@ -516,6 +516,48 @@ def test_seg_trainer_deterministic_steps_are_bit_identical_under_the_tile_queue(
     assert torch.equal(pa, pb)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16x3"])
+def test_every_forward_conv_launch_is_bit_identical_under_the_tile_queue(precision, monkeypatch):
+    """Launch by launch: the backbone's forward at a batch where the persistent kernels draw (24 tiles of 224 x 224), every output tensor of every
+    `ops.conv2d_fwd` call under `tile_queue = 1` against the static schedule -- the shapes no single-op test lists exhaustively (the 1x1 stride-2
+    shortcut convs' two-K-step tiles are where the ws2 queue's first version read its mailbox one barrier early)."""
+    from pistoseg_amd import ops
+    from pistoseg_amd.seg_model import ResNet38dSeg
+    from pistoseg_amd.trainer import init_weights_he
+
+    model = ResNet38dSeg(3, precision)
+    init_weights_he(model, seed=42)
+    model = model.to(D)
+    x = torch.randn(24, 3, 224, 224, generator=torch.Generator().manual_seed(5)).to(D)
+    rec = []
+    orig = ops.conv2d_fwd
+
+    def recording(spec, x_, w_, **kw):
+        r = orig(spec, x_, w_, **kw)
+        rec.append((f"{spec.cin}->{spec.cout} k{spec.ksize} s{spec.stride} d{spec.dilation} @{x_.shape[1]}",
+                    [kw[k].clone() for k in ("out_raw", "out_act") if kw.get(k) is not None]))
+        return r
+
+    monkeypatch.setattr(ops, "conv2d_fwd", recording)
+    for train in (False, True):
+        model.train(train)
+        torch.manual_seed(0)
+        fixed = {k: (torch.rand(v.shape, generator=torch.Generator().manual_seed(1)) >= 0.5).float().to(D) * 2 for k, v in model.sample_dropout(24, D).items()}
+        runs = []
+        for q in (None, 1, 1):
+            model.launch.tile_queue = q
+            rec.clear()
+            with torch.no_grad():
+                model.run_backbone(x, save=train, drop=fixed if train else None)
+            torch.cuda.synchronize()
+            runs.append(list(rec))
+        model.launch.tile_queue = None
+        assert len(runs[0]) >= 38 and len(runs[1]) == len(runs[0]) == len(runs[2])
+        for i, (name, outs) in enumerate(runs[0]):
+            for r in (1, 2):
+                assert all(torch.equal(a, b) for a, b in zip(outs, runs[r][i][1])), (train, r, i, name)
+
+
 def test_bench_batch_bf16_logits_vs_oracle():
     """BASELINE configs[1] says "logits checked vs CPU": the exact batch `bench.py` trains on (bs=64, 224x224, seed 1234, He-init weights
     seed 42, bf16 storage / f32 accumulate) goes through the model in one launch sequence; tiles 0 and 37 are compared with the CPU

@@ -1254,7 +1254,8 @@ def test_conv_halo_tail_as_half_tiles(case, dtype, library):
     (23, 56, 56, 128, 256, 3, 1),    # two column blocks per row, ragged last tile
     (17, 32, 32, 64, 512, 3, 4),     # 256-pixel tiles, ONE K-line: the dispatcher keeps the static kernel (nothing to compare, must still be identical)
     (36, 28, 28, 512, 512, 1, 1),    # 1x1: conv_igemm_ws2_kernel's queue (tiles of eight K-steps, drawn two ahead), the weight gradient's XM = 2 instantiation
-    (37, 28, 28, 128, 512, 1, 1),    # 1x1 with TWO K-steps per tile: the shortest tile the ws2 queue serves; ragged last pixel tile
+    (37, 28, 28, 128, 512, 1, 1),    # 1x1 with TWO K-steps per tile: too short for the ws2 queue's two-tile lead (static kernel; must still be identical)
+    (37, 28, 28, 192, 512, 1, 1),    # ... and THREE: the shortest tile the ws2 queue serves; ragged last pixel tile
 ])
 def test_tile_queue_launch_option_is_exact(case, dtype, library):
     """ps_conv_geom.tile_queue = 1: every tile (halo kernel) / work item (weight gradient) is drawn from per-XCD ticket counters by the blocks
