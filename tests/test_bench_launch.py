@@ -59,7 +59,7 @@ def test_bench_multi_rank_control_flow_on_a_shared_gpu(workload):
         assert line["config"]["tiles_per_gpu"] == 4 and line["value"] > 0
     else:
         assert line["config"]["global_batch"] == 4 and line["value"] > 0
-    if workload in ("seg", "rfm") and not extra:
+    if workload == "seg" and not extra:
         assert line["config"]["share"] == "reserve+queue"
     if workload in ("seg", "rfm"):
         assert "roofline" in line and "cpu_baseline" not in line and "test_backend" in line
