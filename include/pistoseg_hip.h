@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PS_VERSION 224 /* major*10000 + minor*100 + patch */
+#define PS_VERSION 225 /* major*10000 + minor*100 + patch */
 
 typedef enum ps_status {
   PS_OK = 0,
@@ -116,6 +116,10 @@ typedef struct ps_epilogue {
   const void* mask_src; int32_t ldc_mask;  int32_t _pad1;
   const void* add1;     int32_t ldc_add1;  int32_t _pad2;
   void*       out;      int32_t ldc_out;   int32_t _pad3;
+  void*       out_hi;   int32_t ldc_hi;    int32_t _pad4;  /* split types only (NULL otherwise): `out`'s hi halves ALSO as a plain 16-bit tensor
+                                             * [M, >= C] (bf16 for PS_BF16X3, fp16 for PS_F16X3): contiguous rows for the weight gradient, which
+                                             * contracts over pixels (ps_conv2d_wgrad on the plain type with x = such a copy: the x_hi dy_hi term
+                                             * at the plain kernel's speed instead of a gather of every other 64 bytes) */
 } ps_epilogue;
 
 /* 1 if the MFMA implicit-GEMM path handles this geometry, else 0 (message in ps_last_error). */

@@ -43,6 +43,7 @@ class Epilogue(C.Structure):
         ("mask_src", C.c_void_p), ("ldc_mask", C.c_int32), ("_pad1", C.c_int32),
         ("add1", C.c_void_p), ("ldc_add1", C.c_int32), ("_pad2", C.c_int32),
         ("out", C.c_void_p), ("ldc_out", C.c_int32), ("_pad3", C.c_int32),
+        ("out_hi", C.c_void_p), ("ldc_hi", C.c_int32), ("_pad4", C.c_int32),
     ]
 
 

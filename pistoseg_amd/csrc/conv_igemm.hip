@@ -340,8 +340,12 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
         __builtin_amdgcn_sched_barrier(0);
       }
     };
-    auto store_rows = [&](void* base, int ldc, bool bnrelu) {  // bnrelu: max(acc * sc + sh, 0) on the way out (a select, not a branch)
+    // hi_base (split types, `out` only): ALSO the hi halves as a plain 16-bit tensor of row stride hi_ldc -- what the weight gradient, which
+    // contracts over pixels and wants contiguous hi rows, reads instead of gathering every other 64 bytes of the split tensor (ps_epilogue.out_hi)
+    auto store_rows = [&](void* base, int ldc, bool bnrelu, void* hi_base = nullptr, int hi_ldc = 0) {  // bnrelu: max(acc * sc + sh, 0) on the way out (a select, not a branch)
       const __amdgpu_buffer_rsrc_t rs = rsrc(base, ldc);
+      [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_hi =
+          __builtin_amdgcn_make_buffer_rsrc(X3 && hi_base ? hi_base : base, 0, X3 && hi_base ? a.epi_M * hi_ldc * 2 : 0, 0x00020000);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -354,6 +358,12 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
             f[i] = bnrelu ? y : x;
           }
           Raw8<T>::store(rs, roff(mi, ldc, cb) + 8 * o * ES, f);
+          if constexpr (X3) {
+            if (hi_base) {
+              const int row = MAP == 2 ? rrow[MAP == 2 ? mi : 0] : row0 + mi * RSTEP;
+              Raw8<PT>::store(rs_hi, (row * hi_ldc + cb + 8 * o) * 2, f);  // RNE cast = the split tensor's hi half
+            }
+          }
         }
     };
     if (e.add0) add_rows(e.add0, e.ldc_add0);
@@ -394,6 +404,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
           }
           ps_store8<PT>(p, hi);
           ps_store8<PT>(p + 32, lo);
+          if (e.out_hi) ps_store8<PT>(reinterpret_cast<PT*>(e.out_hi) + (long long)m * e.ldc_hi + c, hi);
         } else {
           ps_store8<T>(reinterpret_cast<T*>(base) + (long long)m * ldc + c, v);
         }
@@ -454,7 +465,7 @@ __device__ __forceinline__ void conv_epilogue(const IgemmArgs& a, f32x4 (&acc)[M
       if (e.add1) add_rows(e.add1, e.ldc_add1);
     }
     __builtin_amdgcn_sched_barrier(0);
-    store_rows(e.out, e.ldc_out, e.mode == PS_EPI_BNRELU);
+    store_rows(e.out, e.ldc_out, e.mode == PS_EPI_BNRELU, e.out_hi, e.ldc_hi);
   }
 }
 
@@ -2579,6 +2590,10 @@ int check_epilogue(const ps_epilogue* e, int dtype, const char* who, int cd) {
     if (!x.p) continue;
     PS_REQUIRE(ps_aligned16(x.p) && (x.ldc * es) % 16 == 0 && x.ldc > 0, "%s: epilogue tensor %s misaligned (ptr %p ldc %d)", who, x.nm, x.p, x.ldc);
     PS_REQUIRE(x.ldc >= ps_planes(dtype) * cd, "%s: epilogue tensor %s has channel stride %d < %d produced channels x %d planes", who, x.nm, x.ldc, cd, ps_planes(dtype));
+  }
+  if (e->out_hi) {  // the plain 16-bit copy of `out`'s hi halves (split types)
+    PS_REQUIRE(ps_planes(dtype) == 2 && e->out, "%s: out_hi goes with the split types' `out`", who);
+    PS_REQUIRE(ps_aligned16(e->out_hi) && e->ldc_hi >= cd && (e->ldc_hi * 2) % 16 == 0, "%s: out_hi misaligned or narrower than %d channels (ldc %d)", who, cd, e->ldc_hi);
   }
   return PS_OK;
 }

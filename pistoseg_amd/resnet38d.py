@@ -130,6 +130,7 @@ class Net(nn.Module):
             if isinstance(m, nn.Conv2d) and m is not self.conv1a:
                 _channels_last_(m)
         self.fuse_bottleneck = True       # shortcut conv + last 1x1 of a bottleneck unit (and their dgrads) as one K-concatenated GEMM
+        self.hi_copies = True             # split precisions, training: activations / gradients also keep a plain 16-bit copy of their hi halves for the weight gradients (ops.attach_hi)
         self._out_grad_buf: Dict[str, Tensor] = {}  # unit name -> [N,H,W, cout + cout/4] buffer whose first cout channels hold dL/d(unit output)
         self._cache: Dict[str, Tuple] = {}
         self._weights_epoch = 0           # bumped by code that rewrites parameter memory behind torch's back
@@ -194,6 +195,8 @@ class Net(nn.Module):
             out.copy_(t)
         else:
             ops.convert_rows(t, out, c, dst_split=self.split)
+            if getattr(out, "_ps_hi", None) is not None:  # the plain copy of the hi halves (ops.attach_hi): round16(t) is the split tensor's hi
+                ops.convert_rows(t, out._ps_hi, c)
         return out
 
     def _cached(self, key: str, deps: Tuple[Tensor, ...], make, raw_pointer_updates: bool = True):
@@ -342,11 +345,17 @@ class Net(nn.Module):
         u = next(x for x in self.units if x[0] == name)
         cout = u[4]
         m = self.cm
+        want_hi = self.split and self.hi_copies
         if u[1] == "bot" and self.fuse_bottleneck:
             buf = torch.empty((n, h, w, m * (cout + cout // 4)), device=device, dtype=dtype)
             self._out_grad_buf[name] = buf
-            return buf[..., :m * cout]
-        return torch.empty((n, h, w, m * cout), device=device, dtype=dtype)
+            out = buf[..., :m * cout]
+            if want_hi:  # the plain 16-bit companions of [G | g2] and of G (ops.attach_hi)
+                ops.attach_hi(buf, torch.empty((n, h, w, cout + cout // 4), device=device, dtype=dtype))
+                ops.attach_hi(out, buf._ps_hi[..., :cout])
+            return out
+        t = torch.empty((n, h, w, m * cout), device=device, dtype=dtype)
+        return ops.attach_hi(t, torch.empty((n, h, w, cout), device=device, dtype=dtype)) if want_hi else t
 
     def bn_affine(self, bn: nn.BatchNorm2d, key: str) -> Tuple[Tensor, Tensor]:
         """Eval-mode BN as y = x*scale + shift (f32 per-channel vectors; BN is frozen on this path)."""
@@ -409,25 +418,35 @@ class Net(nn.Module):
 
         cm, kw = self.cm, dict(split=self.split, opts=self.launch)
 
-        def new(hh, ww, c):  # c LOGICAL channels (split path: three bf16 planes each)
-            return torch.empty((n, hh, ww, cm * c), device=dev, dtype=dt)
+        # training on the split types: an activation that a TRAINABLE conv reads also keeps a plain 16-bit copy of its hi halves, written by the
+        # same epilogue, for that conv's weight gradient (ops.attach_hi).  Only those: the extra store is not free (the frozen front units hold the
+        # largest tensors), and raw / shortcut tensors are never weight-gradient operands
+        first_tr = self.first_trainable_unit() if (self.split and self.hi_copies and saved is not None) else len(self.units)
+
+        def new(hh, ww, c, hi=False):  # c LOGICAL channels (split path: 2 stored channels each)
+            t = torch.empty((n, hh, ww, cm * c), device=dev, dtype=dt)
+            return ops.attach_hi(t, torch.empty((n, hh, ww, c), device=dev, dtype=dt)) if hi else t
+
+        def cslice(t, lo, hi_):  # logical channels [lo, hi_) of a (split) tensor, with its companion's slice
+            v = t[..., cm * lo:cm * hi_]
+            return ops.attach_hi(v, t._ps_hi[..., lo:hi_]) if getattr(t, "_ps_hi", None) is not None else v
 
         def new_unit_input(hh, ww, idx):
             """Activated input of unit idx; for a fused bottleneck unit it is the first cin channels of [a | a3]."""
             u = self.units[idx]
             if u[1] == "bot" and self.fuse_bottleneck:
-                wide = new(hh, ww, u[2] + u[4] // 2)
-                return wide[..., :cm * u[2]], wide
-            return new(hh, ww, u[2]), None
+                wide = new(hh, ww, u[2] + u[4] // 2, hi=idx >= first_tr)
+                return cslice(wide, 0, u[2]), wide
+            return new(hh, ww, u[2], hi=idx >= first_tr), None
 
         first = getattr(self, self.units[0][0])
         sc0, sh0 = self.bn_affine(first.bn_branch2a, self.units[0][0] + ".bn_branch2a")
-        a = new(h, w, 64)
+        a = new(h, w, 64, hi=0 >= first_tr)
         a_wide = None
         if self.split:  # conv1a (3 -> 64) on the exact-f32 kernel, then cut into planes
             a32 = torch.empty((n, h, w, 64), device=dev, dtype=torch.float32)
             ops.conv1a_fwd(x, self.conv1a.weight.detach().contiguous(), sc0, sh0, a32)
-            ops.convert_rows(a32, a, 64, dst_split=True)
+            self.act_from_f32(a32, a)  # (fills the plain copy of the hi halves as well, where `a` carries one)
             del a32
         else:
             ops.conv1a_fwd(x, self.conv1a.weight.detach().contiguous(), sc0, sh0, a)
@@ -466,7 +485,7 @@ class Net(nn.Module):
             xraw_next = new(ho, wo, cout) if need_raw else None
             if kind == "res":
                 s1, b1 = self.bn_affine(unit.bn_branch2b1, name + ".bn_branch2b1")
-                a2 = new(ho, wo, cmid)
+                a2 = new(ho, wo, cmid, hi=i >= first_tr)
                 ops.conv2d_fwd(specs["conv_branch2a"], a, self.w_fwd(unit.conv_branch2a, name + ".conv_branch2a"), bn_scale=s1, bn_shift=b1, out_act=a2, **kw)
                 ops.conv2d_fwd(specs["conv_branch2b1"], a2, self.w_fwd(unit.conv_branch2b1, name + ".conv_branch2b1"), add0=shortcut,
                                out_raw=xraw_next, bn_scale=nscale, bn_shift=nshift, out_act=a_next, **kw)
@@ -476,9 +495,9 @@ class Net(nn.Module):
                 d1, d2 = drop.get(f"{name}.dropout_2b1"), drop.get(f"{name}.dropout_2b2")
                 s1, b1 = self.bn_affine(unit.bn_branch2b1, name + ".bn_branch2b1")
                 s2, b2 = self.bn_affine(unit.bn_branch2b2, name + ".bn_branch2b2")
-                a2 = new(ho, wo, cout // 4)
+                a2 = new(ho, wo, cout // 4, hi=i >= first_tr)
                 ops.conv2d_fwd(specs["conv_branch2a"], a, self.w_fwd(unit.conv_branch2a, name + ".conv_branch2a"), bn_scale=s1, bn_shift=b1, drop=d1, out_act=a2, **kw)
-                a3 = a_wide[..., cm * cin:] if fused else new(ho, wo, cout // 2)
+                a3 = cslice(a_wide, cin, cin + cout // 2) if fused else new(ho, wo, cout // 2, hi=i >= first_tr)
                 ops.conv2d_fwd(specs["conv_branch2b1"], a2, self.w_fwd(unit.conv_branch2b1, name + ".conv_branch2b1"), bn_scale=s2, bn_shift=b2, drop=d2, out_act=a3, **kw)
                 if fused:  # branch1(a) + branch2b2(a3) = one 1x1 conv over [a | a3]: no shortcut tensor, no residual read
                     cat_spec = ConvSpec(cin + cout // 2, cout, 1)
@@ -565,8 +584,11 @@ class Net(nn.Module):
                 x_act.record_stream(wgrad_stream)  # keep the caching allocator from recycling them under the side stream
                 dy.record_stream(wgrad_stream)
 
-            def new(hh, ww, c):
-                return torch.empty((n, hh, ww, cm * c), device=dev, dtype=dt)
+            want_hi = self.split and self.hi_copies
+
+            def new(hh, ww, c, hi=True):  # (hi: the tensor is some weight gradient's dY -- every `out` of a data gradient here is)
+                t = torch.empty((n, hh, ww, cm * c), device=dev, dtype=dt)
+                return ops.attach_hi(t, torch.empty((n, hh, ww, c), device=dev, dtype=dt)) if want_hi and hi else t
 
             if kind == "res":
                 (a2,) = saved.mid[name]
@@ -585,7 +607,7 @@ class Net(nn.Module):
                         ops.conv2d_dgrad(specs["conv_branch2a"], gh, self.w_dgrad(unit.conv_branch2a, name + ".conv_branch2a"), (h, w),
                                          mask_src=a, bn_scale=s_in, add1=G, out=Gp, **kw)
                     else:
-                        t = new(h, w, cin)
+                        t = new(h, w, cin, hi=False)
                         ops.conv2d_dgrad(specs["conv_branch1"], G, self.w_dgrad(unit.conv_branch1, name + ".conv_branch1"), (h, w), add0=tap, out_raw=t, **kw)
                         ops.conv2d_dgrad(specs["conv_branch2a"], gh, self.w_dgrad(unit.conv_branch2a, name + ".conv_branch2a"), (h, w),
                                          add0=t, mask_src=a, bn_scale=s_in, out=Gp, **kw)
@@ -604,7 +626,12 @@ class Net(nn.Module):
                 ops.conv2d_dgrad(specs["conv_branch2b2"], G, self.w_dgrad(unit.conv_branch2b2, name + ".conv_branch2b2"), (ho, wo),
                                  mask_src=a3, bn_scale=s2, drop=d2, out=g3, **kw)
                 wgrad("conv_branch2b1", a2, g3)
-                g2 = GG[..., cm * cout:] if fused else new(ho, wo, cout // 4)
+                if fused:
+                    g2 = GG[..., cm * cout:]
+                    if getattr(GG, "_ps_hi", None) is not None:
+                        ops.attach_hi(g2, GG._ps_hi[..., cout:])
+                else:
+                    g2 = new(ho, wo, cout // 4)
                 ops.conv2d_dgrad(specs["conv_branch2b1"], g3, self.w_dgrad(unit.conv_branch2b1, name + ".conv_branch2b1"), (ho, wo),
                                  mask_src=a2, bn_scale=s1, drop=d1, out=g2, **kw)
                 wgrad("conv_branch2a", a, g2)
@@ -616,7 +643,7 @@ class Net(nn.Module):
                         ops.conv2d_dgrad(ConvSpec(cin, cout + cout // 4, 1), GG, self.w_dgrad_cat(unit, name), (h, w),
                                          add0=tap, mask_src=a, bn_scale=s_in, out=Gp, **kw)
                     else:
-                        t = new(h, w, cin)
+                        t = new(h, w, cin, hi=False)
                         ops.conv2d_dgrad(specs["conv_branch1"], G, self.w_dgrad(unit.conv_branch1, name + ".conv_branch1"), (h, w), add0=tap, out_raw=t, **kw)
                         ops.conv2d_dgrad(specs["conv_branch2a"], g2, self.w_dgrad(unit.conv_branch2a, name + ".conv_branch2a"), (h, w),
                                          add0=t, mask_src=a, bn_scale=s_in, out=Gp, **kw)

@@ -205,3 +205,50 @@ def test_split_convs_through_the_tile_queue_are_bit_identical(dt, GEOM):
         ops.TILE_QUEUE = 0
     assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
     assert rel_err(got[2].cpu(), ref[2].cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("dt", [BF, HF])
+@pytest.mark.parametrize("case", [
+    (24, 28, 28, 256, 512, 3, 1, 2),   # halo kernel
+    (3, 13, 10, 128, 128, 3, 1, 1),    # 4-wave kernel, ragged
+    (37, 28, 28, 256, 512, 1, 1, 1),   # ws2 GEMM
+    (42, 56, 56, 128, 256, 3, 2, 1),   # stride 2: the data gradient runs as four parity-class launches (the epilogue's row map)
+    (3, 28, 28, 512, 1024, 1, 1, 1),   # three images per tile: dropout multipliers per row (the epilogue's row-by-row path)
+])
+def test_split_epilogue_hi_copy_and_weight_gradient_on_it(case, dt):
+    """ps_epilogue.out_hi / ops.attach_hi: the epilogue that writes a split tensor as its `out` also writes the hi halves as a plain 16-bit
+    tensor -- bit for bit the hi halves of what it stored, for the forward's activated output (BN + ReLU + dropout, as a channel slice) and for
+    the data gradient's ReLU-masked output -- and a split weight gradient whose operands both carry such a copy runs on the copies: equal to
+    the gathered-hi-halves launch up to f32 summation order."""
+    from pistoseg_amd import ops
+
+    n, h, w, cin, cout, k, s_, d = case
+    spec = ops.ConvSpec(cin, cout, k, s_, d)
+    ho, wo = spec.out_hw(h, w)
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    PL = lambda t: planes(t, False, dt)
+    hi_of = lambda p: p.reshape(*p.shape[:-1], p.shape[-1] // 64, 2, 32)[..., 0, :].reshape(*p.shape[:-1], p.shape[-1] // 2)
+    x = PL(torch.randn(n, h, w, cin, generator=g)).to(D)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    wf, wd = PL(wt.permute(0, 2, 3, 1).contiguous()).to(D), PL(wt.flip(2, 3).permute(1, 2, 3, 0).contiguous()).to(D)
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).to(D), (torch.randn(cout, generator=g) * 0.1).to(D)
+    drop = ((torch.rand(n, cout, generator=g) > 0.3).float() / 0.7).to(D)
+    wide = torch.zeros((n, ho, wo, 2 * cout + 128), device=D, dtype=dt)
+    wide_hi = torch.full((n, ho, wo, cout + 64), 7.0, device=D, dtype=dt)
+    act = ops.attach_hi(wide[..., 128:], wide_hi[..., 64:])
+    ops.conv2d_fwd(spec, x, wf, bn_scale=scale, bn_shift=shift, drop=drop, out_act=act, split=True)
+    assert torch.equal(wide_hi[..., 64:], hi_of(act)) and bool((wide_hi[..., :64] == 7.0).all())
+    gy = PL(torch.randn(n, ho, wo, cout, generator=g)).to(D)
+    mask = PL(torch.relu(torch.randn(n, h, w, cin, generator=g))).to(D)
+    sc2, drop2 = (torch.rand(cin, generator=g) + 0.5).to(D), ((torch.rand(n, cin, generator=g) > 0.3).float() / 0.7).to(D)
+    gx = ops.attach_hi(torch.zeros((n, h, w, 2 * cin), device=D, dtype=dt), torch.full((n, h, w, cin), 7.0, device=D, dtype=dt))
+    ops.conv2d_dgrad(spec, gy, wd, (h, w), mask_src=mask, bn_scale=sc2, drop=drop2 if s_ == 1 else None, out=gx, split=True)
+    assert torch.equal(gx._ps_hi, hi_of(gx))
+    # weight gradient: operands with companions -> the plain 16-bit kernel on them
+    dw_ref = torch.zeros((cout, k, k, cin), device=D)
+    ops.conv2d_wgrad(spec, x, gy, dw_ref, split=True)
+    ops.attach_hi(x, hi_of(x).contiguous())
+    ops.attach_hi(gy, hi_of(gy).contiguous())
+    dw = torch.zeros((cout, k, k, cin), device=D)
+    ops.conv2d_wgrad(spec, x, gy, dw, split=True)
+    assert rel_err(dw.cpu(), dw_ref.cpu()) < 1e-5
