@@ -156,22 +156,31 @@ def pmc_traffic(kernel_label):
     belongs to."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), key=os.path.getmtime)
+    # (by NAME, never by mtime: a fresh checkout / a pushed snapshot gives the files arbitrary times -- the fp16 bs = 128 summary of the same round
+    # was once quoted for the bf16 headline on a GPU box; and by the EXACT kernel family, storage type included)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
     if not files:
         return None
-    try:
-        data = json.load(open(files[-1]))
-    except Exception:
-        return None
-    build = data.get("_build") or {}
-    if build.get("csrc_sha16") != csrc_sha16():
-        return {"bytes_per_launch": None, "source": os.path.basename(files[-1]), "stale": True,
-                "note": f"newest PMC summary is of another build of the kernels (git {build.get('git_head', 'unrecorded')}); re-run tools/profile_round.sh"}
-    for k, v in data.items():  # keys are kernel families "name<dtype>" (tools/pmc_traffic.py)
-        if k.startswith("_"):
+    stale, matched = None, False
+    for f in reversed(files):  # newest round tag first
+        try:
+            data = json.load(open(f))
+        except Exception:
             continue
-        if k == kernel_label or kernel_label.split("<")[0] in k:
-            return {"bytes_per_launch": round(v["hbm_bytes_per_launch_corrected"]), "source": os.path.basename(files[-1]), "git_head": build.get("git_head")}
+        build = data.get("_build") or {}
+        if build.get("csrc_sha16") != csrc_sha16():
+            stale = stale or (os.path.basename(f), build.get("git_head", "unrecorded"))
+            continue
+        matched = True
+        # keys are kernel families "name<dtype>" (tools/pmc_traffic.py); families without a storage type in their name (the weight gradient) by their stem
+        v = data.get(kernel_label) or data.get(kernel_label.split("<")[0])
+        if isinstance(v, dict) and "hbm_bytes_per_launch_corrected" in v:
+            return {"bytes_per_launch": round(v["hbm_bytes_per_launch_corrected"]), "source": os.path.basename(f), "git_head": build.get("git_head")}
+    if matched:
+        return {"bytes_per_launch": None, "note": f"the PMC summaries of this build of the kernels do not hold {kernel_label} (tools/profile_round.sh collects the bf16 bs = 64 and fp16 bs = 128 steps)"}
+    if stale is not None:
+        return {"bytes_per_launch": None, "source": stale[0], "stale": True,
+                "note": f"newest PMC summary is of another build of the kernels (git {stale[1]}); re-run tools/profile_round.sh"}
     return None
 
 

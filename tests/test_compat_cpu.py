@@ -251,3 +251,35 @@ def test_gpu_suite_order_puts_parity_before_selfchecks_before_control_flow():
     k_side = next(k for k, i in enumerate(ids) if "side_stream_weight_gradients" in i)
     k_last_parity = max(k for k, i in enumerate(ids) if "test_contract_gpu.py" in i)
     assert k_last_parity < k_side < first_control
+
+
+def test_bench_traffic_lookup_is_by_name_and_exact_kernel_family(tmp_path, monkeypatch):
+    """bench.py quotes `roofline.traffic` from the committed PMC summaries: the one stamped with THIS build of the kernels that holds the
+    EXACT kernel family (storage type included), chosen by file name -- a fresh checkout gives the files arbitrary mtimes (the fp16 bs = 128
+    summary was once quoted for the bf16 headline on a GPU box)."""
+    import json
+    import os
+    import sys
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    mk = lambda sha, fams: dict({k: {"hbm_bytes_per_launch_corrected": v} for k, v in fams.items()}, _build={"csrc_sha16": sha, "git_head": "abc"})
+    (prof / "r09a_pmc_hbm_traffic.json").write_text(json.dumps(mk("OLD", {"conv_igemm_halo_kernel<bf16>": 1.0})))
+    (prof / "r09b_pmc_hbm_traffic.json").write_text(json.dumps(mk("NOW", {"conv_igemm_halo_kernel<bf16>": 474e6, "conv_wgrad_ws2_kernel": 600e6})))
+    time.sleep(0.05)  # ... and the fp16 summary is the NEWER file
+    (prof / "r09b_cfg5_fp16_bs128_pmc_hbm_traffic.json").write_text(json.dumps(mk("NOW", {"conv_igemm_halo_kernel<f16>": 931e6})))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "csrc_sha16", lambda: "NOW")
+    t = bench.pmc_traffic("conv_igemm_halo_kernel<bf16>")
+    assert t["bytes_per_launch"] == 474000000 and t["source"] == "r09b_pmc_hbm_traffic.json"
+    assert bench.pmc_traffic("conv_igemm_halo_kernel<f16>")["source"] == "r09b_cfg5_fp16_bs128_pmc_hbm_traffic.json"
+    assert bench.pmc_traffic("conv_wgrad_ws2_kernel<bf16>")["bytes_per_launch"] == 600000000  # families named without a storage type: by their stem
+    assert bench.pmc_traffic("conv_igemm_halo_kernel<fp16x3>")["bytes_per_launch"] is None
+    monkeypatch.setattr(bench, "csrc_sha16", lambda: "OTHER")
+    t = bench.pmc_traffic("conv_igemm_halo_kernel<bf16>")
+    assert t["bytes_per_launch"] is None and t["stale"] is True
