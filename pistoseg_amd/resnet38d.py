@@ -338,6 +338,11 @@ class Net(nn.Module):
 
         return self._cached("wdc:" + name, (w1, w2), make)
 
+    def _want_hi(self) -> bool:
+        """Split precisions: whether training tensors get plain 16-bit companions for the weight gradients (ops.attach_hi) -- not when all three
+        product terms are asked for (`launch.wgrad_terms = 3`: those launches read the split tensors themselves)."""
+        return bool(self.split and self.hi_copies and self.launch.wgrad_terms in (None, 0, 1))
+
     def alloc_unit_out_grad(self, name: str, n: int, h: int, w: int, device, dtype) -> Tensor:
         """Buffer for dL/d(output of unit `name`) [N,h,w,cout].  For a bottleneck unit it is the first cout channels of a wider
         buffer that the reverse plan completes with the branch gradient g2, so the two data gradients into the unit's input run
@@ -345,7 +350,7 @@ class Net(nn.Module):
         u = next(x for x in self.units if x[0] == name)
         cout = u[4]
         m = self.cm
-        want_hi = self.split and self.hi_copies
+        want_hi = self._want_hi()
         if u[1] == "bot" and self.fuse_bottleneck:
             buf = torch.empty((n, h, w, m * (cout + cout // 4)), device=device, dtype=dtype)
             self._out_grad_buf[name] = buf
@@ -421,7 +426,7 @@ class Net(nn.Module):
         # training on the split types: an activation that a TRAINABLE conv reads also keeps a plain 16-bit copy of its hi halves, written by the
         # same epilogue, for that conv's weight gradient (ops.attach_hi).  Only those: the extra store is not free (the frozen front units hold the
         # largest tensors), and raw / shortcut tensors are never weight-gradient operands
-        first_tr = self.first_trainable_unit() if (self.split and self.hi_copies and saved is not None) else len(self.units)
+        first_tr = self.first_trainable_unit() if (self._want_hi() and saved is not None) else len(self.units)
 
         def new(hh, ww, c, hi=False):  # c LOGICAL channels (split path: 2 stored channels each)
             t = torch.empty((n, hh, ww, cm * c), device=dev, dtype=dt)
@@ -584,7 +589,7 @@ class Net(nn.Module):
                 x_act.record_stream(wgrad_stream)  # keep the caching allocator from recycling them under the side stream
                 dy.record_stream(wgrad_stream)
 
-            want_hi = self.split and self.hi_copies
+            want_hi = self._want_hi()
 
             def new(hh, ww, c, hi=True):  # (hi: the tensor is some weight gradient's dY -- every `out` of a data gradient here is)
                 t = torch.empty((n, hh, ww, cm * c), device=dev, dtype=dt)
