@@ -30,6 +30,24 @@ def build(classes, precision, sd):
     return m.to(D)
 
 
+_N24_ORACLE = {}
+
+
+def oracle_step_cached(key, sd, x, drop, target, ignore):
+    """CPU oracle forward + CE + backward of a training step (tens of seconds at n = 24, 224 x 224): computed once per (classes, seed) and shared by the
+    precisions that are checked on the same inputs.  Returns (logits, loss, {key: gradient})."""
+    if key not in _N24_ORACLE:
+        sd_ref = {k: v.clone() for k, v in sd.items()}
+        tk = ref_cpu.trainable_keys(sd_ref)
+        for k in tk:
+            sd_ref[k].requires_grad_(True)
+        ref_logits = ref_cpu.seg_forward(sd_ref, x, drop)
+        ref_loss = ref_cpu.seg_ce_loss(ref_logits, target, ignore)
+        ref_loss.backward()
+        _N24_ORACLE[key] = (ref_logits.detach(), ref_loss.detach(), {k: sd_ref[k].grad for k in tk})
+    return _N24_ORACLE[key]
+
+
 def masks_agree_up_to_ties(logits_ref, mask_ref, mask_got, err):
     """Bit-exact except at pixels whose top-2 oracle logits are closer than the logit error."""
     top2 = torch.topk(logits_ref, 2, dim=1)[0]
@@ -61,7 +79,9 @@ def test_seg_forward_fp32_matches_golden_and_oracle(golden_dir, tag, n, s, c, se
     assert abs(float(got.double().abs().sum()) - float(g["cam.abssum"])) < 1e-4 * float(g["cam.abssum"])
     # full-tensor check against the oracle on the same inputs
     with torch.no_grad():
-        ref = ref_cpu.seg_forward(sd, x)
+        if ("seg_fwd", tag) not in _N24_ORACLE:  # the CPU oracle's forward: once per case, shared by the three precisions
+            _N24_ORACLE[("seg_fwd", tag)] = ref_cpu.seg_forward(sd, x)
+        ref = _N24_ORACLE[("seg_fwd", tag)]
     err = float((got - ref).abs().max())
     assert err / float(ref.abs().max()) < F32_TOL
     print(f"[parity] {precision} seg forward {tag}: logits max rel err vs CPU oracle {err / float(ref.abs().max()):.3e}")
@@ -252,14 +272,17 @@ def test_seg_training_gradients_match_oracle(precision):
     loss, dlogits = ops.softmax_ce(logits.detach(), target.to(D), 3, want_grad=True, grad_scale=scale)
     logits.backward(dlogits)
 
-    sd_ref = {k: v.clone() for k, v in sd.items()}
-    tk = ref_cpu.trainable_keys(sd_ref)
-    for k in tk:
-        sd_ref[k].requires_grad_(True)
-    collect = {}
-    ref_logits = ref_cpu.seg_forward(sd_ref, x, drop, collect)
-    ref_loss = ref_cpu.seg_ce_loss(ref_logits, target, 3)
-    ref_loss.backward()
+    if "n2_step" not in _N24_ORACLE:  # the oracle's step (with its activations): once, shared by the four precisions (same inputs)
+        sd_ref = {k: v.clone() for k, v in sd.items()}
+        tk = ref_cpu.trainable_keys(sd_ref)
+        for k in tk:
+            sd_ref[k].requires_grad_(True)
+        collect = {}
+        ref_logits = ref_cpu.seg_forward(sd_ref, x, drop, collect)
+        ref_loss = ref_cpu.seg_ce_loss(ref_logits, target, 3)
+        ref_loss.backward()
+        _N24_ORACLE["n2_step"] = (sd_ref, tk, collect, ref_loss.detach())
+    sd_ref, tk, collect, ref_loss = _N24_ORACLE["n2_step"]
     named = dict(model.named_parameters())
     assert sorted(k for k, p in named.items() if p.requires_grad) == sorted(tk)
     # frozen layers got nothing
@@ -316,19 +339,14 @@ def test_seg_training_gradients_bf16_at_persistent_kernel_batch_match_oracle():
     logits.backward(dlogits)
     torch.cuda.synchronize()
 
-    sd_ref = {k: v.clone() for k, v in sd.items()}
-    tk = ref_cpu.trainable_keys(sd_ref)
-    for k in tk:
-        sd_ref[k].requires_grad_(True)
-    ref_logits = ref_cpu.seg_forward(sd_ref, x, drop)
-    ref_loss = ref_cpu.seg_ce_loss(ref_logits, target, 3)
-    ref_loss.backward()
+    ref_logits, ref_loss, ref_grads = oracle_step_cached((c, 78), sd, x, drop, target, 3)  # (shared with the fp16x3 test below: same inputs)
+    tk = list(ref_grads)
     named = dict(model.named_parameters())
     assert abs(float(loss) - float(ref_loss)) < 3e-2 * abs(float(ref_loss))
     e_log = rel_err(logits.detach().cpu(), ref_logits.detach())
     worst = ("", 0.0)
     for k in tk:
-        a, b = named[k].grad.cpu().double(), sd_ref[k].grad.double()
+        a, b = named[k].grad.cpu().double(), ref_grads[k].double()
         e = float((a - b).norm() / b.norm())
         worst = max(worst, (k, e), key=lambda t: t[1])
         assert e < 1.5e-1, (k, e)
@@ -664,7 +682,7 @@ def test_seg_training_gradients_fp16x3_at_persistent_kernel_batch_match_oracle()
     sd = ref_cpu.make_state_dict(c, False, seed=42)
     model = build(c, "fp16x3", sd)
     model.train()
-    g = torch.Generator().manual_seed(80)
+    g = torch.Generator().manual_seed(78)  # (the bf16 test's inputs: the CPU oracle's step is computed once for both)
     x = torch.randn(n, 3, s, s, generator=g)
     target = torch.randint(0, 4, (n, s, s), generator=g)  # 3 = ignore_index
     drop = {}
@@ -677,13 +695,8 @@ def test_seg_training_gradients_fp16x3_at_persistent_kernel_batch_match_oracle()
     logits.backward(dlogits)
     torch.cuda.synchronize()
 
-    sd_ref = {k: v.clone() for k, v in sd.items()}
-    tk = ref_cpu.trainable_keys(sd_ref)
-    for k in tk:
-        sd_ref[k].requires_grad_(True)
-    ref_logits = ref_cpu.seg_forward(sd_ref, x, drop)
-    ref_loss = ref_cpu.seg_ce_loss(ref_logits, target, 3)
-    ref_loss.backward()
+    ref_logits, ref_loss, ref_grads = oracle_step_cached((c, 78), sd, x, drop, target, 3)
+    tk = list(ref_grads)
     named = dict(model.named_parameters())
     assert abs(float(loss) - float(ref_loss)) < 1e-4 * abs(float(ref_loss))
     e_log = rel_err(logits.detach().cpu(), ref_logits.detach())
@@ -692,7 +705,7 @@ def test_seg_training_gradients_fp16x3_at_persistent_kernel_batch_match_oracle()
     for k in tk:
         ga = named[k].grad
         assert bool(torch.isfinite(ga).all()), k
-        a, b = ga.cpu().double() / scale, sd_ref[k].grad.double()
+        a, b = ga.cpu().double() / scale, ref_grads[k].double()
         e = float((a - b).norm() / b.norm())
         worst = max(worst, (k, e), key=lambda t: t[1])
         assert e < 2e-2, (k, e)
@@ -759,18 +772,21 @@ def test_seg_trainer_multi_step_trajectory_matches_oracle_adamw(precision):
         tr.settle()
     assert tr.skipped_steps == 0
 
-    sd_ref = {k: v.clone() for k, v in sd.items()}
-    tk = ref_cpu.trainable_keys(sd_ref)
-    for k in tk:
-        sd_ref[k].requires_grad_(True)
-    opt = torch.optim.AdamW([sd_ref[k] for k in tk], lr=LR, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8)
-    ref_losses = []
-    for _ in range(steps):
-        opt.zero_grad()
-        loss = ref_cpu.seg_ce_loss(ref_cpu.seg_forward(sd_ref, x, drop), target, 3)
-        loss.backward()
-        opt.step()
-        ref_losses.append(float(loss.detach()))
+    if "trajectory" not in _N24_ORACLE:  # the oracle's four steps: once, shared by the two precisions (same inputs)
+        sd_ref = {k: v.clone() for k, v in sd.items()}
+        tk = ref_cpu.trainable_keys(sd_ref)
+        for k in tk:
+            sd_ref[k].requires_grad_(True)
+        opt = torch.optim.AdamW([sd_ref[k] for k in tk], lr=LR, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8)
+        ref_losses = []
+        for _ in range(steps):
+            opt.zero_grad()
+            loss = ref_cpu.seg_ce_loss(ref_cpu.seg_forward(sd_ref, x, drop), target, 3)
+            loss.backward()
+            opt.step()
+            ref_losses.append(float(loss.detach()))
+        _N24_ORACLE["trajectory"] = (sd_ref, tk, ref_losses)
+    sd_ref, tk, ref_losses = _N24_ORACLE["trajectory"]
     tol = 1e-5 if precision == "fp32" else 1e-4  # first step; every further step may multiply an earlier difference (ReLU boundaries, Adam's normalisation)
     for k, (a, b) in enumerate(zip(losses, ref_losses)):
         assert abs(a - b) < tol * 4 ** k * abs(b), (k, losses, ref_losses)

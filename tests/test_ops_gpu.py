@@ -619,6 +619,8 @@ def test_wgrad_large_tile_persistent_kernel(case, dtype, library):
     spec = ops.ConvSpec(cin, cout, k, s, d)
     if library == "product" and conv_variant(spec, dtype, n, h, w, "wgrad") not in (1, 2):
         pytest.skip("the product library serves this small problem with the 128x128 kernel (covered by test_conv_fwd_dgrad_wgrad)")
+    if library == "debug" and cin * cout * k * k >= 8 * 1024 * 1024 and conv_variant(spec, dtype, n, h, w, "wgrad") in (1, 2):
+        pytest.skip("a large case that the product library already runs on this kernel by geometry (the CPU reference is the slow part)")
     g = torch.Generator().manual_seed(cin + cout + k)
     q = quant(dtype)
     x = q(torch.randn(n, cin, h, w, generator=g))

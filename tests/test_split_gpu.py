@@ -89,7 +89,7 @@ SPLIT_CASES = [
     ((17, 32, 32, 64, 512, 3, 1, 4), "halo"),   # 256-pixel tiles (maps of 256 x 256 inputs)
     ((37, 28, 28, 256, 512, 1, 1, 1), "ws2"),
     ((42, 56, 56, 128, 256, 3, 2, 1), "ws2"),   # stride-2 3x3: the data gradient runs as four parity-class launches
-    ((33, 28, 28, 1024, 1024, 1, 1, 1), "ws2"),  # a GEMM the plain types send to conv_gemm256_kernel: split types keep the wave-specialised one
+    ((17, 28, 28, 1024, 1024, 1, 1, 1), "ws2"),  # a GEMM the plain types send to conv_gemm256_kernel: split types keep the wave-specialised one
 ]
 
 
