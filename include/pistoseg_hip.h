@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PS_VERSION 225 /* major*10000 + minor*100 + patch */
+#define PS_VERSION 226 /* major*10000 + minor*100 + patch */
 
 typedef enum ps_status {
   PS_OK = 0,
@@ -289,6 +289,12 @@ int ps_argmax_mask(const float* x, const float* label, const uint8_t* tissue, ui
  * truth >= num_class dropped).  cm: int64 [num_class*num_class], accumulated with atomics. */
 int ps_confusion_accum(const uint8_t* pred, const int64_t* gt, int64_t* cm, int64_t npix, int32_t num_class, void* stream);
 
+/* loss.py:28-53 evaluated on the device, so that `mIoUMask.forward` (called once per training step, models/segmentation_module.py:108-109)
+ * needs no device->host copy: out f64[2 + num_class] = { Mean_Intersection_over_Union, Frequency_Weighted_Intersection_over_Union,
+ * Tissue_Intersection_over_Union[0..num_class) } of the int64 [num_class*num_class] matrix, numpy's f64 evaluation order (bit-identical to the
+ * host computation on the copied matrix). */
+int ps_iou_from_confusion(const int64_t* cm, int32_t num_class, double* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * RFM head (stage 3/4, models/revise_net.py) and the feature-consistency losses
  * (revise_pseudo_labels.py:115-138,253-282).  f32 arithmetic.
@@ -392,6 +398,14 @@ int ps_sgd_step(float* p, const float* g, float* buf, void* p_bf16, int64_t n, f
 /* Same, with the gradient multiplied by grad_inv_scale first and a 16-bit shadow of dtype shadow_dtype in {PS_BF16, PS_F16}. */
 int ps_sgd_step_scaled(float* p, const float* g, float* buf, void* p_shadow, int32_t shadow_dtype, int64_t n, float lr,
                        float momentum, float weight_decay, int32_t first_step, float grad_inv_scale, void* stream);
+/* The same update with the overflow check of dynamic loss scaling on the device, as ps_adamw_step_guarded: state[0] = steps applied so far,
+ * state[1] = non-finite elements of this step's gradient.  When state[1] != 0 nothing is written; otherwise `first_step` is state[0] == 0 and, with
+ * poly_max_step > 0, lr is multiplied by utils.PolyOptimizer's schedule (1 - t / poly_max_step) ** poly_power at t = state[0] (utils.py:176-182; held
+ * at t = poly_max_step - 1 beyond it).  A step over several parameter groups is several calls on one stream, `advance` != 0 on the last only
+ * (state[0] += 1 when the step was applied). */
+int ps_sgd_step_guarded(float* p, const float* g, float* buf, void* p_shadow, int32_t shadow_dtype, int64_t n, float lr, float momentum,
+                        float weight_decay, int32_t* state, int32_t advance, int32_t poly_max_step, float poly_power, float grad_inv_scale,
+                        void* stream);
 
 /* ---- sliding-window evaluation ------------------------------------------------------------------ */
 /* Where one tile of a batch lands: its valid (un-padded) region [0, vh) x [0, vw) is added at (y0, x0) of a per-image f64 canvas.

@@ -17,7 +17,7 @@ import torch  # noqa: F401  (side effect: loads the HIP runtime torch uses)
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PISTOSEG_HIP_LIB") or os.path.join(HERE, "libpistoseg_hip.so")  # override: A/B-testing another build
 
-PS_F32, PS_BF16, PS_F16, PS_BF16X3, PS_F16X3 = 0, 1, 2, 3, 4  # PS_*X3: split 16-bit conv formats (planes [hi | lo | hi]; include/pistoseg_hip.h)
+PS_F32, PS_BF16, PS_F16, PS_BF16X3, PS_F16X3 = 0, 1, 2, 3, 4  # PS_*X3: split 16-bit conv formats (blocks of 32 logical channels as [hi(32) | lo(32)]; include/pistoseg_hip.h)
 PS_EPI_NONE, PS_EPI_BNRELU, PS_EPI_RELUBWD = 0, 1, 2
 PS_MASK_PLAIN, PS_MASK_MUL, PS_MASK_FILL = 0, 1, 2
 
@@ -110,11 +110,13 @@ PROTOTYPES = {
     "ps_dice_loss": (C.c_int, [_P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P, _P]),
     "ps_argmax_mask": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "ps_confusion_accum": (C.c_int, [_P, _P, _P, _L, _I, _P]),
+    "ps_iou_from_confusion": (C.c_int, [_P, _I, _P, _P]),
     "ps_adamw_step": (C.c_int, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
     "ps_sgd_step": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _I, _P]),
     "ps_adamw_step_scaled": (C.c_int, [_P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
     "ps_adamw_step_guarded": (C.c_int, [_P, _P, _P, _P, _P, _I, _L, _F, _F, _F, _F, _F, _P, _F, _P]),
     "ps_sgd_step_scaled": (C.c_int, [_P, _P, _P, _P, _I, _L, _F, _F, _F, _I, _F, _P]),
+    "ps_sgd_step_guarded": (C.c_int, [_P, _P, _P, _P, _I, _L, _F, _F, _F, _P, _I, _I, _F, _F, _P]),
     "ps_softmax_scatter_accum": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _P]),
     "ps_canvas_resize_accum": (C.c_int, [_P, _P, _D, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ps_canvas_argmax": (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _I, _P, _P]),

@@ -458,6 +458,53 @@ __global__ __launch_bounds__(256) void confusion_kernel(const uint8_t* __restric
   if (threadIdx.x < nc * nc && hist[threadIdx.x]) atomicAdd(&cm[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
 }
 
+// loss.py:28-53 on the device: per-tissue IoU, their mean, the frequency-weighted IoU -- f64, the sums taken in numpy's order (row / column
+// sums of exact integers; the mean and the weighted sum left to right, as numpy's pairwise sum does for fewer than 8 terms... and, for up to
+// 16 classes, in its 8-accumulator block order -- see iou_sum), so that the values equal the host computation bit for bit.
+__device__ inline double iou_sum(const double* v, int n) {
+  if (n < 8) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += v[i];
+    return n ? s : 0.0;
+  }
+  double r[8];  // numpy pairwise_sum, 8 <= n <= 128: eight strided partial sums, combined as ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)), then the remainder
+  for (int j = 0; j < 8; ++j) r[j] = v[j];
+  int i = 8;
+  for (; i + 8 <= n; i += 8)
+    for (int j = 0; j < 8; ++j) r[j] += v[i + j];
+  double s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; ++i) s += v[i];
+  return s;
+}
+
+__global__ void iou_from_confusion_kernel(const long long* __restrict__ cm, int nc, double* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double rows[16], cols[16], iou[16], w[16];
+  double total_rows[16];
+  for (int i = 0; i < nc; ++i) {
+    double r[16], c[16];
+    for (int j = 0; j < nc; ++j) {
+      r[j] = (double)cm[i * nc + j];
+      c[j] = (double)cm[j * nc + i];
+    }
+    rows[i] = iou_sum(r, nc);
+    cols[i] = iou_sum(c, nc);
+    total_rows[i] = rows[i];
+  }
+  const double total = iou_sum(total_rows, nc);  // (integers below 2^53: any order gives the same value)
+  int nw = 0;
+  for (int i = 0; i < nc; ++i) {
+    const double d = (double)cm[i * nc + i];
+    double v = d / (rows[i] + cols[i] - d);  // 0/0 -> NaN
+    const double freq = rows[i] / total;     // NaN for an empty matrix: `freq > 0` is then false everywhere and the sum is empty (0.0)
+    if (freq > 0) w[nw++] = freq * v;
+    iou[i] = (v != v) ? 0.0 : v;             // Tissue_Intersection_over_Union: iou[np.isnan(iou)] = 0
+    out[2 + i] = iou[i];
+  }
+  out[0] = iou_sum(iou, nc) / (double)nc;  // np.mean = pairwise sum / n
+  out[1] = iou_sum(w, nw);
+}
+
 static inline int grid_for(long long items, int per_block, int cap = 2048) {
   long long b = (items + per_block - 1) / per_block;
   if (b < 1) b = 1;
@@ -614,6 +661,14 @@ extern "C" int ps_argmax_mask(const float* x, const float* label, const uint8_t*
     default: launch(argmax_mask_kernel<0>); break;
   }
   PS_CHECK_LAUNCH("argmax_mask");
+  return PS_OK;
+}
+
+extern "C" int ps_iou_from_confusion(const int64_t* cm, int32_t num_class, double* out, void* stream) {
+  PS_REQUIRE(cm && out, "iou_from_confusion: null argument");
+  PS_REQUIRE(num_class >= 1 && num_class <= 16, "iou_from_confusion: num_class %d unsupported (1..16)", num_class);
+  hipLaunchKernelGGL(iou_from_confusion_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), (const long long*)cm, num_class, out);
+  PS_CHECK_LAUNCH("iou_from_confusion");
   return PS_OK;
 }
 

@@ -616,9 +616,18 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// guarded form (ps_sgd_step_guarded): state as for AdamW above; the launch does nothing when state[1] != 0, takes `first` (momentum buffer = gradient)
+// from state[0] == 0 and scales lr by utils.PolyOptimizer's (1 - t / max_step) ** power with t = state[0] (held at max_step - 1 beyond the schedule).
 template <typename SH, bool VEC>
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
-                                                  SH* __restrict__ pb, long long n, float lr, float mom, float wd, int first, float ginv) {
+                                                  SH* __restrict__ pb, long long n, float lr, float mom, float wd, int first, float ginv,
+                                                  const int* __restrict__ state, int poly_max_step, float poly_power) {
+  if (state) {
+    if (state[1] != 0) return;
+    const int t = state[0];
+    first = t == 0;
+    if (poly_max_step > 0) lr *= powf(1.f - (float)(t < poly_max_step ? t : poly_max_step - 1) / (float)poly_max_step, poly_power);
+  }
   auto upd = [&](float& pk, float gk, float& bk) {
     gk *= ginv;
     if (wd != 0.f) gk = fmaf(wd, pk, gk);
@@ -967,12 +976,34 @@ extern "C" int ps_sgd_step_scaled(float* p, const float* g, float* buf, void* p_
   const dim3 grid((unsigned)((n + (vec ? 1024 : 256) - 1) / (vec ? 1024 : 256)));
 #define PS_SGD(SH)                                                                                                                              \
   if (vec) hipLaunchKernelGGL((sgd_kernel<SH, true>), grid, dim3(256), 0, s, p, g, buf, (SH*)p_shadow, (long long)n, lr, momentum, weight_decay, \
-                              first_step, grad_inv_scale);                                                                                     \
+                              first_step, grad_inv_scale, (const int*)nullptr, 0, 0.f);                                                        \
   else hipLaunchKernelGGL((sgd_kernel<SH, false>), grid, dim3(256), 0, s, p, g, buf, (SH*)p_shadow, (long long)n, lr, momentum, weight_decay,    \
-                          first_step, grad_inv_scale);
+                          first_step, grad_inv_scale, (const int*)nullptr, 0, 0.f);
   if (p_shadow && shadow_dtype == PS_F16) { PS_SGD(_Float16) } else { PS_SGD(__bf16) }
 #undef PS_SGD
   PS_CHECK_LAUNCH("sgd_step");
+  return PS_OK;
+}
+
+extern "C" int ps_sgd_step_guarded(float* p, const float* g, float* buf, void* p_shadow, int32_t shadow_dtype, int64_t n, float lr, float momentum,
+                                   float weight_decay, int32_t* state, int32_t advance, int32_t poly_max_step, float poly_power, float grad_inv_scale,
+                                   void* stream) {
+  PS_REQUIRE(p && g && state && n >= 0 && (momentum == 0.f || buf), "sgd_step_guarded: bad argument");
+  PS_REQUIRE(!p_shadow || shadow_dtype == PS_BF16 || shadow_dtype == PS_F16, "sgd_step_guarded: shadow dtype %d unsupported", shadow_dtype);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n > 0) {
+    const bool vec = ps_aligned16(p) && ps_aligned16(g) && (!buf || ps_aligned16(buf)) && (!p_shadow || (reinterpret_cast<uintptr_t>(p_shadow) & 7u) == 0);
+    const dim3 grid((unsigned)((n + (vec ? 1024 : 256) - 1) / (vec ? 1024 : 256)));
+#define PS_SGD(SH)                                                                                                                              \
+  if (vec) hipLaunchKernelGGL((sgd_kernel<SH, true>), grid, dim3(256), 0, s, p, g, buf, (SH*)p_shadow, (long long)n, lr, momentum, weight_decay, \
+                              0, grad_inv_scale, (const int*)state, poly_max_step, poly_power);                                                \
+  else hipLaunchKernelGGL((sgd_kernel<SH, false>), grid, dim3(256), 0, s, p, g, buf, (SH*)p_shadow, (long long)n, lr, momentum, weight_decay,    \
+                          0, grad_inv_scale, (const int*)state, poly_max_step, poly_power);
+    if (p_shadow && shadow_dtype == PS_F16) { PS_SGD(_Float16) } else { PS_SGD(__bf16) }
+#undef PS_SGD
+  }
+  if (advance) hipLaunchKernelGGL(adamw_state_advance_kernel, dim3(1), dim3(1), 0, s, state);  // behind the update(s): every block read the old count
+  PS_CHECK_LAUNCH("sgd_step_guarded");
   return PS_OK;
 }
 

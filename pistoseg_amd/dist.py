@@ -23,6 +23,31 @@ import torch.distributed as dist
 Tensor = torch.Tensor
 
 
+RCCL_DEFAULT_CHANNELS = 32  # workgroups (one CU each) an RCCL ring collective occupies on an 8-GPU xGMI node when nothing overrides it
+
+
+def default_reserved_cus() -> int:
+    """CUs the conv launches leave to an in-flight collective (`share="reserve"`): RCCL runs one workgroup per channel, so this is its channel
+    count -- `NCCL_MAX_NCHANNELS` caps it and `NCCL_MIN_NCHANNELS` floors it when the job sets them (the usual way to trade collective bandwidth
+    against compute CUs), else RCCL's default.  Echoed in bench.py's `config` so that a scaling run states what it assumed."""
+    import os
+
+    def env_int(name):
+        try:
+            v = int(os.environ.get(name, ""))
+            return v if v > 0 else None
+        except ValueError:
+            return None
+
+    n = RCCL_DEFAULT_CHANNELS
+    hi, lo = env_int("NCCL_MAX_NCHANNELS"), env_int("NCCL_MIN_NCHANNELS")
+    if hi is not None:
+        n = min(n, hi)
+    if lo is not None:
+        n = max(n, lo)
+    return max(1, min(n, 128))
+
+
 def plan_buckets(entries: Sequence[Tuple[str, int]], limit_elems: int) -> List[Tuple[str, int, int]]:
     """entries: (parameter name 'unit.conv.weight', numel) in arena order.  Returns (closing unit, start, end)
     slices that tile the arena exactly; a bucket closes at a unit boundary once it holds >= limit_elems."""
@@ -73,19 +98,35 @@ class BucketedAllReduce:
         self.payload = payload
         # bf16 wire format: one staging arena the size of the gradient arena (buckets are disjoint slices of it)
         self.stage = torch.empty(flat.numel(), device=flat.device, dtype=torch.bfloat16) if payload == "bf16" else None
+        if payload == "bf16" and flat.is_cuda:  # ps_cast_f32_lowp / ps_convert_rows move 8 elements (16 bytes of bf16) per lane: every bucket must start and end on one
+            bad = [(u, b, e) for u, b, e in buckets if b % 8 or (e - b) % 8]
+            if bad or flat.data_ptr() % 32:
+                raise ValueError(f"bf16 gradient payload needs buckets aligned to 8 elements (and a 32-byte aligned arena); offending (unit, start, end): {bad[:3]}")
         self._next = 0
         self._pending = []
         self._sharing = False
+        self._opts_before = (None, None, None)
+        self.measure = False   # record launch-stream events around finish()'s wait (comm_report)
+        self._exposed = []
+        # what the exchange costs, for bench.py's N > 1 line: bytes each rank puts through the collectives per step
+        self.bytes_per_step = sum(e - b for _, b, e in buckets) * (2 if payload == "bf16" else 4)
 
     def _share_gpu(self, on: bool) -> None:
+        """Switches the model's launch options for the time buckets are in flight and puts back WHAT WAS THERE BEFORE when they are done (a
+        user may have set `tile_queue` / `cus_reserved` on the model for good: ops.LaunchOpts)."""
         if self.comm_stream is None or on == self._sharing or self.launch_opts is None:
             return
-        if self.share == "batch":  # (all three are per-launch arguments of the C-ABI: ps_conv_geom)
-            self.launch_opts.tiles_per_block = self.shared_tiles_per_block if on else None
-        if "reserve" in self.share:
-            self.launch_opts.cus_reserved = self.reserved_cus if on else None
-        if "queue" in self.share:
-            self.launch_opts.tile_queue = 1 if on else None
+        lo = self.launch_opts
+        if on:
+            self._opts_before = (lo.tiles_per_block, lo.cus_reserved, lo.tile_queue)
+            if self.share == "batch":  # (all three are per-launch arguments of the C-ABI: ps_conv_geom)
+                lo.tiles_per_block = self.shared_tiles_per_block
+            if "reserve" in self.share:
+                lo.cus_reserved = max(self.reserved_cus, lo.cus_reserved or 0)
+            if "queue" in self.share:
+                lo.tile_queue = 1
+        else:
+            lo.tiles_per_block, lo.cus_reserved, lo.tile_queue = self._opts_before
         self._sharing = on
 
     def begin_step(self) -> None:
@@ -135,12 +176,32 @@ class BucketedAllReduce:
             _, s, e = self.buckets[self._next]
             self._launch(s, e)
             self._next += 1
+        ev = None
+        if self.measure and self.comm_stream is not None:  # how long the launch stream stands still for the collectives: the EXPOSED part of the exchange
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for w in self._pending:
             w.wait()
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if ev is not None:
+            ev[1].record()
+            self._exposed.append(ev)
         self._pending = []
         self._share_gpu(False)
+
+    def comm_report(self) -> dict:
+        """bench.py's N > 1 line: what one step's exchange moves and how much of it the backward did not hide (mean over the steps since
+        `measure` was switched on; synchronises)."""
+        out = {"bytes_per_step": self.bytes_per_step, "buckets": len(self.buckets), "payload": self.payload, "share": self.share,
+               "reserved_cus": self.reserved_cus if "reserve" in self.share else 0, "exposed_ms": None}
+        if self._exposed:
+            torch.cuda.synchronize()
+            ms = [a.elapsed_time(b) for a, b in self._exposed]
+            out["exposed_ms"] = round(sum(ms) / len(ms), 3)
+            out["exposed_ms_max"] = round(max(ms), 3)
+            out["steps_measured"] = len(ms)
+        return out
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:

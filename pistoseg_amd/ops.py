@@ -558,6 +558,18 @@ def confusion_accum(pred: Tensor, gt: Tensor, cm: Tensor, num_class: int) -> Non
     _lib.check(lib.ps_confusion_accum(pred.data_ptr(), gt.data_ptr(), cm.data_ptr(), pred.numel(), num_class, _stream()), "ps_confusion_accum")
 
 
+def iou_from_confusion(cm: Tensor, num_class: int, out: Optional[Tensor] = None) -> Tensor:
+    """f64 [2 + num_class] on the device: (mIoU, fwIoU, per-tissue IoU...) of the int64 confusion matrix, loss.py:28-53 in numpy's evaluation order."""
+    _require_gpu(cm)
+    assert cm.dtype == torch.int64 and cm.numel() == num_class * num_class and cm.is_contiguous()
+    if out is None:
+        out = torch.empty(2 + num_class, device=cm.device, dtype=torch.float64)
+    assert out.dtype == torch.float64 and out.numel() == 2 + num_class and out.is_contiguous()
+    lib = _lib.load()
+    _lib.check(lib.ps_iou_from_confusion(cm.data_ptr(), num_class, out.data_ptr(), _stream()), "ps_iou_from_confusion")
+    return out
+
+
 def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, p_shadow: Optional[Tensor], lr: float, betas, eps: float, weight_decay: float, step: int,
                grad_inv_scale: float = 1.0) -> None:
     """Fused AdamW over a flat arena; p_shadow (bf16 or fp16, optional) receives the refreshed 16-bit weights;
@@ -629,6 +641,21 @@ def sgd_step(p: Tensor, g: Tensor, buf: Optional[Tensor], p_shadow: Optional[Ten
         lib.ps_sgd_step_scaled(p.data_ptr(), g.data_ptr(), _ptr(buf), _ptr(p_shadow), sdt, p.numel(), lr, momentum, weight_decay, int(first_step),
                                float(grad_inv_scale), _stream()),
         "ps_sgd_step_scaled",
+    )
+
+
+def sgd_step_guarded(p: Tensor, g: Tensor, buf: Optional[Tensor], p_shadow: Optional[Tensor], lr: float, momentum: float, weight_decay: float,
+                     state: Tensor, advance: bool, poly_max_step: int = 0, poly_power: float = 0.0, grad_inv_scale: float = 1.0) -> None:
+    """SGD with the dynamic-loss-scale overflow check (and the poly LR schedule) on the device (ps_sgd_step_guarded): state = int32[2] =
+    (steps applied so far, non-finite elements of this step's gradient); `advance` on the last parameter group of a step."""
+    _require_gpu(p, g, state)
+    assert state.dtype == torch.int32 and state.numel() == 2 and state.is_contiguous()
+    lib = _lib.load()
+    sdt = PS_BF16 if p_shadow is None else _dt(p_shadow)
+    _lib.check(
+        lib.ps_sgd_step_guarded(p.data_ptr(), g.data_ptr(), _ptr(buf), _ptr(p_shadow), sdt, p.numel(), lr, momentum, weight_decay, state.data_ptr(),
+                                int(advance), int(poly_max_step), float(poly_power), float(grad_inv_scale), _stream()),
+        "ps_sgd_step_guarded",
     )
 
 

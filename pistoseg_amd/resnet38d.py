@@ -20,6 +20,7 @@ launches (pistoseg_amd/ops.py -> libpistoseg_hip.so):
 """
 from __future__ import annotations
 
+import weakref
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -52,6 +53,15 @@ UNITS = [
     ("b7", "bot", 2048, 1024, 4096, 1, 4, 4, 0.5),
 ]
 TAP_OF_UNIT = {"b4": "conv3", "b5": "conv4", "b6": "conv5"}  # x_bn_relu taps, resnet38d.py:172,180,184
+
+
+_OWNERS: "weakref.WeakValueDictionary[int, Net]" = weakref.WeakValueDictionary()  # id(model) -> model, see Net.train
+
+
+def owner_of(p):
+    """The `Net` whose `train()` tagged parameter p (None for foreign parameters, copies, or a model that is gone)."""
+    m = _OWNERS.get(getattr(p, "_ps_owner", None))
+    return m if m is not None and any(q is p for q in m.parameters()) else None
 
 
 def _channels_last_(conv: nn.Conv2d) -> None:
@@ -138,6 +148,13 @@ class Net(nn.Module):
         self._shadow_version: Dict[str, int] = {}  # param name -> the parameter's torch version the shadow was last derived at
         self._drop_seed, self._drop_calls = None, 0  # Philox key / per-call counter of the Dropout2d masks (sample_dropout)
         self._wd_plan: Dict[str, Tuple] = {}       # cache key -> (deps, [(src fn, dst view, cout, taps, cin)]): see refresh_dgrad_weights
+        # Where the autograd nodes of the reference-style calls (`model(x)` under grad mode, then `loss.backward()`) put the weight gradients:
+        #   "arena"    (default) straight into the model's flat gradient arena, which every parameter's `.grad` is a view of (arena.ParamArena):
+        #              no per-step allocation / zero fill / accumulate pass; `arena.ArenaAdamW` / `arena.PolyOptimizer` then step in one launch;
+        #   "autograd" returned to autograd as fresh tensors (needed under a torch DistributedDataParallel wrapper, whose hooks fire on
+        #              accumulation, and for torch.autograd.grad).
+        self.grad_sink = "arena"
+        self.overlap_wgrad = True  # autograd path: weight gradients on a side stream (see backward_backbone), as the native trainers run them
         self.train(True)  # apply the freezing rules from the start (the reference's scripts always call train())
 
     # ------------------------------------------------------------------ reference API
@@ -167,6 +184,10 @@ class Net(nn.Module):
                 layer.eval()
                 layer.bias.requires_grad = False
                 layer.weight.requires_grad = False
+        self._freeze_epoch = getattr(self, "_freeze_epoch", 0) + 1  # (arena.ParamArena re-checks the trainable set when this moves)
+        _OWNERS[id(self)] = self
+        for p in self.parameters():  # lets an optimiser built from bare parameter lists find the model's arena (arena.model_of)
+            p._ps_owner = id(self)   # (a plain key into a weak registry: parameter objects stay picklable)
         return
 
     # ------------------------------------------------------------------ device-side views of the parameters
@@ -586,8 +607,11 @@ class Net(nn.Module):
                 wgrad_stream.wait_stream(torch.cuda.current_stream())  # dy (and the zeroed gradient arena) are ready
                 with torch.cuda.stream(wgrad_stream):
                     ops.conv2d_wgrad(specs[cname], x_act, dy, grads[f"{name}.{cname}.weight"], **kw)
-                x_act.record_stream(wgrad_stream)  # keep the caching allocator from recycling them under the side stream
-                dy.record_stream(wgrad_stream)
+                # keep the caching allocator from recycling them under the side stream -- the plain 16-bit companions too (ops.attach_hi):
+                # in the split precisions they are separate allocations and the ones the weight gradient actually reads
+                for t in (x_act, dy, ops._hi_of(x_act), ops._hi_of(dy)):
+                    if t is not None:
+                        t.record_stream(wgrad_stream)
 
             want_hi = self._want_hi()
 

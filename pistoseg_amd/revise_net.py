@@ -32,6 +32,7 @@ import torch
 from torch import nn
 
 from . import ops
+from .arena import ParamArena
 from .ops import ConvSpec
 from .seg_model import ResNet38dSeg
 
@@ -250,18 +251,40 @@ class _RFMFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *d_outs):
         model = ctx.model
-        dev = ctx.saved_ctx["F"].device
-        grads = model.new_grad_buffers(dev)
+        saved_ctx, ctx.saved_ctx = ctx.saved_ctx, None
+        dev = saved_ctx["F"].device
         d_outs = [d if d is None else d.float() for d in d_outs]
-        model.rfm_backward(ctx.saved_ctx, d_outs, grads)
-        ctx.saved_ctx = None
-        res = []
-        f9 = model._unpack_w9_grad(grads["f9"].view(384, FCAT)) if "f9" in grads else (None, None)
-        for name in ctx.names:
-            if name == "f9_1.weight":
-                res.append(f9[0])
-            elif name == "f9_2.weight":
-                res.append(f9[1])
-            else:
-                res.append(grads[name].permute(0, 3, 1, 2))
-        return (None, None, None, None) + tuple(res)
+        if model.grad_sink != "arena":  # gradients handed to autograd: fresh buffers every backward (see seg_model._SegFunction)
+            grads = model.new_grad_buffers(dev)
+            model.rfm_backward(saved_ctx, d_outs, grads)
+            res = []
+            f9 = model._unpack_w9_grad(grads["f9"].view(384, FCAT)) if "f9" in grads else (None, None)
+            for name in ctx.names:
+                if name == "f9_1.weight":
+                    res.append(f9[0])
+                elif name == "f9_2.weight":
+                    res.append(f9[1])
+                else:
+                    res.append(grads[name].permute(0, 3, 1, 2))
+            return (None, None, None, None) + tuple(res)
+        arena = ParamArena.of(model)
+        arena.bind_param_grads()
+        red = arena.reducer
+        if red is not None:
+            inv = 1.0 / torch.distributed.get_world_size(red.group)
+            d_outs = [d if d is None else d * inv for d in d_outs]
+            red.begin_step()
+
+        def after(name):
+            if name == "heads":  # fc8 / f8_3 / f8_4 / f9 gradients are final: unpack f9 into its arena slots
+                arena.heads_done()
+                if red is not None:
+                    for nm in ("fc8", "f8_3", "f8_4", "f9_1", "f9_2"):
+                        red.on_unit_done(nm)
+            elif red is not None:
+                red.on_unit_done(name)
+
+        model.rfm_backward(saved_ctx, d_outs, arena.grads, after_unit=after, wgrad_stream=arena.side_stream() if model.overlap_wgrad else None)
+        if red is not None:
+            red.finish()
+        return (None, None, None, None) + (None,) * len(ctx.names)

@@ -74,3 +74,30 @@ def rfm_losses(outputs, pmask: Tensor, pcam: Tensor, label: Tensor, want_grad: b
     total = l_cls + l_rfm + l_ecr
     grads = (d_cam, d_cam_rv, d_pm, d_pc) if want_grad else None
     return (total, l_cls, l_rfm, l_ecr), grads
+
+
+class _RFMLossBlock(torch.autograd.Function):
+    """The whole loss block as one autograd node: forward = the fused reductions with their gradients, backward hands them out."""
+
+    @staticmethod
+    def forward(ctx, cam, cam_rv, pmask_rv, pcam_rv, pmask, pcam, label, deterministic):
+        (total, l_cls, l_rfm, l_ecr), grads = rfm_losses((cam, cam_rv, pmask_rv, pcam_rv), pmask, pcam, label, want_grad=True,
+                                                          deterministic=deterministic)
+        ctx.save_for_backward(*grads)
+        ctx.mark_non_differentiable(l_cls, l_rfm, l_ecr)
+        return total.reshape(()), l_cls.reshape(()), l_rfm.reshape(()), l_ecr.reshape(())
+
+    @staticmethod
+    def backward(ctx, g_total, *_unused):
+        # (g_total is the 1.0 of `l.backward()`, or a loss scale: applied to the four maps in place -- they are this node's own buffers)
+        grads = [g.mul_(g_total) for g in ctx.saved_tensors]
+        return (*grads, None, None, None, None)
+
+
+def rfm_loss_block(cam: Tensor, cam_rv: Tensor, pmask_rv: Tensor, pcam_rv: Tensor, pmask: Tensor, pcam: Tensor, label: Tensor,
+                   deterministic: Optional[bool] = None) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """`l, loss_cls, loss_rfm, loss_ecr` of the reference's `train_epoch` (revise_pseudo_labels.py:253-282) from the network's four outputs,
+    attached to autograd: `l.backward()` then `optimizer.step()` work as in the script.  The one-call replacement for the script's ~25 eager
+    torch statements (two `topk` over 200 k elements per sample among them); pmask / pcam carry the zero background channel and label is
+    [N, C] or [N, C, 1, 1] with label[:, 0] = 1, as the script builds them (:238-248).  The three partial losses are for logging (no gradient)."""
+    return _RFMLossBlock.apply(cam, cam_rv, pmask_rv, pcam_rv, pmask, pcam, label, deterministic)

@@ -15,6 +15,7 @@ import torch
 from torch import nn
 
 from . import ops, resnet38d
+from .arena import ParamArena
 
 Tensor = torch.Tensor
 
@@ -113,13 +114,32 @@ class _SegFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits: Tensor):
         model, saved = ctx.model, ctx.saved_acts
-        grads = model.new_grad_buffers(dlogits.device)
+        ctx.saved_acts = None
+        if model.grad_sink != "arena":  # gradients handed to autograd (torch DDP's hooks, torch.autograd.grad): fresh buffers every backward
+            grads = model.new_grad_buffers(dlogits.device)
+            dw8 = grads["fc8.weight"].view(model.classes, 4096) if "fc8.weight" in grads else torch.zeros(
+                (model.classes, 4096), device=dlogits.device)
+            g_x7 = model.head_backward(saved.conv6, ctx.drop7, dlogits, dw8)
+            model.backward_backbone(saved, g_x7, grads)
+            return (None, None) + tuple(grads[n].permute(0, 3, 1, 2) for n in ctx.names)
+        # the weight gradients go straight into the model's gradient arena, which the parameters' `.grad` are views of (arena.ParamArena):
+        # nothing to allocate, zero or accumulate per step, weight gradients on the side stream, [N > 1: buckets all-reduced behind the plan]
+        arena = ParamArena.of(model)
+        arena.bind_param_grads()
+        grads, red = arena.grads, arena.reducer
+        if red is not None:  # SUM all-reduce of local-mean losses: the global mean's gradient is 1/world of each
+            dlogits = dlogits * (1.0 / torch.distributed.get_world_size(red.group))
         dw8 = grads["fc8.weight"].view(model.classes, 4096) if "fc8.weight" in grads else torch.zeros(
             (model.classes, 4096), device=dlogits.device)
         g_x7 = model.head_backward(saved.conv6, ctx.drop7, dlogits, dw8)
-        model.backward_backbone(saved, g_x7, grads)
-        ctx.saved_acts = None
-        return (None, None) + tuple(grads[n].permute(0, 3, 1, 2) for n in ctx.names)
+        if red is not None:
+            red.begin_step()
+            red.on_unit_done("fc8")
+        model.backward_backbone(saved, g_x7, grads, after_unit=red.on_unit_done if red is not None else None,
+                                wgrad_stream=arena.side_stream() if model.overlap_wgrad else None)
+        if red is not None:
+            red.finish()
+        return (None, None) + (None,) * len(ctx.names)
 
 
 def create_model(arch: str, encoder_name: Optional[str] = None, in_channels: int = 3, classes: int = 3, precision: str = "bf16", **kw):

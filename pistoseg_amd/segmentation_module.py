@@ -18,9 +18,10 @@ import os
 from functools import partial
 
 from . import ops
+from .arena import ArenaAdamW
 from .lightning_shim import LightningModule
 from .metrics import mIoUMask
-from .seg_model import create_model
+from .seg_model import ResNet38dSeg, create_model
 from .sliding import SlidingWindowAccumulator
 from .tta import SegmentationTTAWrapper
 
@@ -136,10 +137,20 @@ class _Shell(LightningModule):
         return {k: v for k, (v, _) in out.items()}
 
     def configure_optimizers(self):
+        """`[AdamW(params, lr, weight_decay)], [ExponentialLR(gamma=0.9)]` (segmentation_module.py:86-90, mosaic_module.py:92-96).  For the in-tree
+        ResNet38-d model the AdamW is `arena.ArenaAdamW`, a torch.optim.AdamW subclass with the same arithmetic whose `step()` is one fused launch
+        over the model's flat parameter arena and whose `zero_grad()` is one memset (the autograd node writes the gradients into that arena)."""
         params = [p for p in self.model.parameters() if p.requires_grad]
-        optimizer = AdamW(params, self.args.lr, weight_decay=self.args.weight_decay)
+        opt_cls = ArenaAdamW if isinstance(self.model, ResNet38dSeg) else AdamW
+        optimizer = opt_cls(params, self.args.lr, weight_decay=self.args.weight_decay)
         scheduler = ExponentialLR(optimizer, gamma=0.9)
         return [optimizer], [scheduler]
+
+    def _train_miou(self):
+        """What `self.log("train_miou...", self.train_iou.Mean_Intersection_over_Union())` logs, without the device->host copy when the meter has
+        just been updated on the device (metrics.mIoUMask.forward keeps the values it computed): a 0-d device tensor, same f64 value."""
+        vals = getattr(self.train_iou, "last_iou", None)
+        return vals[0] if vals is not None else self.train_iou.Mean_Intersection_over_Union()
 
     def forward(self, x):
         return self.model(x)
@@ -161,7 +172,7 @@ class SegmentationModule(_Shell):
         loss = pixel_ce_mean(mask_pred, batch["mask"], self.ignore_index)
         self.log("train_loss", loss, prog_bar=True)
         self.train_iou(mask_pred, batch["mask"])
-        self.log("train_miou", self.train_iou.Mean_Intersection_over_Union(), prog_bar=True)
+        self.log("train_miou", self._train_miou(), prog_bar=True)
         return loss
 
 
@@ -176,5 +187,5 @@ class MosaicModule(_Shell):
         loss = dice_multiclass(mask_pred, batch["mask"], self.ignore_index)
         self.log("train_loss", loss, prog_bar=True)
         self.train_iou(mask_pred, batch["mask"])
-        self.log("train_miou_epoch", self.train_iou.Mean_Intersection_over_Union(), prog_bar=True)
+        self.log("train_miou_epoch", self._train_miou(), prog_bar=True)
         return loss

@@ -19,8 +19,8 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _lib, ops
-from .dist import BucketedAllReduce, plan_buckets
-from .resnet38d import UNITS
+from .arena import ParamArena, arena_order  # noqa: F401  (arena_order: re-exported, earlier rounds imported it from here)
+from .dist import BucketedAllReduce, default_reserved_cus, plan_buckets
 from .seg_model import ResNet38dSeg
 
 Tensor = torch.Tensor
@@ -52,33 +52,71 @@ def init_weights_he(model: torch.nn.Module, seed: int = 42) -> None:
                 b.copy_(torch.rand(b.shape, generator=g) + 0.6)
 
 
-def arena_order(model: ResNet38dSeg) -> List[Tuple[str, torch.nn.Parameter]]:
-    """Trainable conv weights in the order their gradients become final during the reverse plan
-    (fc8, b7, b6, ... ) so that all-reduce buckets are contiguous arena slices."""
-    named = dict(model.trainable_conv_params())
-    out: List[Tuple[str, torch.nn.Parameter]] = []
-    units = getattr(model, "units", UNITS)
-    for k in list(named):
-        if k.split(".")[0] not in {u[0] for u in units}:
-            out.append((k, named.pop(k)))  # heads (fc8, ...) finish first
-    for u in reversed(units):
-        for k in list(named):
-            if k.split(".")[0] == u[0]:
-                out.append((k, named.pop(k)))
-    assert not named
-    return out
-
-
 class _ArenaMixin:
+    """The trainers keep their parameters, gradients and 16-bit shadow in the model's `arena.ParamArena` (shared with the reference-API
+    optimisers `arena.ArenaAdamW` / `arena.PolyOptimizer`); the attributes below are views of it."""
+
+    def _use_arena(self, model) -> None:
+        self.arena = ParamArena.of(model)
+        a = self.arena
+        self.entries, self.offsets, self.grads = a.entries, a.offsets, a.grads
+        self.p_flat, self.g_flat, self.pb_flat = a.p_flat, a.g_flat, a.pb_flat
+        self.n_scratch, self.f9_packed = a.n_scratch, a.f9_packed
+
+    # -- dynamic loss scaling without a host round trip per step (fp16 / fp16x3) ----------------------------------------------------------
+    # The overflow check gates the optimiser ON THE DEVICE (ps_adamw_step_guarded / ps_sgd_step_guarded: opt_state = [steps applied, non-finite
+    # elements of this step]); the host learns each step's flag through an asynchronous 4-byte copy and adapts the scale `scale_lag` steps later
+    # (`settle()` brings the bookkeeping up to date; it is exact once called).  Policy: torch.cuda.amp.GradScaler's (x 0.5 and skip on overflow,
+    # x 2 every 200 clean steps).
+    def _init_dynamic_scale(self, dev, default_scale: float, loss_scale: Optional[float]) -> None:
+        fp16 = self.model.precision in ("fp16", "fp16x3")
+        self.dynamic_scale = fp16 and loss_scale is None
+        self.loss_scale = float(loss_scale) if loss_scale is not None else (default_scale if fp16 else 1.0)
+        self.clean_steps, self.skipped_steps = 0, 0
+        self.opt_state = torch.zeros(2, device=dev, dtype=torch.int32)
+        self.scale_lag = 2
+        self._pending_flags = []  # (event, pinned flag, loss scale the step ran with), oldest first
+        # (pinned slots and events are made once: allocating pinned memory synchronises the device)
+        self._flag_slots = [torch.empty(1, dtype=torch.int32, pin_memory=True) for _ in range(self.scale_lag + 2)] if self.dynamic_scale else []
+        self._flag_events = [torch.cuda.Event() for _ in self._flag_slots]
+        self._flag_next = 0
+
+    def _count_nonfinite(self) -> None:
+        """opt_state[1] <- non-finite elements of the gradient arena (after the all-reduce: every rank sees the same count and takes the same decisions)."""
+        flag = self.opt_state[1:]
+        flag.zero_()
+        ops.nonfinite_count(self.g_flat, out=flag)
+
+    def _enqueue_flag(self) -> None:
+        self.settle(keep=len(self._flag_slots) - 1)  # (a free slot in the ring)
+        host, ev = self._flag_slots[self._flag_next], self._flag_events[self._flag_next]
+        self._flag_next = (self._flag_next + 1) % len(self._flag_slots)
+        host.copy_(self.opt_state[1:], non_blocking=True)
+        ev.record()
+        self._pending_flags.append((ev, host, self.loss_scale))
+        self.settle(keep=self.scale_lag)
+
+    def settle(self, keep: int = 0) -> None:
+        """Bring the dynamic-loss-scale bookkeeping (`loss_scale`, `skipped_steps`, the applied-step count, `clean_steps`) up to date with all
+        but the newest `keep` steps: waits for their overflow flags.  A flag only ever lowers the scale below the scale ITS step ran with, so two
+        overflowing steps enqueued with the same scale halve it once."""
+        while len(self._pending_flags) > keep:
+            ev, host, used = self._pending_flags.pop(0)
+            ev.synchronize()
+            if int(host[0]) > 0:
+                self.loss_scale = max(min(self.loss_scale, used * 0.5), 1.0)
+                self.clean_steps = 0
+                self.skipped_steps += 1
+            else:
+                self._step_applied()
+                self.clean_steps += 1
+                if self.clean_steps >= 200:
+                    self.loss_scale, self.clean_steps = min(self.loss_scale * 2.0, 2.0 ** 24), 0
+
     def sync_shadow(self) -> None:
         """Re-derive the whole 16-bit weight arena from the f32 master in one launch (after construction, or after the masters were
         written through torch: `load_state_dict` on resume).  Per-parameter staleness is also caught lazily by `Net.w_fwd`."""
-        if self.pb_flat is not None:
-            ops.cast_f32_lowp(self.p_flat, self.pb_flat)
-            for name, p in self.entries:
-                if name in self.model._bf16_shadow:
-                    self.model._shadow_version[name] = p._version
-        self.model.invalidate_weight_cache()
+        self.arena.sync_shadow()
 
     def load_state_dict(self, state_dict, strict: bool = True):
         """Checkpoint resume through the trainer: the parameters live in the f32 arena (their `.data` are views of it), so the
@@ -92,7 +130,7 @@ class SegTrainer(_ArenaMixin):
     def __init__(self, model: ResNet38dSeg, lr: float = 1e-3, weight_decay: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8,
                  ignore_index: Optional[int] = 3, process_group=None, bucket_mb: float = 48.0, track_iou: bool = True,
                  loss_scale: Optional[float] = None, overlap_wgrad: bool = True, deterministic: Optional[bool] = None, grad_payload: str = "fp32",
-                 share: str = "reserve+queue", reserved_cus: int = 32):
+                 share: str = "reserve+queue", reserved_cus: Optional[int] = None):
         """grad_payload: what the N > 1 gradient exchange puts on the wire -- "fp32" (SUM all-reduce of the f32 arena slices) or "bf16" (each
         bucket cast to bf16, all-reduced, widened back: half the xGMI bytes; see dist.BucketedAllReduce).  share / reserved_cus: how this model's
         conv launches make room for the collectives while buckets are in flight ("batch": tiles_per_block = 1; "reserve": cus_reserved; "queue": tile_queue;
@@ -116,50 +154,17 @@ class SegTrainer(_ArenaMixin):
         dev = next(model.parameters()).device
         self.device = dev
         model.train()
-        self.entries = arena_order(model)
-        total = sum(p.numel() for _, p in self.entries)
-        self.p_flat = torch.empty(total, device=dev, dtype=torch.float32)
-        self.g_flat = torch.zeros(total, device=dev, dtype=torch.float32)
-        self.m_flat = torch.zeros(total, device=dev, dtype=torch.float32)
-        self.v_flat = torch.zeros(total, device=dev, dtype=torch.float32)
-        # 16-bit shadow of the weights, refreshed by the fused optimiser (the split path re-derives its [hi | hi | lo] planes from the master instead)
-        self.pb_flat = torch.empty(total, device=dev, dtype=model.compute_dtype) if model.precision in ("bf16", "fp16") else None
-        # fp16 activations gradients underflow without a loss scale (a CE gradient is ~1/(N*H*W) = 3e-7 per pixel):
-        # dynamic scaling a la torch.cuda.amp.GradScaler (x0.5 and skip on overflow, x2 every 200 clean steps).
-        self.dynamic_scale = model.precision in ("fp16", "fp16x3") and loss_scale is None
-        self.loss_scale = float(loss_scale) if loss_scale is not None else (65536.0 if model.precision in ("fp16", "fp16x3") else 1.0)
-        self.clean_steps, self.skipped_steps = 0, 0
-        # Dynamic loss scaling without a host round trip per step: the overflow check gates the optimiser ON THE DEVICE (ps_adamw_step_guarded:
-        # opt_state = [steps applied, non-finite elements of this step]); the host learns each step's flag through an asynchronous 4-byte copy and
-        # adapts the scale `scale_lag` steps later (`settle()` brings the bookkeeping up to date; it is exact once called).
-        self.opt_state = torch.zeros(2, device=dev, dtype=torch.int32)
-        self.scale_lag = 2
-        self._pending_flags = []  # (event, pinned flag, loss scale the step ran with), oldest first
-        # (pinned slots and events are made once: allocating pinned memory synchronises the device)
-        self._flag_slots = [torch.empty(1, dtype=torch.int32, pin_memory=True) for _ in range(self.scale_lag + 2)] if self.dynamic_scale else []
-        self._flag_events = [torch.cuda.Event() for _ in self._flag_slots]
-        self._flag_next = 0
-        self.grads: Dict[str, Tensor] = {}
-        self.offsets: Dict[str, Tuple[int, int]] = {}
-        off = 0
-        for name, p in self.entries:
-            cout, cin, kh, kw = p.shape
-            n = p.numel()
-            view = self.p_flat[off:off + n].view(cout, kh, kw, cin)
-            view.copy_(p.detach().permute(0, 2, 3, 1))
-            p.data = view.permute(0, 3, 1, 2)  # OIHW shape, channels-last strides, arena storage
-            self.grads[name] = self.g_flat[off:off + n].view(cout, kh, kw, cin)
-            if self.pb_flat is not None:
-                model.register_shadow(name, p, self.pb_flat[off:off + n].view(cout, kh, kw, cin))
-            self.offsets[name] = (off, n)
-            off += n
-        self.sync_shadow()
+        self._use_arena(model)
+        self.m_flat = torch.zeros_like(self.p_flat)
+        self.v_flat = torch.zeros_like(self.p_flat)
+        # fp16 activations gradients underflow without a loss scale (a CE gradient is ~1/(N*H*W) = 3e-7 per pixel)
+        self._init_dynamic_scale(dev, 65536.0, loss_scale)
         # all-reduce buckets: (unit after which the bucket is final, start, end) over the arena
         self.reducer: Optional[BucketedAllReduce] = None
         if self.world > 1:
             buckets = plan_buckets([(name, p.numel()) for name, p in self.entries], int(bucket_mb * (1 << 20) / 4))
             self.reducer = BucketedAllReduce(self.g_flat, buckets, process_group, launch_opts=model.launch, payload=grad_payload, share=share,
-                                             reserved_cus=reserved_cus)
+                                             reserved_cus=default_reserved_cus() if reserved_cus is None else reserved_cus)
         self.cm = torch.zeros(model.classes * model.classes, device=dev, dtype=torch.int64)  # train_iou confusion
 
     # ------------------------------------------------------------------
@@ -186,20 +191,11 @@ class SegTrainer(_ArenaMixin):
         if self.reducer is not None:
             self.reducer.finish()
         if self.dynamic_scale:
-            # (the all-reduce already summed the arenas, so every rank sees the same count and takes the same decisions)
-            flag = self.opt_state[1:]
-            flag.zero_()
-            ops.nonfinite_count(self.g_flat, out=flag)
+            self._count_nonfinite()
             ops.adamw_step_guarded(self.p_flat, self.g_flat, self.m_flat, self.v_flat, self.pb_flat, self.lr, self.betas, self.eps,
                                    self.weight_decay, self.opt_state, grad_inv_scale=1.0 / self.loss_scale)
-            self.settle(keep=len(self._flag_slots) - 1)  # (a free slot in the ring)
-            host, ev = self._flag_slots[self._flag_next], self._flag_events[self._flag_next]
-            self._flag_next = (self._flag_next + 1) % len(self._flag_slots)
-            host.copy_(flag, non_blocking=True)
-            ev.record()
-            self._pending_flags.append((ev, host, self.loss_scale))
+            self._enqueue_flag()
             model.invalidate_weight_cache()
-            self.settle(keep=self.scale_lag)
             return loss
         self.step_count += 1
         ops.adamw_step(self.p_flat, self.g_flat, self.m_flat, self.v_flat, self.pb_flat, self.lr, self.betas, self.eps,
@@ -207,23 +203,8 @@ class SegTrainer(_ArenaMixin):
         model.invalidate_weight_cache()
         return loss
 
-    def settle(self, keep: int = 0) -> None:
-        """Bring the dynamic-loss-scale bookkeeping (`loss_scale`, `skipped_steps`, `step_count`, `clean_steps`) up to date with all but the
-        newest `keep` steps: waits for their overflow flags (torch.cuda.amp.GradScaler's policy: x 0.5 and skip on overflow, x 2 every 200 clean
-        steps).  A flag only ever lowers the scale below the scale ITS step ran with, so two overflowing steps enqueued with the same scale
-        halve it once."""
-        while len(self._pending_flags) > keep:
-            ev, host, used = self._pending_flags.pop(0)
-            ev.synchronize()
-            if int(host[0]) > 0:
-                self.loss_scale = max(min(self.loss_scale, used * 0.5), 1.0)
-                self.clean_steps = 0
-                self.skipped_steps += 1
-            else:
-                self.step_count += 1
-                self.clean_steps += 1
-                if self.clean_steps >= 200:
-                    self.loss_scale, self.clean_steps = min(self.loss_scale * 2.0, 2.0 ** 24), 0
+    def _step_applied(self) -> None:
+        self.step_count += 1
 
     def lr_scheduler_step(self, gamma: float = 0.9) -> None:
         """ExponentialLR(gamma=0.9) once per epoch (segmentation_module.py:88)."""
@@ -239,7 +220,7 @@ class RFMTrainer(_ArenaMixin):
 
     def __init__(self, model, lr: float = 0.01, wt_dec: float = 5e-4, max_step: int = 1000, power: float = 0.9, process_group=None,
                  bucket_mb: float = 48.0, loss_scale: Optional[float] = None, overlap_wgrad: bool = True, deterministic: Optional[bool] = None,
-                 grad_payload: str = "fp32", share: str = "reserve+queue", reserved_cus: int = 32):
+                 grad_payload: str = "fp32", share: str = "reserve+queue", reserved_cus: Optional[int] = None):
         from .revise_net import FCAT, Net
 
         assert isinstance(model, Net) and next(model.parameters()).is_cuda
@@ -253,43 +234,14 @@ class RFMTrainer(_ArenaMixin):
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         dev = next(model.parameters()).device
         model.train()
-        self.entries = arena_order(model)  # heads (from_scratch_layers) first, then b7 ... b3
-        total = sum(p.numel() for _, p in self.entries)
-        self.p_flat = torch.empty(total, device=dev, dtype=torch.float32)
-        self.g_flat = torch.zeros(total, device=dev, dtype=torch.float32)
-        self.buf_flat = torch.zeros(total, device=dev, dtype=torch.float32)
-        # 16-bit shadow of the weights, refreshed by the fused optimiser (the split path re-derives its [hi | hi | lo] planes from the master instead)
-        self.pb_flat = torch.empty(total, device=dev, dtype=model.compute_dtype) if model.precision in ("bf16", "fp16") else None
-        self.dynamic_scale = model.precision in ("fp16", "fp16x3") and loss_scale is None
-        self.loss_scale = float(loss_scale) if loss_scale is not None else (1024.0 if model.precision in ("fp16", "fp16x3") else 1.0)
-        self.clean_steps, self.skipped_steps = 0, 0
-        self.grads: Dict[str, Tensor] = {}
-        self.offsets: Dict[str, Tuple[int, int]] = {}
-        scratch = {id(m.weight) for m in model.from_scratch_layers}
-        off, self.n_scratch = 0, 0
-        for name, p in self.entries:
-            cout, cin, kh, kw = p.shape
-            n = p.numel()
-            view = self.p_flat[off:off + n].view(cout, kh, kw, cin)
-            view.copy_(p.detach().permute(0, 2, 3, 1))
-            p.data = view.permute(0, 3, 1, 2)
-            if not name.startswith("f9_"):
-                self.grads[name] = self.g_flat[off:off + n].view(cout, kh, kw, cin)
-                if self.pb_flat is not None:
-                    model.register_shadow(name, p, self.pb_flat[off:off + n].view(cout, kh, kw, cin))
-            self.offsets[name] = (off, n)
-            off += n
-            if id(p) in scratch:
-                assert off - n == self.n_scratch, "scratch heads must be contiguous at the start of the arena"
-                self.n_scratch = off
-        self.f9_packed = torch.zeros((384, 1, 1, FCAT), device=dev, dtype=torch.float32)
-        self.grads["f9"] = self.f9_packed
-        self.sync_shadow()
+        self._use_arena(model)  # heads (from_scratch_layers) first, then b7 ... b3
+        self.buf_flat = torch.zeros_like(self.p_flat)
+        self._init_dynamic_scale(dev, 1024.0, loss_scale)
         self.reducer: Optional[BucketedAllReduce] = None
         if self.world > 1:
             buckets = plan_buckets([(name, p.numel()) for name, p in self.entries], int(bucket_mb * (1 << 20) / 4))
             self.reducer = BucketedAllReduce(self.g_flat, buckets, process_group, launch_opts=model.launch, payload=grad_payload, share=share,
-                                             reserved_cus=reserved_cus)
+                                             reserved_cus=default_reserved_cus() if reserved_cus is None else reserved_cus)
 
     def train_step(self, x: Tensor, pmask: Tensor, pcam: Tensor, label: Tensor):
         """x [N,3,H,W]; pmask/pcam [N,C,32,32] with the zero background channel; label [N,C] with label[:,0] = 1.
@@ -308,10 +260,7 @@ class RFMTrainer(_ArenaMixin):
 
         def after(name):
             if name == "heads":  # fc8 / f8_3 / f8_4 / f9 gradients are final: unpack f9 into its arena slots
-                g1, g2 = model._unpack_w9_grad(self.f9_packed.view(384, self.FCAT))
-                for nm, g in (("f9_1.weight", g1), ("f9_2.weight", g2)):
-                    o, n = self.offsets[nm]
-                    self.g_flat[o:o + n].view(192, 1, 1, 195).copy_(g.permute(0, 2, 3, 1))
+                self.arena.heads_done()
                 if self.reducer is not None:
                     for nm in ("fc8", "f8_3", "f8_4", "f9_1", "f9_2"):
                         self.reducer.on_unit_done(nm)
@@ -321,27 +270,30 @@ class RFMTrainer(_ArenaMixin):
         model.rfm_backward(ctx, list(d_outs), self.grads, after_unit=after, wgrad_stream=self.wgrad_stream)
         if self.reducer is not None:
             self.reducer.finish()
+        inv = 1.0 / self.loss_scale  # the scale these gradients were produced with
+        ns, tot = self.n_scratch, self.p_flat.numel()
+        shadow = lambda lo, hi: None if self.pb_flat is None else self.pb_flat[lo:hi]  # noqa: E731
+        groups = [(lo, hi, lr) for lo, hi, lr in ((0, ns, 10 * self.lr0), (ns, tot, self.lr0)) if hi > lo]  # scratch heads at 10 x lr (revise_pseudo_labels.py:173-176)
         if self.dynamic_scale:
-            if int(ops.nonfinite_count(self.g_flat).item()) > 0:
-                self.loss_scale = max(self.loss_scale * 0.5, 1.0)
-                self.clean_steps = 0
-                self.skipped_steps += 1
-                return losses
-            self.clean_steps += 1
-        inv = 1.0 / self.loss_scale  # the scale these gradients were produced with (it may grow below, for the NEXT step)
+            # overflow check, `first step` and the poly schedule on the device (steps applied so far = opt_state[0]): no host read per step
+            self._count_nonfinite()
+            for k, (lo, hi, lr) in enumerate(groups):
+                ops.sgd_step_guarded(self.p_flat[lo:hi], self.g_flat[lo:hi], self.buf_flat[lo:hi], shadow(lo, hi), lr, self.wt_dec, self.wt_dec,
+                                     self.opt_state, advance=k == len(groups) - 1, poly_max_step=self.max_step, poly_power=self.power, grad_inv_scale=inv)
+            self._enqueue_flag()
+            model.invalidate_weight_cache()
+            return losses
         # utils.PolyOptimizer.step
         mult = (1 - self.global_step / self.max_step) ** self.power if self.global_step < self.max_step else None
         if mult is not None:
             self._lr_mult = mult
         mult = getattr(self, "_lr_mult", 1.0)
         first = self.global_step == 0
-        ns, tot = self.n_scratch, self.p_flat.numel()
-        for lo, hi, lr in ((0, ns, 10 * self.lr0 * mult), (ns, tot, self.lr0 * mult)):
-            if hi > lo:
-                ops.sgd_step(self.p_flat[lo:hi], self.g_flat[lo:hi], self.buf_flat[lo:hi], None if self.pb_flat is None else self.pb_flat[lo:hi],
-                             lr, self.wt_dec, self.wt_dec, first, grad_inv_scale=inv)
+        for lo, hi, lr in groups:
+            ops.sgd_step(self.p_flat[lo:hi], self.g_flat[lo:hi], self.buf_flat[lo:hi], shadow(lo, hi), lr * mult, self.wt_dec, self.wt_dec, first, grad_inv_scale=inv)
         self.global_step += 1
         model.invalidate_weight_cache()
-        if self.dynamic_scale and self.clean_steps >= 200:
-            self.loss_scale, self.clean_steps = min(self.loss_scale * 2.0, 2.0 ** 24), 0
         return losses
+
+    def _step_applied(self) -> None:
+        self.global_step += 1

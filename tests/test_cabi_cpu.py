@@ -32,7 +32,7 @@ def test_exports_match_header(lib):
     for name in decl:
         assert hasattr(lib, name), f"{name} declared in include/pistoseg_hip.h but not exported"
     assert decl == set(_lib.PROTOTYPES), (decl ^ set(_lib.PROTOTYPES))
-    assert lib.ps_version() == 225
+    assert lib.ps_version() == 226
 
 
 def test_product_library_has_no_debug_switches_and_debug_library_has_all(lib):

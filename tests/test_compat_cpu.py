@@ -23,7 +23,7 @@ def test_stage_scripts_import_lines_resolve_to_the_mirrors():
         "import pistoseg_amd",
         "assert SegmentationModule.__module__ == 'pistoseg_amd.segmentation_module' and MosaicModule.__module__ == SegmentationModule.__module__",
         "assert Net.__module__ == 'pistoseg_amd.revise_net' and mIoUMask.__module__ == 'pistoseg_amd.metrics'",
-        "assert utils.PolyOptimizer.__module__ == 'pistoseg_amd.optim' and models.resnet38d.Net.__module__ == 'pistoseg_amd.resnet38d'",
+        "assert utils.PolyOptimizer.__module__ == 'pistoseg_amd.arena' and models.resnet38d.Net.__module__ == 'pistoseg_amd.resnet38d'",
         "net = Net(num_classes=4); assert len(net.state_dict()) == 233 and net.eval() is None",
         "print('ok')",
     ])
@@ -36,7 +36,7 @@ def test_utils_shim_overlays_a_utils_module_further_down_the_path(tmp_path):
     """With the reference tree behind the shim on sys.path its host-side helpers stay visible; only PolyOptimizer is replaced."""
     (tmp_path / "utils.py").write_text("def get_background(region):\n    return 'host helper'\nclass PolyOptimizer: pass\n")
     (tmp_path / "loss.py").write_text("class DiceLoss: pass\nclass mIoUMask: pass\n")
-    code = ("import utils, loss; assert utils.get_background(None) == 'host helper'; assert utils.PolyOptimizer.__module__ == 'pistoseg_amd.optim';"
+    code = ("import utils, loss; assert utils.get_background(None) == 'host helper'; assert utils.PolyOptimizer.__module__ == 'pistoseg_amd.arena';"
             "assert loss.mIoUMask.__module__ == 'pistoseg_amd.metrics' and hasattr(loss, 'DiceLoss'); print('ok')")
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "pistoseg_amd", "compat"), str(tmp_path)]))
     r = subprocess.run([sys.executable, "-c", code], env=env, cwd="/tmp", capture_output=True, text=True, timeout=300)
