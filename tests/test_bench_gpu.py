@@ -33,6 +33,13 @@ def test_bench_json_contract_small_config():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r and "kernel" in r
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["unit"] == "tiles/s" and c["value"] > 0 and c["cores"] >= 1 and isinstance(c["sample"], str)
+    assert c["cores"] in {row["threads"] for row in c["sweep"]} and c["host_threads"] >= c["cores"] and len(c["sweep"]) >= 2
+    assert max(row["train_tiles_s"] for row in c["sweep"]) == c["value"]  # `value` is the best of the thread sweep, `cores` the thread count that gave it
+    a = d["api_path"]  # the same step through the reference's API (SegmentationModule.training_step + configure_optimizers + loss.backward), timed beside
+    assert a["train_tiles_s"] > 0 and abs(a["ratio_to_native"] - a["train_tiles_s"] / d["value"]) < 1e-3 and "ArenaAdamW" in a["what"] and 0 < a["final_loss"] < 1e3
+    q = d["parity_path"]  # the parity-grade precision on the same batch, with its error against the oracle forward of the cpu_baseline leg
+    assert q["dtype"] == "fp16x3" and q["train_tiles_s"] > 0 and q["infer_tiles_s"] > 0 and 0 < q["final_loss"] < 1e3
+    assert q["logits_rel_err_vs_oracle"] < 1e-4 and q["argmax_agreement_vs_oracle"] > 0.999
     assert "power" in d  # board power / shader clock of an extra untimed pass; None where rocm-smi is unavailable
     if d["power"] is not None:
         assert 50 < d["power"]["mean_w"] <= d["power"]["max_w"] <= 1.05 * (d["power"]["cap_w"] or 2000) and d["power"]["samples"] >= 1
@@ -45,6 +52,18 @@ def test_bench_rfm_workload_carries_roofline_and_cpu_baseline():
     r, c = d["roofline"], d["cpu_baseline"]
     assert r["bound"] == "mfma" and r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "stage-3" in c["sample"]
+
+
+def test_bench_reference_api_workloads():
+    """`--workload module` (stage 5 as Lightning drives the mirrors) and `--workload rfm_api` (the stage-3 train_epoch body; eager torch loss block
+    and the fused one) print the contract line, with finite losses."""
+    d = run_bench("--workload", "module", "--batch", "2", "--tile", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-power")
+    assert d["value"] > 0 and "reference API" in d["metric"] and "training_step" in d["config"]["workload"] and 0 < d["final_loss"] < 1e3
+    assert d["roofline"]["achieved"] > 0 and "api_path" not in d
+    for extra in ([], ["--fused-loss"]):
+        d = run_bench("--workload", "rfm_api", "--batch", "2", "--tile", "64", "--steps", "2", "--warmup", "1", *extra)
+        assert d["value"] > 0 and "train_epoch" in d["config"]["workload"] and ("rfm_loss_block" in d["config"]["workload"]) == bool(extra)
+        assert all(v == v and abs(v) < 1e4 for v in d["final_losses"].values())
 
 
 def test_bench_infer4_workload_runs():
