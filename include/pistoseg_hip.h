@@ -120,6 +120,13 @@ typedef struct ps_epilogue {
                                              * [M, >= C] (bf16 for PS_BF16X3, fp16 for PS_F16X3): contiguous rows for the weight gradient, which
                                              * contracts over pixels (ps_conv2d_wgrad on the plain type with x = such a copy: the x_hi dy_hi term
                                              * at the plain kernel's speed instead of a gather of every other 64 bytes) */
+  void*       sk_ws;    int64_t sk_ws_bytes;               /* optional scratch for the STREAM-K finish of a launch's partial last round (3x3 stride-1 layers
+                                             * on the halo kernel): with T tiles on #CUs compute units the last T mod #CUs tiles are cut along K into equal
+                                             * shares, one per CU; tiles that span CUs are added up through f32 slabs here, in a fixed order (bit-identical from
+                                             * run to run, same MFMA chain per element up to the split points).  >= ps_conv_sk_workspace_bytes(g, dgrad)
+                                             * bytes, 256-byte aligned, ZEROED ONCE by the caller when allocated (its first 4 KiB are arrival counters that
+                                             * every launch leaves zeroed) and used by ONE stream at a time.  NULL / too small: the launch keeps the static
+                                             * schedule (half-tile tail launch or an idle partial round). */
 } ps_epilogue;
 
 /* 1 if the MFMA implicit-GEMM path handles this geometry, else 0 (message in ps_last_error). */
@@ -137,6 +144,9 @@ enum {
   PS_CONV_HALO = 7      /* conv_igemm_halo_kernel: 3x3 stride-1, width % 28 == 0 (224x128 tile of 8 rows x 28 columns) or % 32 == 0 (256x128, 8 x 32), pixel window + halo staged once per tap row */
 };
 int ps_conv_variant(const ps_conv_geom* g, int32_t dgrad);
+/* Bytes of ps_epilogue.sk_ws with which ps_conv2d_fwd (dgrad = 0) / ps_conv2d_dgrad (dgrad = 1) finishes this geometry's partial last round by
+ * stream-K; 0 when the launch would not use it (no partial round, another kernel family, batch / queue launch options, ...). */
+int64_t ps_conv_sk_workspace_bytes(const ps_conv_geom* g, int32_t dgrad);
 /* 1 if ps_conv2d_wgrad will launch conv_wgrad_ws2_kernel (256x128 tile, persistent, wave-specialised), 0 for conv_wgrad_kernel, -1 unsupported
  * (2: conv_wgrad256_kernel, an experiment that only the debug library can select). */
 int ps_conv_wgrad_variant(const ps_conv_geom* g);

@@ -44,6 +44,7 @@ class Epilogue(C.Structure):
         ("add1", C.c_void_p), ("ldc_add1", C.c_int32), ("_pad2", C.c_int32),
         ("out", C.c_void_p), ("ldc_out", C.c_int32), ("_pad3", C.c_int32),
         ("out_hi", C.c_void_p), ("ldc_hi", C.c_int32), ("_pad4", C.c_int32),
+        ("sk_ws", C.c_void_p), ("sk_ws_bytes", C.c_int64),
     ]
 
 
@@ -82,6 +83,7 @@ PROTOTYPES = {
     "ps_device_count": (C.c_int, []),
     "ps_conv_supported": (C.c_int, [C.POINTER(ConvGeom)]),
     "ps_conv_variant": (C.c_int, [C.POINTER(ConvGeom), _I]),
+    "ps_conv_sk_workspace_bytes": (C.c_int64, [C.POINTER(ConvGeom), _I]),
     "ps_conv_wgrad_variant": (C.c_int, [C.POINTER(ConvGeom)]),
     "ps_conv2d_fwd": (C.c_int, [C.POINTER(ConvGeom), _P, _P, C.POINTER(Epilogue), _P]),
     "ps_conv2d_dgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _P, C.POINTER(Epilogue), _P]),
@@ -165,6 +167,7 @@ DEBUG_PROTOTYPES = {
     "ps_debug_set_gemm256_min_tiles": (None, [C.c_int]),
     "ps_debug_set_halo_ring": (None, [C.c_int]),
     "ps_debug_set_halo_tail": (None, [C.c_int]),
+    "ps_debug_set_halo_sk": (None, [C.c_int]),
     "ps_debug_set_s2split": (None, [C.c_int]),
     "ps_debug_set_wgrad_ws": (None, [C.c_int]),
     "ps_debug_set_wgrad_ws2": (None, [C.c_int]),

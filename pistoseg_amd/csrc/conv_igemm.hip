@@ -60,6 +60,15 @@ struct IgemmArgs {
   int m_off;                  // rows of the layer that precede this launch's row 0 (a gemm256 launch's tail rows go to a second launch on the
                               // gathered-tile kernels, with every tensor pointer advanced): only the dropout epilogue's image index needs it
   int tm0;                    // halo kernel: first pixel tile of this launch (a layer's tail tiles go to a second launch as 64-cout half tiles)
+  // conv_igemm_halo_kernel<.., SK>: the launch's partial last round is cut along K ("stream-K").  Every block first takes its sk_dp whole
+  // tiles of the static schedule (tiles [0, sk_tile0) = sk_dp whole rounds), then a contiguous share of the sk_lines = (ntiles - sk_tile0) * klines
+  // K-lines of the remaining tiles: block s (XCD-remapped id) owns lines [sk_lines * s / nb, sk_lines * (s + 1) / nb).  A tile whose lines are spread
+  // over several blocks is finished by the block whose part arrives LAST: parts go to f32 slabs (write-through stores), arrivals are counted per
+  // (tile, consumer wave), the last arriver adds the parts up in part order -- bit-identical from run to run -- and runs the epilogue.
+  int sk_dp, sk_tile0, sk_lines, sk_maxparts;
+  float* sk_slabs;            // [tile - sk_tile0][part < sk_maxparts][consumer wave][MI * WI fragments][64 lanes] float4
+  unsigned* sk_cnt;           // [tile - sk_tile0][consumer wave] arrival counters, zeroed by the host in front of the launch
+  unsigned sk_slab_bytes;     // extent of sk_slabs (buffer descriptor)
   ps_epilogue epi;
 };
 
@@ -1890,8 +1899,12 @@ __device__ unsigned long long g_halo_stamps[256 * 4 * 6];  // [block][consumer w
 // dispatcher sends one-K-line problems to the static kernel); the loaders' cursors cross into tile s + 1 from K-step nst - 6 on.  As LATE as that
 // allows on purpose: collecting the ticket is a vmcnt(0) in a wave whose memory queue still holds the previous tile's epilogue stores, and while
 // the memory system is busy those take microseconds (collected at K-step 8 the queue cost 2-6 % on the 3x3 layers of a training step).
-template <typename Tr, int TW, int NW = 3, int WI = 4, bool Q = false>  // TW = 28 (maps of 224-pixel tiles: 28 / 56 / 112 wide) or 32 (256-pixel tiles: 32 / 64 / 128 wide); NW = weight ring depth
+// SK: stream-K over the partial last round (IgemmArgs::sk_*).  A block's work is a list of ITEMS (tile, K-lines [kl0, kl1)): its sk_dp whole tiles,
+// then the pieces of its K-line share -- the three cursors (windows, weights, consumers) walk the same list; a piece that is not a whole tile ends
+// in the slab hand-off instead of the epilogue.
+template <typename Tr, int TW, int NW = 3, int WI = 4, bool Q = false, bool SK = false>  // TW = 28 (maps of 224-pixel tiles: 28 / 56 / 112 wide) or 32 (256-pixel tiles: 32 / 64 / 128 wide); NW = weight ring depth
 __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs a) {
+  static_assert(!(Q && SK), "stream-K runs on the static schedule");
   typedef typename Tr::elem T [[maybe_unused]];
   static_assert(TW == 28 || TW == 32, "tile width");
   static_assert(WI == 4 || WI == 2, "cout fragments per wave");
@@ -1923,12 +1936,38 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
   } else {
     ps_block_items(blockIdx.x, gridDim.x, a.ntm * a.ntn, a.nb, a.tpb, first, G, ntiles);
   }
+  // SK: this block's item list (wave-uniform scalars).  sblk = its stream-K index: blocks that share an XCD get consecutive indices, i.e.
+  // neighbouring K-line shares -- the parts of one tile then mostly meet in one L2 (speed only)
+  [[maybe_unused]] int sk_g0 = 0, sk_g1 = 0, sk_nitems = 0, sk_mylines = 0;
+  [[maybe_unused]] const int sblk = SK ? first : 0;  // (ps_block_items: first = ps_xcd_remap(blockIdx.x, gridDim.x) under tpb = 0, grid = nb)
+  if constexpr (SK) {
+    sk_g0 = (int)((long long)a.sk_lines * sblk / a.nb);
+    sk_g1 = (int)((long long)a.sk_lines * (sblk + 1) / a.nb);
+    sk_nitems = a.sk_dp + (sk_g1 > sk_g0 ? (sk_g1 - 1) / a.klines - sk_g0 / a.klines + 1 : 0);
+    sk_mylines = a.sk_dp * a.klines + (sk_g1 - sk_g0);
+    if (sk_nitems == 0) return;  // (fewer K-lines than blocks)
+  }
+  [[maybe_unused]] auto sk_item = [&](int i, int& tile, int& kl0, int& kl1) {  // item i of this block
+    if (i < a.sk_dp) {
+      tile = first + i * G;
+      kl0 = 0;
+      kl1 = a.klines;
+      return;
+    }
+    const int j = i - a.sk_dp;
+    const int line = j == 0 ? sk_g0 : (sk_g0 / a.klines + j) * a.klines;
+    const int tl = line / a.klines;
+    tile = a.sk_tile0 + tl;
+    kl0 = line - tl * a.klines;
+    const int rest = sk_g1 - line;
+    kl1 = kl0 + rest < a.klines ? kl0 + rest : a.klines;
+  };
   const int nwin = 3 * a.klines;             // windows (K-line, ty) per tile, three K-steps each
   const int my_tiles = Q ? 1 : (ntiles - first + G - 1) / G;
   // Q: the loaders' three countdowns (windows, weight steps, consumed steps) count what is KNOWN to exist -- the first tile, plus one tile
   // every time the window cursor learns from the mailbox that there is a next one -- so every test below reads the same in both modes (and
   // hipcc proves the same things about them: the steady-state path must stay free of per-issue end tests)
-  const int total_steps = Q ? nwin * 3 : my_tiles * nwin * 3;
+  const int total_steps = SK ? sk_mylines * 9 : Q ? nwin * 3 : my_tiles * nwin * 3;
   [[maybe_unused]] const unsigned mbox = ps_q_mbox_addr(smem + MB_OFF);
   const int H = a.Hs, W = a.Ws, NH = a.M / W;  // stride 1: produced grid == source grid; NH = global rows n*H + p
   const int ncb = W / TW;                    // column blocks per row (W is a multiple of TW)
@@ -1959,12 +1998,17 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
     // --- cursor of the next WINDOW to stage: (tile, K-line, ty).  Window row wr of tap row ty serves exactly ONE produced row,
     // global row R0 + wr: it holds source row p + (ty-1)*dstep of the SAME image, or zeros (vertical padding; produced rows
     // past the tensor's end; rows that would come from the neighbouring image when a tile straddles two images).
-    int a_tile = first, a_kl = 0, a_ty = 0, a_buf = 0, a_left = Q ? nwin : my_tiles * nwin;
+    int a_tile = first, a_kl = 0, a_ty = 0, a_buf = 0, a_left = SK ? sk_mylines * 3 : Q ? nwin : my_tiles * nwin;
+    [[maybe_unused]] int a_item = 0, a_kl_end = a.klines, b_item = 0, b_kl_end = a.klines;  // SK: item cursors of the window / weight streams
     // Q: the cursors cross a tile boundary in the order windows (K-step nst - 6), weights (nst - NW), and the windows do not cross the next one
     // before the weights have crossed this one: ONE mailbox read per tile, handed down in a register
     [[maybe_unused]] int a_seq = 0, q_next = -1;
     int c_left = total_steps;  // consumed steps left (Q: that are known of)
     int b_tile = first, b_kl = 0, b_tap = 0, b_slot = 0, b_left = total_steps;  // cursor of the next WEIGHT tile to stage (see below)
+    if constexpr (SK) {
+      sk_item(0, a_tile, a_kl, a_kl_end);
+      b_tile = a_tile, b_kl = a_kl, b_kl_end = a_kl_end;
+    }
     int a_R0 = 0, a_X0 = 0, prow = 0;  // prow: image row p of the produced row this lane's window row serves (per tile)
     auto window_tile_setup = [&](int tile) {
       int tm, tn;
@@ -1993,6 +2037,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
       a_buf ^= 1;
       if (++a_ty == 3) {
         a_ty = 0;
+        if constexpr (SK) {
+          if (++a_kl == a_kl_end && a_left) {
+            sk_item(++a_item, a_tile, a_kl, a_kl_end);
+            window_tile_setup(a_tile);
+          }
+        } else
         if (++a_kl == a.klines) {
           a_kl = 0;
           if constexpr (Q) {
@@ -2038,6 +2088,12 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
       b_slot = (b_slot == NW - 1) ? 0 : b_slot + 1;
       if (++b_tap == 9) {
         b_tap = 0;
+        if constexpr (SK) {
+          if (++b_kl == b_kl_end && b_left) {
+            sk_item(++b_item, b_tile, b_kl, b_kl_end);
+            weights_setup(b_tile);
+          }
+        } else
         if (++b_kl == a.klines) {
           b_kl = 0;
           if constexpr (Q) {
@@ -2165,7 +2221,11 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
   const unsigned long long st_c0 = st_prev, st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
   [[maybe_unused]] int q_seq = 0;
-  for (int tile = first; Q ? tile >= 0 : tile < ntiles; tile = Q ? ps_q_mbox_read(mbox, ++q_seq) : tile + G) {
+  [[maybe_unused]] int sk_i = 0, kl0 = 0, kl1 = a.klines;  // SK: the consumers' item cursor
+  int tile = first;
+  if constexpr (SK) sk_item(0, tile, kl0, kl1);
+  for (; SK ? sk_i < sk_nitems : (Q ? tile >= 0 : tile < ntiles);) {
+    const int nst = SK ? 9 * (kl1 - kl0) : 3 * nwin;  // K-steps of this item
     if constexpr (Q) {
 #ifndef PS_Q_STATIC_TICKETS  // (diagnostic build: the queue's code paths fed with the static schedule -- no atomics; what the restructuring alone costs)
       if (wave == 0) ps_q_draw_begin(a.queue, blockIdx.x & 7, lane, q_peek, q_tk);  // the ticket of this block's tile q_seq + 1: in flight until K-step nst - 7
@@ -2283,7 +2343,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
     // first K-step of the tile peeled (no previous MFMAs to overlap its reads with), then tx = 1, 2, 0, 1, 2, ...
     kstep(0, true);
     int tx = 1;
-    for (int s = 1; s < 3 * nwin; ++s) {
+    for (int s = 1; s < nst; ++s) {
       if constexpr (Q) {
 #ifdef PS_Q_STATIC_TICKETS
         if (s == 3 * nwin - 7 && wave == 0) ps_q_mbox_write(mbox, q_seq + 1, tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : -1);
@@ -2313,10 +2373,93 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
     ps_tile_of_block(tile, a.ntn, a.ntm, tm, tn, a.supertile);
       tm += a.tm0;
     const int rb = tm / ncb;
-    conv_epilogue<typename Tr::epi, MI, WI, 1>(a, acc, rb * TR * W + (tm - rb * ncb) * TW + wm * (TW / 2), tn * BN + wn * WN, lane);
+    bool finish = true;  // whether this wave runs the tile's epilogue
+    if constexpr (SK) {
+      if (kl1 - kl0 < a.klines) {
+        // A PART of a tile: hand the wave's accumulators over.  Slab stores are write-through (sc1: they leave this XCD's L2, no release
+        // fence needed), drained by this wave's vmcnt(0); then ONE agent-scope add on the (tile, wave) arrival counter.  The wave whose
+        // add returns nparts - 1 came last: every other part is complete in memory, it reads them with sc1 loads (L2-served, never this
+        // CU's L1: MI355X_MICROARCH.md, inter-workgroup visibility) IN PART ORDER and finishes the tile.
+        const int tl = tile - a.sk_tile0, x0 = tl * a.klines, x1 = x0 + a.klines - 1;
+        const int bfirst = (int)((((long long)x0 + 1) * a.nb - 1) / a.sk_lines), blast = (int)((((long long)x1 + 1) * a.nb - 1) / a.sk_lines);
+        const int nparts = blast - bfirst + 1, part = sblk - bfirst;
+        const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)a.sk_slabs, 0, (int)a.sk_slab_bytes, 0x00020000);
+        constexpr int SLAB = MI * WI * 1024;  // bytes per (part, wave)
+        const int tbase = tl * a.sk_maxparts * 4 * SLAB + wave * SLAB + lane * 16;
+        const int mine = tbase + part * 4 * SLAB;
+        // The owner of a tile's HEAD part (kl0 == 0) reaches it as the LAST item of its share, the owners of the later parts reach theirs first
+        // (at most a whole share earlier): it usually finds every other part complete.  One look at the counter then saves its own slab --
+        // a third of the exchange's bytes, which is what the exchange costs (all CUs hand over within the same few microseconds).
+        bool skip_store = false;
+        if (kl0 == 0) {
+          unsigned seen = 0;
+          if (lane == 0) seen = __hip_atomic_load(a.sk_cnt + tl * 4 + wave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          skip_store = (int)__builtin_amdgcn_readfirstlane((int)seen) == nparts - 1;  // every other part has drained its stores and counted itself
+        }
+        unsigned old = (unsigned)(nparts - 1);
+        if (!skip_store) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int i = 0; i < WI; ++i)
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[mi][i]), rsS, mine + (mi * WI + i) * 1024, 0, 16);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          old = 0;
+          if (lane == 0) old = __hip_atomic_fetch_add(a.sk_cnt + tl * 4 + wave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+        }
+        finish = (int)old == nparts - 1;
+        if (finish) {
+          if (lane == 0) __hip_atomic_store(a.sk_cnt + tl * 4 + wave, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the stream's next launch
+          // the sum in part order 0, 1, ...: with two parts a + b is the same either way round (own part stays in registers); with more the
+          // own part is re-read from its slab in its place, so that the result does not depend on who came last
+          // the sum in part order 0, 1, ...: the head part (part 0: this wave's own whenever it skipped its store) comes first, so the own
+          // accumulators are the running sum's start; otherwise the own part sits at `part` and is re-read from its slab in its place -- the
+          // result never depends on who came last.  (Two parts: a + b either way round.)
+          if (nparts == 2 || part == 0) {
+            for (int pp = 0; pp < nparts; ++pp) {
+              if (pp == part) continue;
+              const int src = tbase + pp * 4 * SLAB;
+#pragma unroll
+              for (int mi = 0; mi < MI; ++mi) {
+                u32x4 t[WI];
+#pragma unroll
+                for (int i = 0; i < WI; ++i) t[i] = __builtin_amdgcn_raw_buffer_load_b128(rsS, src + (mi * WI + i) * 1024, 0, 16);
+#pragma unroll
+                for (int i = 0; i < WI; ++i) acc[mi][i] += __builtin_bit_cast(f32x4, t[i]);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+              for (int i = 0; i < WI; ++i) acc[mi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int pp = 0; pp < nparts; ++pp) {
+              const int src = tbase + pp * 4 * SLAB;
+#pragma unroll
+              for (int mi = 0; mi < MI; ++mi) {
+                u32x4 t[WI];
+#pragma unroll
+                for (int i = 0; i < WI; ++i) t[i] = __builtin_amdgcn_raw_buffer_load_b128(rsS, src + (mi * WI + i) * 1024, 0, 16);
+#pragma unroll
+                for (int i = 0; i < WI; ++i) acc[mi][i] += __builtin_bit_cast(f32x4, t[i]);
+              }
+            }
+          }
+        }
+      }
+    }
+    if (finish) conv_epilogue<typename Tr::epi, MI, WI, 1>(a, acc, rb * TR * W + (tm - rb * ncb) * TW + wm * (TW / 2), tn * BN + wn * WN, lane);
 #ifdef PS_HALO_STAMPS
     PS_STAMP(st_prev);  // the epilogue is not part of segment 0 of the next tile's first step
 #endif
+    if constexpr (SK) {
+      if (++sk_i < sk_nitems) sk_item(sk_i, tile, kl0, kl1);
+    } else if constexpr (Q) {
+      tile = ps_q_mbox_read(mbox, ++q_seq);
+    } else {
+      tile += G;
+    }
   }
   if constexpr (Q) {
 #ifndef PS_Q_STATIC_TICKETS
@@ -2517,6 +2660,10 @@ PS_TUNABLE g_use_pp = 0;       // experimental ping-pong kernel (correct, slower
 PS_TUNABLE g_use_ws = 1;       // wave-specialised (loader/consumer) kernel for big problems
 PS_TUNABLE g_use_ws2 = 1;
 PS_TUNABLE g_use_halo = 1;     // window + halo staging for 3x3 stride-1 layers (width a multiple of 28): 0 off, 1 for big 16-bit problems, 2 forced      // large-tile wave-specialised kernel: 0 off, 1 by cost model, 256 / 224 force that pixel tile
+#ifndef PS_HALO_SK
+#define PS_HALO_SK 2  // (A/B builds: -DPS_HALO_SK=0|1)
+#endif
+PS_TUNABLE g_halo_sk = PS_HALO_SK;  // halo kernel: stream-K finish of a partial last round (needs ps_epilogue.sk_ws): 0 off, 1 on unless gpu_shared, 2 on
 PS_TUNABLE g_halo_tail = 1;   // halo kernel: a partial last round (<= half the CUs) as a second launch of 64-cout half tiles: 0 off, 1 on
 PS_TUNABLE g_halo_ring = 3;   // weight ring depth of the halo kernel (3 | 4 | 5 stages of 16 KiB; 256-pixel tiles: <= 4)
 PS_TUNABLE g_gemm256 = 1;      // 256 x 256 tile kernel for the plain GEMMs (1x1 stride-1, 16-bit): 0 off, 1 by shape, 2 whenever legal
@@ -2633,6 +2780,36 @@ int set_extents(IgemmArgs& a, long long src_bytes, long long wgt_bytes, int es) 
 static int usable_cus(int reserved) {
   const int n = ps_num_cus();
   return reserved <= 0 ? n : (n - reserved > n / 4 ? n - reserved : n / 4);
+}
+
+// Stream-K plan of a halo launch: T tiles of `klines` K-lines on nb CUs.  full = whole rounds that stay data-parallel, R = tiles of the partial
+// round, cut into nb equal K-line shares.  Off (on = false) when there is no partial round, when the round is nearly full (nothing to win against
+// the slab traffic), or when a tile would be spread over more than 8 blocks (tiny R: the half-tile tail launch serves those).
+struct SkPlan {
+  bool on;
+  int full, R, lines, maxparts;
+  long long ws_bytes;
+};
+constexpr long long kSkCounterBytes = 4096;
+static SkPlan halo_sk_plan(long long T, int nb, int klines, int slab_bytes_per_part) {
+  SkPlan p{false, 0, 0, 0, 0, 0};
+  if (nb <= 0 || klines <= 0) return p;
+  p.full = (int)(T / nb);
+  p.R = (int)(T % nb);
+  p.lines = p.R * klines;
+  // lines < 4 nb: a share of fewer than four K-lines (36 K-steps) does not pay for the slab exchange -- measured per layer, profiles/r05c_convbench_stream_k.txt:
+  // shares of 2 lines lose 2-6 %, of 4-6 lines win 0-1.5 %, of 8-12 lines win 3-7 %.  (And every block must own at least one line: the part numbering.)
+  if (p.R == 0 || p.R * 100LL > nb * 92LL || p.R > 1000 || p.lines < 4LL * nb) return p;
+  for (int t = 0; t < p.R; ++t) {  // (the kernel's own formula for the blocks a tile is spread over)
+    const long long x0 = (long long)t * klines, x1 = x0 + klines - 1;
+    const int parts = (int)(((x1 + 1) * nb - 1) / p.lines) - (int)(((x0 + 1) * nb - 1) / p.lines) + 1;
+    p.maxparts = parts > p.maxparts ? parts : p.maxparts;
+  }
+  if (p.maxparts > 8) return p;
+  p.ws_bytes = kSkCounterBytes + (long long)p.R * p.maxparts * slab_bytes_per_part;
+  if (p.ws_bytes >= (1LL << 31)) return p;
+  p.on = true;
+  return p;
 }
 
 static int halo_tile_width(int w) { return (w <= 0 || w > 256) ? 0 : (w % 28 == 0 ? 28 : (w % 32 == 0 ? 32 : 0)); }
@@ -2760,6 +2937,27 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s, bool allow_gemm256 = true) {
       // as 2 R half tiles of 64 couts (half the MFMAs, 8 instead of 16 KiB of weights per K-step: ~0.6 of a round on every CU).
       // Not while another stream of the process shares the GPU (gpu_shared: the two-stream backward): its blocks take the idle CUs, and the
       // split then COSTS 2 % of a training step (profiles/r03_tail_split_two_streams.txt).
+      // Stream-K finish of the partial round (ps_epilogue.sk_ws given): one launch, every CU busy to the end.
+      if constexpr (sizeof(typename Tr::elem) == 2) {
+        if (g_halo_sk && (g_halo_sk == 2 || !a.shared) && a.tpb == 0 && !a.use_queue && a.epi.sk_ws) {
+          const int slab = (tw == 28 ? 7 : 8) * 4 * 1024 * 4;  // MI x WI fragments x 1 KiB x 4 consumer waves
+          const SkPlan p = halo_sk_plan((long long)b.ntm * b.ntn, b.nb, a.klines, slab);
+          if (p.on && a.epi.sk_ws_bytes >= p.ws_bytes && (reinterpret_cast<uintptr_t>(a.epi.sk_ws) & 255u) == 0) {
+            b.sk_dp = p.full;
+            b.sk_tile0 = p.full * b.nb;
+            b.sk_lines = p.lines;
+            b.sk_maxparts = p.maxparts;
+            b.sk_cnt = static_cast<unsigned*>(a.epi.sk_ws);
+            b.sk_slabs = reinterpret_cast<float*>(static_cast<unsigned char*>(a.epi.sk_ws) + kSkCounterBytes);
+            b.sk_slab_bytes = (unsigned)(p.ws_bytes - kSkCounterBytes);
+            const dim3 sgrid((unsigned)b.nb);
+            if (tw == 28) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 3, 4, false, true>), sgrid, dim3(512), 2 * 9 * 4096 + 3 * 16384, s, b);
+            else hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32, 3, 4, false, true>), sgrid, dim3(512), 2 * 10 * 4096 + 3 * 16384, s, b);
+            PS_CHECK_LAUNCH("conv_igemm_halo<stream-K>");
+            return PS_OK;
+          }
+        }
+      }
       int tail_ptiles = 0;
       if constexpr (sizeof(typename Tr::elem) == 2) {
         const long long T = (long long)b.ntm * b.ntn, R = T % b.nb;
@@ -2915,10 +3113,11 @@ extern "C" int ps_debug_read_stamps(unsigned long long* host_out) {  // 256 x 4 
 #endif
 extern "C" void ps_debug_set_halo_ring(int v) { g_halo_ring = v; }
 extern "C" void ps_debug_set_halo_tail(int v) { g_halo_tail = v; }
+extern "C" void ps_debug_set_halo_sk(int v) { g_halo_sk = v; }
 extern "C" void ps_debug_set_supertile(int v) { g_supertile = v; }
 // every tunable of this translation unit back to its default (one list, next to the definitions: the tools call ps_debug_reset())
 void ps_debug_reset_igemm(void) {
-  g_use_glds = 2; g_use_pp = 0; g_use_ws = 1; g_use_ws2 = 1; g_use_halo = 1; g_halo_tail = 1; g_halo_ring = 3; g_gemm256 = 1;
+  g_use_glds = 2; g_use_pp = 0; g_use_ws = 1; g_use_ws2 = 1; g_use_halo = 1; g_halo_sk = PS_HALO_SK; g_halo_tail = 1; g_halo_ring = 3; g_gemm256 = 1;
   g_gemm256_min_klines = 32; g_gemm256_min_cd = 1024; g_gemm256_min_tiles = 0; g_gemm256_tail = 1; g_use_3stage = 0; g_ablate = 0;
   g_supertile = 4; g_force_bm = 0; g_force_bn = 0; g_s2split = 1;
 }
@@ -2939,6 +3138,18 @@ extern "C" int ps_conv_variant(const ps_conv_geom* g, int32_t dgrad) {
   const bool halo_ok = g->ksize == 3 && g->stride == 1 && halo_tile_width(g->w) != 0 && g->dilation <= 4;
   const int v = pick_ws_variant(M, dgrad ? g->cin : g->cout, ps_esize(g->dtype), halo_ok);
   return v ? v : PS_CONV_4WAVE;
+}
+
+extern "C" int64_t ps_conv_sk_workspace_bytes(const ps_conv_geom* g, int32_t dgrad) {
+  if (!g || check_geom(g) != PS_OK || !g_halo_sk || ps_esize(g->dtype) != 2 || g->tiles_per_block != 0 || g->tile_queue != 0) return 0;
+  if (g_halo_sk != 2 && g->gpu_shared) return 0;
+  if (ps_conv_variant(g, dgrad) != PS_CONV_HALO) return 0;
+  const int tw = halo_tile_width(g->w);
+  const long long M = (long long)g->n * g->h * g->w;  // stride 1: both directions produce on the input grid
+  const long long ntm = (M / g->w + 7) / 8 * (g->w / tw), ntn = (dgrad ? g->cin : g->cout) / 128;
+  const int klines = ps_planes(g->dtype) * (dgrad ? g->cout : g->cin) * 2 / 128;
+  const SkPlan p = halo_sk_plan(ntm * ntn, usable_cus(g->cus_reserved), klines, (tw == 28 ? 7 : 8) * 4 * 1024 * 4);
+  return p.on ? p.ws_bytes : 0;
 }
 
 // ---- 1x1 conv + BN + ReLU + narrow head in one launch (inference) ------------------------------------------------------------------

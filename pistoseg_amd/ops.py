@@ -7,6 +7,7 @@ tensors (f32 or bf16) that may be channel slices of wider buffers (`stride(2)` =
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -162,6 +163,29 @@ def _hi_of(t: Optional[Tensor]) -> Optional[Tensor]:
     return getattr(t, "_ps_hi", None) if t is not None else None
 
 
+# Scratch of the stream-K finish (ps_epilogue.sk_ws): one grow-only ZEROED buffer per (device, stream) -- the launches of a stream run in order and
+# every launch leaves its arrival counters zeroed.  Sizes per geometry are asked of the library once and remembered.
+_SK_WS: dict = {}
+_SK_NEED: dict = {}
+STREAM_K = os.environ.get("PISTOSEG_STREAM_K", "1") != "0"  # module switch (tools' A/Bs, PISTOSEG_STREAM_K=0): False = never hand a workspace to the conv launches
+
+
+def _sk_workspace(g: ConvGeom, dgrad: bool, device):
+    if not STREAM_K:
+        return None
+    key = (g.dtype, g.n, g.h, g.w, g.cin, g.cout, g.ksize, g.stride, g.dilation, g.tiles_per_block, g.gpu_shared, g.cus_reserved, g.tile_queue, dgrad)
+    need = _SK_NEED.get(key)
+    if need is None:
+        need = _SK_NEED[key] = int(_lib.load().ps_conv_sk_workspace_bytes(C.byref(g), 1 if dgrad else 0)) if g.ksize == 3 and g.stride == 1 else 0
+    if need <= 0:
+        return None
+    wkey = (device, _stream())
+    ws = _SK_WS.get(wkey)
+    if ws is None or ws.numel() < need:
+        ws = _SK_WS[wkey] = torch.zeros(max(need, 64 << 20), device=device, dtype=torch.uint8)  # (allocated on, and zeroed by, the launch stream)
+    return ws
+
+
 def _epilogue(mode=PS_EPI_NONE, add0=None, out_raw=None, scale=None, shift=None, drop=None, mask_src=None, add1=None, out=None, out_hi=None) -> Epilogue:
     e = Epilogue()
     e.mode = mode
@@ -193,6 +217,9 @@ def conv2d_fwd(spec: ConvSpec, x: Tensor, w_fwd: Tensor, *, add0=None, out_raw=N
     ref = out_act if out_act is not None else out_raw
     g = _geom(spec, _conv_dt(x, split), n, h, w, _ldc(x), _ldc(ref), opts)
     e = _epilogue(mode, add0=add0, out_raw=out_raw, scale=bn_scale, shift=bn_shift, drop=drop, out=out_act, out_hi=_hi_of(out_act) if split else None)
+    ws = _sk_workspace(g, False, x.device)
+    if ws is not None:
+        e.sk_ws, e.sk_ws_bytes = ws.data_ptr(), ws.numel()
     lib = _lib.load()
     ho, wo = spec.out_hw(h, w)
     m = n * ho * wo
@@ -211,6 +238,9 @@ def conv2d_dgrad(spec: ConvSpec, dy: Tensor, w_dgrad: Tensor, x_hw, *, add0=None
     ref = out if out is not None else out_raw
     g = _geom(spec, _conv_dt(dy, split), n, h, w, _ldc(ref), _ldc(dy), opts)
     e = _epilogue(mode, add0=add0, out_raw=out_raw, scale=bn_scale, drop=drop, mask_src=mask_src, add1=add1, out=out, out_hi=_hi_of(out) if split else None)
+    ws = _sk_workspace(g, True, dy.device)
+    if ws is not None:
+        e.sk_ws, e.sk_ws_bytes = ws.data_ptr(), ws.numel()
     lib = _lib.load()
     mo = n * dy.shape[1] * dy.shape[2]
     _launch(_conv_label("dgrad", g) if PROFILE is not None else "", 2.0 * mo * spec.cout * spec.cin * spec.ksize**2,
@@ -285,6 +315,7 @@ def release_workspaces() -> None:
     _WGRAD_WS.clear()
     _fc8_ws.clear()
     _HEAD_WS.clear()
+    _SK_WS.clear()
 
 
 def conv2d_wgrad(spec: ConvSpec, x: Tensor, dy: Tensor, dw: Tensor, deterministic: Optional[bool] = None, split: bool = False,

@@ -1222,6 +1222,15 @@ def test_conv_halo_tail_as_half_tiles(case, dtype, library):
         return out_raw, out_act, gx
 
     assert conv_variant(spec, dtype, n, h, w, "fwd") == V_HALO and conv_variant(spec_t, dtype, n, h, w, "dgrad") == V_HALO
+    stream_k_before, ops.STREAM_K = ops.STREAM_K, False  # (this test is about the static schedule's tail launch; stream-K: test_conv_halo_stream_k)
+    request_finalizer = lambda: setattr(ops, "STREAM_K", stream_k_before)  # noqa: E731
+    try:
+        _halo_tail_body(lib, ops, library, run, y, res, act, gx_ref, dtype)
+    finally:
+        request_finalizer()
+
+
+def _halo_tail_body(lib, ops, library, run, y, res, act, gx_ref, dtype):
     if library == "debug":
         try:
             lib.ps_debug_set_halo_tail(1)
@@ -1246,6 +1255,77 @@ def test_conv_halo_tail_as_half_tiles(case, dtype, library):
     tol = TOL[dtype]
     for a_, r_ in zip(split[0], (nhwc((y + res).detach()), nhwc(act.detach()), nhwc(gx_ref))):
         assert rel_err(a_.float().cpu(), r_) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [
+    # (n, h, w, cin, cout, d, reserved CUs, stream-K expected): T tiles on nb CUs -> whole rounds + a partial round of R tiles cut along K into nb shares
+    # (shares of >= 4 K-lines only: the library's rule, measured in profiles/r05c_convbench_stream_k.txt)
+    (32, 28, 28, 512, 512, 1, 0, True),    # BASELINE configs[3]'s per-GPU layer: 448 tiles = 1 round + 192; 8 K-lines -> shares of 6 lines, two parts per tile
+    (24, 28, 28, 1024, 512, 2, 0, True),   # 336 = 256 + 80; 16 K-lines -> shares of 5 lines, tiles in 3-5 parts (the ordered re-sum path)
+    (20, 32, 32, 1024, 512, 4, 0, True),   # 256-pixel tiles: 320 = 256 + 64; shares of exactly 4 lines, 4 parts per tile
+    (32, 28, 28, 128, 512, 1, 0, False),   # 448 tiles of 2 K-lines: shares of 1.5 lines -- not worth the exchange, the static schedule stays
+    (32, 28, 28, 512, 512, 1, 32, False),  # 448 tiles beside a collective that holds 32 CUs (ps_conv_geom.cus_reserved): 2 x 224, whole rounds, nothing to cut
+    (30, 28, 28, 512, 512, 2, 32, True),   # 420 = 224 + 196 on 224 CUs: shares of 7 lines
+])
+def test_conv_halo_stream_k(case, dtype):
+    """Stream-K finish of the halo kernel's partial last round (ps_epilogue.sk_ws): forward with the full epilogue (residual, raw + BN/ReLU outputs)
+    and data gradient against the CPU, bit-identical from run to run (fixed part order), and equal to the static schedule up to the f32
+    re-association at the split points (the partial sums are f32; the stored 16-bit values almost always round the same)."""
+    import ctypes
+
+    from pistoseg_amd import _lib, ops
+
+    n, h, w, cin, cout, d, reserved, expect_sk = case
+    g = torch.Generator().manual_seed(h + cin + cout + d + n)
+    q = quant(dtype)
+    x = q(torch.randn(n, cin, h, w, generator=g))
+    wt = q(torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5)
+    y = F.conv2d(x, wt, padding=d, dilation=d)
+    res = q(torch.randn(y.shape, generator=g))
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    act = F.relu((y + res) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    spec = ops.ConvSpec(cin, cout, 3, 1, d)
+    D = dev()
+    xd, wf = nhwc(x).to(D, dtype), w_fwd_layout(wt).to(D, dtype)
+    resd = nhwc(res).to(D, dtype)
+    gy = q(torch.randn(n, cin, h, w, generator=g))
+    wt_t = q(torch.randn(cin, cout, 3, 3, generator=g) * 0.05)  # conv cout -> cin; its dgrad produces cout channels
+    gx_ref = torch.nn.grad.conv2d_input((n, cout, h, w), wt_t, gy, padding=d, dilation=d)
+    spec_t = ops.ConvSpec(cout, cin, 3, 1, d)
+    gyd, wdt = nhwc(gy).to(D, dtype), w_dgrad_layout(wt_t).to(D, dtype)
+
+    def run():
+        out_raw = torch.full((n, h, w, cout), float("nan"), device=D, dtype=dtype)
+        out_act = torch.full((n, h, w, cout), float("nan"), device=D, dtype=dtype)
+        ops.conv2d_fwd(spec, xd, wf, add0=resd, out_raw=out_raw, bn_scale=scale.to(D), bn_shift=shift.to(D), out_act=out_act)
+        gx = torch.full((n, h, w, cout), float("nan"), device=D, dtype=dtype)
+        ops.conv2d_dgrad(spec_t, gyd, wdt, (h, w), out_raw=gx)
+        return out_raw, out_act, gx
+
+    assert conv_variant(spec, dtype, n, h, w, "fwd") == V_HALO and conv_variant(spec_t, dtype, n, h, w, "dgrad") == V_HALO
+    before = (ops.STREAM_K, ops.CUS_RESERVED)
+    try:
+        ops.CUS_RESERVED = reserved
+        geom = ops._geom(spec, ops._dt(xd), n, h, w, cin, cout)
+        need = int(_lib.load().ps_conv_sk_workspace_bytes(ctypes.byref(geom), 0))
+        assert (need > 0) == expect_sk, need  # (the library's own plan for this geometry)
+        ops.STREAM_K = True
+        sk = [run() for _ in range(3)]
+        ops.STREAM_K = False
+        static = run()
+    finally:
+        ops.STREAM_K, ops.CUS_RESERVED = before
+    for other in sk[1:]:
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(sk[0], other))  # deterministic: parts are added in part order, whoever arrives last
+    tol = TOL[dtype]
+    for a_, s_, r_ in zip(sk[0], static, (nhwc((y + res).detach()), nhwc(act.detach()), nhwc(gx_ref))):
+        assert rel_err(a_.float().cpu(), r_) < tol
+        diff = (a_.float() - s_.float()).abs()
+        # the same products, summed in f32 with different association at <= 7 split points: a few 16-bit roundings flip by one ulp
+        assert float(diff.max()) <= 2.0 ** (-7 if dtype == torch.bfloat16 else -10) * float(s_.float().abs().max()) and float((diff > 0).float().mean()) < 2e-2
+        if need == 0:
+            assert torch.equal(a_, s_)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
