@@ -1688,6 +1688,22 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const IgemmArgs a)
   auto mma_quadrant = [&](int msub, int nsub, const u32x4 (&w)[2][2], auto mid) {
     if constexpr (PS_GEMM256_PRIO == 1) __builtin_amdgcn_s_setprio(1);
     if constexpr (PS_GEMM256_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+    if constexpr (Tr::split) {
+      // split types: the K-tile's two 64-byte halves are the hi and the lo fragments of the same 32 logical channels (bf16x3_t) -- three MFMA
+      // groups on the registers the plain loop holds anyway: x_hi w_hi, x_hi w_lo, x_lo w_hi (24 MFMAs per quadrant instead of 16)
+#pragma unroll
+      for (int grp3 = 0; grp3 < 3; ++grp3) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) Tr::mma(w[i][grp3 == 1 ? 1 : 0], xf[j][grp3 == 2 ? 1 : 0], acc[4 * msub + j][2 * nsub + i]);
+        if (grp3 == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          mid();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
 #pragma unroll
@@ -1699,6 +1715,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const IgemmArgs a)
         mid();
         __builtin_amdgcn_sched_barrier(0);
       }
+    }
     }
     if constexpr (PS_GEMM256_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     if constexpr (PS_GEMM256_PRIO == 2) __builtin_amdgcn_s_setprio(1);
@@ -1783,15 +1800,18 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const IgemmArgs a)
   // 4t + 1 and re-staged by G0 in 4t + 2: G1 retires those four reads (issued FIRST: lgkmcnt(8)) before its barrier.
   auto mma_half = [&](int msub, const u32x4 (&w0)[2][2], const u32x4 (&w1)[2][2]) {
     __builtin_amdgcn_s_setprio(1);
+    constexpr int NG = Tr::split ? 3 : 2;  // (split: hi.hi, x_hi w_lo, x_lo w_hi -- see mma_quadrant)
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
+    for (int kg = 0; kg < NG; ++kg) {
+      const int wk = Tr::split ? (kg == 1 ? 1 : 0) : kg, xk = Tr::split ? (kg == 2 ? 1 : 0) : kg;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) Tr::mma(w0[i][kh], xf[j][kh], acc[4 * msub + j][i]);
+        for (int i = 0; i < 2; ++i) Tr::mma(w0[i][wk], xf[j][xk], acc[4 * msub + j][i]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) Tr::mma(w1[i][kh], xf[j][kh], acc[4 * msub + j][2 + i]);
+        for (int i = 0; i < 2; ++i) Tr::mma(w1[i][wk], xf[j][xk], acc[4 * msub + j][2 + i]);
       }
+    }
     __builtin_amdgcn_s_setprio(0);
   };
   auto end_load4 = [&](bool staged, bool drain_first4) {
@@ -2850,11 +2870,11 @@ static bool use_gemm256(long long M, int Cd, int esize, int taps, int mul, int d
 
 template <typename Tr>
 int dispatch_bn(const IgemmArgs& a, hipStream_t s, bool allow_gemm256 = true) {
-  if constexpr (sizeof(typename Tr::elem) == 2 && !Tr::split) {
+  if constexpr (sizeof(typename Tr::elem) == 2) {
     // (one tile per block, dispatched by the hardware: this kernel re-balances around CUs held by a communication kernel by itself, so
     // the tiles_per_block launch option of the persistent kernels does not apply to it)
-    // (split types stay on the wave-specialised kernels: conv_gemm256_kernel's eight-phase loop has no third MFMA group)
-    if (allow_gemm256 && use_gemm256(a.M, a.Cd, 2, a.taps, a.mul, a.div_shift, a.klines)) {
+    // (split types, round 5: the same kernel with a third MFMA group per quadrant; the rule counts LOGICAL K: a split K-line holds 32 channels)
+    if (allow_gemm256 && use_gemm256(a.M, a.Cd, 2, a.taps, a.mul, a.div_shift, Tr::split ? a.klines / 2 : a.klines)) {
       IgemmArgs b = a;
       b.ntn = a.Cd / 256;
       b.ntm = (a.M + 255) / 256;
@@ -2884,6 +2904,7 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s, bool allow_gemm256 = true) {
         c.epi.mask_src = adv(a.epi.mask_src, a.epi.ldc_mask);
         c.epi.add1 = adv(a.epi.add1, a.epi.ldc_add1);
         c.epi.out = const_cast<void*>(adv(a.epi.out, a.epi.ldc_out));
+        c.epi.out_hi = const_cast<void*>(adv(a.epi.out_hi, a.epi.ldc_hi));  // (split types: the plain 16-bit copy of `out`'s hi halves has rows of its own)
         return dispatch_bn<Tr>(c, s, false);
       }
       return PS_OK;
@@ -3130,9 +3151,8 @@ extern "C" int ps_conv_variant(const ps_conv_geom* g, int32_t dgrad) {
   const long long ho = (g->h - 1) / g->stride + 1, wo = (g->w - 1) / g->stride + 1;
   const long long M = dgrad ? (long long)g->n * g->h * g->w : (long long)g->n * ho * wo;
   if (g_use_3stage + g_use_pp != 0) return PS_CONV_OTHER;
-  if (ps_planes(g->dtype) == 1 &&
-      use_gemm256(M, dgrad ? g->cin : g->cout, ps_esize(g->dtype), g->ksize * g->ksize, dgrad ? 1 : g->stride, dgrad && g->stride == 2 ? 1 : 0,
-                  (dgrad ? g->cout : g->cin) * ps_esize(g->dtype) / 128))
+  if (use_gemm256(M, dgrad ? g->cin : g->cout, ps_esize(g->dtype), g->ksize * g->ksize, dgrad ? 1 : g->stride, dgrad && g->stride == 2 ? 1 : 0,
+                  (dgrad ? g->cout : g->cin) * ps_esize(g->dtype) / 128))  // (split types: the rule counts logical K -- as the dispatcher)
     return PS_CONV_GEMM256;
   // both directions of a stride-1 3x3 layer gather on the input grid h x w
   const bool halo_ok = g->ksize == 3 && g->stride == 1 && halo_tile_width(g->w) != 0 && g->dilation <= 4;

@@ -95,6 +95,8 @@ class BucketedAllReduce:
         self.comm_stream = torch.cuda.Stream(device=flat.device) if flat.is_cuda else None
         self.shared_tiles_per_block = shared_tiles_per_block
         self.launch_opts = launch_opts
+        if launch_opts is not None and flat.is_cuda and hasattr(launch_opts, "stream_k"):
+            launch_opts.stream_k = False  # this reducer changes the model's launch options by bucket timing: see ops.LaunchOpts.stream_k
         self.payload = payload
         # bf16 wire format: one staging arena the size of the gradient arena (buckets are disjoint slices of it)
         self.stage = torch.empty(flat.numel(), device=flat.device, dtype=torch.bfloat16) if payload == "bf16" else None

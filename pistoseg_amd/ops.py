@@ -119,6 +119,10 @@ class LaunchOpts:
     # 1 = the persistent kernels draw every work item behind a block's first one from per-XCD ticket counters (ps_conv_geom.tile_queue): blocks
     # that start late or share their CU take fewer items; set by dist.BucketedAllReduce(share="queue"), or for good on a model whose GPU is shared
     tile_queue: Optional[int] = None
+    # stream-K finish of a launch's partial last round (ps_epilogue.sk_ws): None = the module default (on).  It re-associates the f32 sums at
+    # its split points and only runs on the static schedule, so a model whose OTHER launch options change from launch to launch by timing (the
+    # gradient reducer's tile_queue / cus_reserved while buckets are in flight) switches it off: results must not depend on when a bucket finished
+    stream_k: Optional[bool] = None
 
 
 TILES_PER_BLOCK = 0  # module defaults (see LaunchOpts): read when a launch is ENQUEUED
@@ -170,8 +174,8 @@ _SK_NEED: dict = {}
 STREAM_K = os.environ.get("PISTOSEG_STREAM_K", "1") != "0"  # module switch (tools' A/Bs, PISTOSEG_STREAM_K=0): False = never hand a workspace to the conv launches
 
 
-def _sk_workspace(g: ConvGeom, dgrad: bool, device):
-    if not STREAM_K:
+def _sk_workspace(g: ConvGeom, dgrad: bool, device, opts: Optional["LaunchOpts"] = None):
+    if not (STREAM_K if opts is None or opts.stream_k is None else opts.stream_k):
         return None
     key = (g.dtype, g.n, g.h, g.w, g.cin, g.cout, g.ksize, g.stride, g.dilation, g.tiles_per_block, g.gpu_shared, g.cus_reserved, g.tile_queue, dgrad)
     need = _SK_NEED.get(key)
@@ -217,7 +221,7 @@ def conv2d_fwd(spec: ConvSpec, x: Tensor, w_fwd: Tensor, *, add0=None, out_raw=N
     ref = out_act if out_act is not None else out_raw
     g = _geom(spec, _conv_dt(x, split), n, h, w, _ldc(x), _ldc(ref), opts)
     e = _epilogue(mode, add0=add0, out_raw=out_raw, scale=bn_scale, shift=bn_shift, drop=drop, out=out_act, out_hi=_hi_of(out_act) if split else None)
-    ws = _sk_workspace(g, False, x.device)
+    ws = _sk_workspace(g, False, x.device, opts)
     if ws is not None:
         e.sk_ws, e.sk_ws_bytes = ws.data_ptr(), ws.numel()
     lib = _lib.load()
@@ -238,7 +242,7 @@ def conv2d_dgrad(spec: ConvSpec, dy: Tensor, w_dgrad: Tensor, x_hw, *, add0=None
     ref = out if out is not None else out_raw
     g = _geom(spec, _conv_dt(dy, split), n, h, w, _ldc(ref), _ldc(dy), opts)
     e = _epilogue(mode, add0=add0, out_raw=out_raw, scale=bn_scale, drop=drop, mask_src=mask_src, add1=add1, out=out, out_hi=_hi_of(out) if split else None)
-    ws = _sk_workspace(g, True, dy.device)
+    ws = _sk_workspace(g, True, dy.device, opts)
     if ws is not None:
         e.sk_ws, e.sk_ws_bytes = ws.data_ptr(), ws.numel()
     lib = _lib.load()

@@ -155,6 +155,9 @@ class Net(nn.Module):
         #              accumulation, and for torch.autograd.grad).
         self.grad_sink = "arena"
         self.overlap_wgrad = True  # autograd path: weight gradients on a side stream (see backward_backbone), as the native trainers run them
+        # A trainer that runs its optimiser on a side stream (trainer.SegTrainer(defer_optimizer=True)) leaves here the event behind that launch: the
+        # forward waits for it in front of the first TRAINABLE unit -- conv1a and the frozen b2 units (models/resnet38d.py:191-205) run beside the update
+        self._weights_event = None
         self.train(True)  # apply the freezing rules from the start (the reference's scripts always call train())
 
     # ------------------------------------------------------------------ reference API
@@ -477,8 +480,11 @@ class Net(nn.Module):
         else:
             ops.conv1a_fwd(x, self.conv1a.weight.detach().contiguous(), sc0, sh0, a)
         xraw = None
+        first_trainable = self.first_trainable_unit() if self._weights_event is not None else -1
         for i, (name, kind, cin, cmid, cout, stride, fdil, dil, _p) in enumerate(self.units):
             unit = getattr(self, name)
+            if i == first_trainable:
+                self.wait_weights()  # (a deferred optimiser launch: everything up to here read frozen weights only)
             specs = self.unit_specs(name, kind, cin, cmid, cout, stride, fdil, dil)
             if i + 1 < len(self.units):
                 nxt_name, nxt = self.units[i + 1][0], getattr(self, self.units[i + 1][0])
@@ -545,6 +551,7 @@ class Net(nn.Module):
         if saved is not None:
             saved.conv6 = a
             saved.n = n
+        self.wait_weights()  # (a net whose only trainable weights are the heads behind the backbone)
         return feats, saved
 
     # ------------------------------------------------------------------ backward plan
@@ -683,6 +690,14 @@ class Net(nn.Module):
                 else:
                     with torch.cuda.stream(wgrad_stream):
                         after_unit(name)
+
+    def wait_weights(self) -> None:
+        """Make the current stream wait for a deferred optimiser launch (no-op otherwise): called by the forward plan in front of the first
+        trainable unit, by `state_dict()` (hook below) and by anything else that reads trainable weights outside the plans."""
+        ev = self._weights_event
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._weights_event = None
 
     def register_shadow(self, name: str, param: nn.Parameter, view: Tensor) -> None:
         """`view`: 16-bit [cout][kh][kw][cin] storage that a trainer keeps equal to `param` (cast by its fused optimiser)."""

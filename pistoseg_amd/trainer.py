@@ -113,6 +113,53 @@ class _ArenaMixin:
                 if self.clean_steps >= 200:
                     self.loss_scale, self.clean_steps = min(self.loss_scale * 2.0, 2.0 ** 24), 0
 
+    # -- optimiser on a side stream (defer_optimizer=True) ------------------------------------------------------------------------------------
+    # The update -- one HBM-bound launch over the arenas (3.1 GB at bs-independent 0.5 ms) plus the zero fill of the gradient arena -- depends on
+    # the whole backward, but nothing needs its result before the next step's first TRAINABLE layer: conv1a and the frozen b2 units
+    # (models/resnet38d.py:191-205; 1.7 ms of a bs = 64 forward) run beside it.  The launch goes to `opt_stream`; the model's forward waits for its
+    # event in front of unit b3 (`Net.wait_weights`), `state_dict()` and `load_state_dict()` wait too.  Code that reads parameters or arenas through
+    # torch right after `train_step` must call `wait_weights()` first -- which is why the trainers default to defer_optimizer=False.
+    def _init_deferred(self, defer: bool, dev) -> None:
+        self.defer_optimizer = bool(defer)
+        self.opt_stream = torch.cuda.Stream(device=dev) if defer else None
+        self._zeroed_by_optimizer = False
+        if defer:
+            model = self.model
+            model.register_state_dict_pre_hook(lambda m, prefix, keep_vars: m.wait_weights() if prefix == "" else None)
+
+    def _optimizer_scope(self):
+        """Context in which the optimiser launches of this step run: the side stream (behind everything the launch stream holds), or nothing."""
+        import contextlib
+
+        if self.opt_stream is None:
+            return contextlib.nullcontext()
+        self.opt_stream.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(self.opt_stream)
+
+    def _optimizer_done(self) -> None:
+        """Inside _optimizer_scope, behind the update: zero the gradient arena for the next step there too and leave the event for the forward."""
+        if self.opt_stream is None:
+            return
+        self.g_flat.zero_()
+        if self.f9_packed is not None:
+            self.f9_packed.zero_()
+        self._zeroed_by_optimizer = True
+        ev = torch.cuda.Event()
+        ev.record()
+        self.model._weights_event = ev
+
+    def _zero_grads(self) -> None:
+        """Start of a step: the gradient arena must be zero (the weight gradients accumulate)."""
+        if self._zeroed_by_optimizer:  # the deferred optimiser of the previous step did it, ordered in front of this step's weight gradients by the forward's wait
+            self._zeroed_by_optimizer = False
+            return
+        self.g_flat.zero_()
+        if self.f9_packed is not None:
+            self.f9_packed.zero_()
+
+    def wait_weights(self) -> None:
+        self.model.wait_weights()
+
     def sync_shadow(self) -> None:
         """Re-derive the whole 16-bit weight arena from the f32 master in one launch (after construction, or after the masters were
         written through torch: `load_state_dict` on resume).  Per-parameter staleness is also caught lazily by `Net.w_fwd`."""
@@ -121,6 +168,7 @@ class _ArenaMixin:
     def load_state_dict(self, state_dict, strict: bool = True):
         """Checkpoint resume through the trainer: the parameters live in the f32 arena (their `.data` are views of it), so the
         module's own load writes the masters in place; then the 16-bit shadows and every derived weight layout are refreshed."""
+        self.model.wait_weights()
         out = self.model.load_state_dict(state_dict, strict=strict)
         self.sync_shadow()
         return out
@@ -130,8 +178,9 @@ class SegTrainer(_ArenaMixin):
     def __init__(self, model: ResNet38dSeg, lr: float = 1e-3, weight_decay: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8,
                  ignore_index: Optional[int] = 3, process_group=None, bucket_mb: float = 48.0, track_iou: bool = True,
                  loss_scale: Optional[float] = None, overlap_wgrad: bool = True, deterministic: Optional[bool] = None, grad_payload: str = "fp32",
-                 share: str = "reserve+queue", reserved_cus: Optional[int] = None):
-        """grad_payload: what the N > 1 gradient exchange puts on the wire -- "fp32" (SUM all-reduce of the f32 arena slices) or "bf16" (each
+                 share: str = "reserve+queue", reserved_cus: Optional[int] = None, defer_optimizer: bool = False):
+        """defer_optimizer: the AdamW launch (and the next step's gradient zero fill) on a side stream, overlapped with the next forward's frozen
+        layers (see _ArenaMixin._init_deferred).  grad_payload: what the N > 1 gradient exchange puts on the wire -- "fp32" (SUM all-reduce of the f32 arena slices) or "bf16" (each
         bucket cast to bf16, all-reduced, widened back: half the xGMI bytes; see dist.BucketedAllReduce).  share / reserved_cus: how this model's
         conv launches make room for the collectives while buckets are in flight ("batch": tiles_per_block = 1; "reserve": cus_reserved; "queue": tile_queue;
         "reserve+queue", the default: both -- beside a kernel that holds 16 / 48 CUs a step costs + 9 % / + 25 % with it, + 14 % / + 29 % in batch mode, + 8 % /
@@ -155,6 +204,7 @@ class SegTrainer(_ArenaMixin):
         self.device = dev
         model.train()
         self._use_arena(model)
+        self._init_deferred(defer_optimizer, dev)
         self.m_flat = torch.zeros_like(self.p_flat)
         self.v_flat = torch.zeros_like(self.p_flat)
         # fp16 activations gradients underflow without a loss scale (a CE gradient is ~1/(N*H*W) = 3e-7 per pixel)
@@ -172,7 +222,7 @@ class SegTrainer(_ArenaMixin):
         """One optimisation step on a batch {'image': [N,3,H,W] f32, 'mask': [N,H,W] int64}; returns the loss (1-element device tensor)."""
         model = self.model
         n = image.shape[0]
-        self.g_flat.zero_()
+        self._zero_grads()
         drop = model.sample_dropout(n, image.device)
         feats, saved = model.run_backbone(image, save=True, drop=drop)
         logits, _ = model.head_forward(feats["conv6"], drop.get("dropout7"), image.shape[-2:])
@@ -190,16 +240,17 @@ class SegTrainer(_ArenaMixin):
                                 wgrad_stream=self.wgrad_stream)
         if self.reducer is not None:
             self.reducer.finish()
-        if self.dynamic_scale:
-            self._count_nonfinite()
-            ops.adamw_step_guarded(self.p_flat, self.g_flat, self.m_flat, self.v_flat, self.pb_flat, self.lr, self.betas, self.eps,
-                                   self.weight_decay, self.opt_state, grad_inv_scale=1.0 / self.loss_scale)
-            self._enqueue_flag()
-            model.invalidate_weight_cache()
-            return loss
-        self.step_count += 1
-        ops.adamw_step(self.p_flat, self.g_flat, self.m_flat, self.v_flat, self.pb_flat, self.lr, self.betas, self.eps,
-                       self.weight_decay, self.step_count, grad_inv_scale=1.0 / self.loss_scale)
+        with self._optimizer_scope():
+            if self.dynamic_scale:
+                self._count_nonfinite()
+                ops.adamw_step_guarded(self.p_flat, self.g_flat, self.m_flat, self.v_flat, self.pb_flat, self.lr, self.betas, self.eps,
+                                       self.weight_decay, self.opt_state, grad_inv_scale=1.0 / self.loss_scale)
+                self._enqueue_flag()
+            else:
+                self.step_count += 1
+                ops.adamw_step(self.p_flat, self.g_flat, self.m_flat, self.v_flat, self.pb_flat, self.lr, self.betas, self.eps,
+                               self.weight_decay, self.step_count, grad_inv_scale=1.0 / self.loss_scale)
+            self._optimizer_done()
         model.invalidate_weight_cache()
         return loss
 
@@ -220,7 +271,7 @@ class RFMTrainer(_ArenaMixin):
 
     def __init__(self, model, lr: float = 0.01, wt_dec: float = 5e-4, max_step: int = 1000, power: float = 0.9, process_group=None,
                  bucket_mb: float = 48.0, loss_scale: Optional[float] = None, overlap_wgrad: bool = True, deterministic: Optional[bool] = None,
-                 grad_payload: str = "fp32", share: str = "reserve+queue", reserved_cus: Optional[int] = None):
+                 grad_payload: str = "fp32", share: str = "reserve+queue", reserved_cus: Optional[int] = None, defer_optimizer: bool = False):
         from .revise_net import FCAT, Net
 
         assert isinstance(model, Net) and next(model.parameters()).is_cuda
@@ -235,6 +286,7 @@ class RFMTrainer(_ArenaMixin):
         dev = next(model.parameters()).device
         model.train()
         self._use_arena(model)  # heads (from_scratch_layers) first, then b7 ... b3
+        self._init_deferred(defer_optimizer, dev)
         self.buf_flat = torch.zeros_like(self.p_flat)
         self._init_dynamic_scale(dev, 1024.0, loss_scale)
         self.reducer: Optional[BucketedAllReduce] = None
@@ -249,8 +301,7 @@ class RFMTrainer(_ArenaMixin):
         from .rfm_loss import rfm_losses
 
         model = self.model
-        self.g_flat.zero_()
-        self.f9_packed.zero_()
+        self._zero_grads()
         drop = model.sample_dropout(x.shape[0], x.device)
         outs, ctx = model.rfm_forward(x, pmask, pcam, save=True, drop=drop)
         # (the loss block's top-k backward chooses among exact ties: deterministic mode takes them in index order)
@@ -274,24 +325,26 @@ class RFMTrainer(_ArenaMixin):
         ns, tot = self.n_scratch, self.p_flat.numel()
         shadow = lambda lo, hi: None if self.pb_flat is None else self.pb_flat[lo:hi]  # noqa: E731
         groups = [(lo, hi, lr) for lo, hi, lr in ((0, ns, 10 * self.lr0), (ns, tot, self.lr0)) if hi > lo]  # scratch heads at 10 x lr (revise_pseudo_labels.py:173-176)
-        if self.dynamic_scale:
-            # overflow check, `first step` and the poly schedule on the device (steps applied so far = opt_state[0]): no host read per step
-            self._count_nonfinite()
-            for k, (lo, hi, lr) in enumerate(groups):
-                ops.sgd_step_guarded(self.p_flat[lo:hi], self.g_flat[lo:hi], self.buf_flat[lo:hi], shadow(lo, hi), lr, self.wt_dec, self.wt_dec,
-                                     self.opt_state, advance=k == len(groups) - 1, poly_max_step=self.max_step, poly_power=self.power, grad_inv_scale=inv)
-            self._enqueue_flag()
-            model.invalidate_weight_cache()
-            return losses
-        # utils.PolyOptimizer.step
-        mult = (1 - self.global_step / self.max_step) ** self.power if self.global_step < self.max_step else None
-        if mult is not None:
-            self._lr_mult = mult
-        mult = getattr(self, "_lr_mult", 1.0)
-        first = self.global_step == 0
-        for lo, hi, lr in groups:
-            ops.sgd_step(self.p_flat[lo:hi], self.g_flat[lo:hi], self.buf_flat[lo:hi], shadow(lo, hi), lr * mult, self.wt_dec, self.wt_dec, first, grad_inv_scale=inv)
-        self.global_step += 1
+        with self._optimizer_scope():
+            if self.dynamic_scale:
+                # overflow check, `first step` and the poly schedule on the device (steps applied so far = opt_state[0]): no host read per step
+                self._count_nonfinite()
+                for k, (lo, hi, lr) in enumerate(groups):
+                    ops.sgd_step_guarded(self.p_flat[lo:hi], self.g_flat[lo:hi], self.buf_flat[lo:hi], shadow(lo, hi), lr, self.wt_dec, self.wt_dec,
+                                         self.opt_state, advance=k == len(groups) - 1, poly_max_step=self.max_step, poly_power=self.power, grad_inv_scale=inv)
+                self._enqueue_flag()
+            else:
+                # utils.PolyOptimizer.step
+                mult = (1 - self.global_step / self.max_step) ** self.power if self.global_step < self.max_step else None
+                if mult is not None:
+                    self._lr_mult = mult
+                mult = getattr(self, "_lr_mult", 1.0)
+                first = self.global_step == 0
+                for lo, hi, lr in groups:
+                    ops.sgd_step(self.p_flat[lo:hi], self.g_flat[lo:hi], self.buf_flat[lo:hi], shadow(lo, hi), lr * mult, self.wt_dec, self.wt_dec, first,
+                                 grad_inv_scale=inv)
+                self.global_step += 1
+            self._optimizer_done()
         model.invalidate_weight_cache()
         return losses
 

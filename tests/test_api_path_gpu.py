@@ -347,3 +347,55 @@ def test_side_stream_weight_gradients_in_split_precision_survive_a_slow_side_str
     assert set(a) == set(b) and len(a) == 36
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.selfcheck
+@pytest.mark.parametrize("kind", ["seg", "seg_fp16x3", "rfm"])
+def test_deferred_optimizer_is_the_same_step(kind):
+    """`defer_optimizer=True` (the update and the gradient zero fill on a side stream, overlapped with the next forward's frozen layers) runs the
+    same kernels on the same data: weights after 4 steps are bit-identical to the strict trainer's (deterministic weight gradients), `state_dict()`
+    waits for the pending update, and a slowed side stream changes nothing (the forward waits in front of the first trainable unit)."""
+    from pistoseg_amd.revise_net import Net
+    from pistoseg_amd.seg_model import ResNet38dSeg
+    from pistoseg_amd.trainer import RFMTrainer, SegTrainer
+
+    n, s, c = 2, 64, 4
+    rfm = kind == "rfm"
+    precision = "fp16x3" if kind == "seg_fp16x3" else "bf16"
+    sd = ref_cpu.make_state_dict(c if rfm else 3, rfm, seed=42)
+    x, pm_fg, pc_fg, lab = _rfm_inputs(n, c, s, 5)
+    target = torch.randint(0, 4, (n, s, s), generator=torch.Generator().manual_seed(6)).to(D)
+    pmask = torch.cat([torch.zeros(n, 1, 32, 32), pm_fg], 1).to(D)
+    pcam = torch.cat([torch.zeros(n, 1, 32, 32), pc_fg], 1).to(D)
+    label = torch.cat([torch.ones(n, 1), lab], 1).to(D)
+    xd = x.to(D)
+    drops, res = None, []
+    for defer in (False, True):
+        model = Net(c, precision=precision) if rfm else ResNet38dSeg(3, precision)
+        model.load_state_dict(sd)
+        model = model.to(D)
+        model.train()
+        if drops is None:
+            drops = [model.sample_dropout(n, D) for _ in range(4)]
+        it = iter(drops)
+        model.sample_dropout = lambda n_, dev_: next(it)
+        if rfm:
+            tr = RFMTrainer(model, lr=1e-3, wt_dec=5e-4, max_step=10, deterministic=True, defer_optimizer=defer)
+            step = lambda: tr.train_step(xd, pmask, pcam, label)[0]  # noqa: E731
+        else:
+            tr = SegTrainer(model, lr=2e-4, weight_decay=0.05, ignore_index=3, deterministic=True, defer_optimizer=defer)
+            step = lambda: tr.train_step(xd, target)  # noqa: E731
+        losses = []
+        for i in range(4):
+            losses.append(step())
+            if defer and i == 1:  # hold the side stream back: the next forward must still see the new weights
+                with torch.cuda.stream(tr.opt_stream):
+                    torch.cuda._sleep(50_000_000)
+        state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}  # (the pre-hook waits for the pending update)
+        assert model._weights_event is None
+        tr.settle()
+        res.append(([float(v) for v in losses], state, tr.skipped_steps))
+    (l1, s1, k1), (l2, s2, k2) = res
+    assert l1 == l2 and k1 == k2 == 0, (l1, l2, k1, k2)
+    for k in s1:
+        assert torch.equal(s1[k], s2[k]), k

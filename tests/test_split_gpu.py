@@ -78,7 +78,7 @@ def test_convert_rows_split_planes_and_casts(weights, dt):
         assert torch.equal(up.cpu(), low.cpu().float())
 
 
-# (n, h, w, cin, cout, k, stride, dilation), which kernel family the geometry selects for the FORWARD (split GEMMs stay on the wave-specialised kernel)
+# (n, h, w, cin, cout, k, stride, dilation), which kernel family the geometry selects for the FORWARD
 SPLIT_CASES = [
     ((2, 13, 10, 64, 128, 3, 2, 1), None),      # small / ragged: the 4-wave kernels
     ((2, 13, 10, 128, 128, 3, 1, 1), None),
@@ -89,7 +89,8 @@ SPLIT_CASES = [
     ((17, 32, 32, 64, 512, 3, 1, 4), "halo"),   # 256-pixel tiles (maps of 256 x 256 inputs)
     ((37, 28, 28, 256, 512, 1, 1, 1), "ws2"),
     ((42, 56, 56, 128, 256, 3, 2, 1), "ws2"),   # stride-2 3x3: the data gradient runs as four parity-class launches
-    ((17, 28, 28, 1024, 1024, 1, 1, 1), "ws2"),  # a GEMM the plain types send to conv_gemm256_kernel: split types keep the wave-specialised one
+    ((17, 28, 28, 1024, 1024, 1, 1, 1), "ws2"),  # a plain GEMM below conv_gemm256_kernel's range (K < 2048, 212 tiles)
+    ((32, 28, 28, 2048, 1024, 1, 1, 1), "gemm256"),  # round 5: the 256 x 256 tile GEMM kernel's split instantiation (third MFMA group per quadrant): 392 tiles, K = 2048
 ]
 
 
@@ -107,7 +108,7 @@ def test_split_conv_fwd_dgrad_wgrad_match_fp32_cpu(case, family, dt):
     spec = ops.ConvSpec(cin, cout, k, s_, d)
     if family is not None:
         g_ = ops._geom(spec, _lib.PS_BF16X3 if dt == BF else _lib.PS_F16X3, n, h, w, 2 * cin, 2 * cout)
-        want = {"halo": (7,), "ws2": (4, 5)}[family]
+        want = {"halo": (7,), "ws2": (4, 5), "gemm256": (8,)}[family]
         assert int(_lib.load().ps_conv_variant(C.byref(g_), 0)) in want
     SR = lambda t: split_repr(t, dt)
     PL = lambda t, weights=False: planes(t, weights, dt)
