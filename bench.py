@@ -201,7 +201,7 @@ def pmc_traffic(kernel_label):
 def power_leg(run_step, seconds=1.5):
     """Board power and shader clock while the SAME step keeps running, in an extra UNTIMED pass after the measurement (world 1 only): the MFMA
     peak the roofline divides by assumes the 2.4 GHz boost clock, which the 1400 W package cap does not sustain on dense 16-bit MFMA work
-    (DESIGN 7.28, profiles/r03_power_probe.txt) -- this records where the run sat.  `rocm-smi` runs as a child process from a sampler thread;
+    (NOTES 7.28, profiles/r03_power_probe.txt) -- this records where the run sat.  `rocm-smi` runs as a child process from a sampler thread;
     None when it is missing or its output does not parse."""
     import shutil
     import subprocess
@@ -951,6 +951,14 @@ def main():
         serial_step()  # keep ranks in lockstep through the instrumented step (it contains collectives)
     if rank == 0 and world == 1 and not args.no_power:
         out["power"] = power_leg(train_step)
+        # the clock the board HELD while the same step kept running (rocm-smi, extra untimed pass), next to the fraction: `peak` assumes the 2.4 GHz
+        # boost clock; `frac_at_held_clock` = achieved / (peak x held / 2400) says how much of the gap is the clock and how much the kernel's own idle
+        # matrix-pipe cycles (in-kernel s_memtime / s_memrealtime stamps of the dominant kernel: profiles/r05_halo_kstep_cycle_stamps.txt)
+        pw = out["power"]
+        if isinstance(pw, dict) and pw.get("sclk_mhz_mean") and out.get("roofline"):
+            held = float(pw["sclk_mhz_mean"])
+            out["roofline"]["sclk_mhz_during_step"] = held
+            out["roofline"]["frac_at_held_clock"] = round(out["roofline"]["achieved"] / (out["roofline"]["peak"] * held / 2400.0), 4)
 
     # ---- the same step through the reference's own API, beside the native trainer's (world 1: the default line)
     if not api_only and world == 1 and args.api_steps > 0:

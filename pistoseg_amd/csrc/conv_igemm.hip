@@ -1342,7 +1342,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_ws2_kernel(const IgemmArgs 
     [[maybe_unused]] bool l_done = false;  // Q: the last K-step of the block's last tile has been staged
     tile_setup(tile);
     // stages the next K-step of the flat sequence (exactly NLD loads per wave); the caller guarantees issued < total_steps (no end test and,
-    // in the product build, no selector test in the issue path: it is on the K-step's critical path)
+    // in the product build, no selector test in the issue path: it is on the K-step's critical path, NOTES 7.20)
     auto issue_next = [&]() {
       if (PS_ABLATE(a.ablate) == 1 && issued >= 3) { ++issued; return; }  // timing experiment: consumers run on stale LDS contents
       unsigned char* sa = smem + slot * STAGE;
@@ -1590,7 +1590,7 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restric
 // 256 x 256 tile kernel for the PLAIN GEMMs of the net: 1x1 stride-1 layers (forward and data gradient; the bottleneck units'
 // K-concatenated shortcut + last conv included), 16-bit operands.
 //   The ws2 kernel stages (256 + 128) x 128 B per K-step for 256 x 128 x 64 MACs and is bound by the L2 -> LDS fill rate (~65 GB/s per
-//   CU); a 256 x 256 tile stages 64 KiB for twice the MACs: 1.5x fewer staged bytes (and LDS-DMA pieces) per FLOP.  Its
+//   CU, NOTES 7.1); a 256 x 256 tile stages 64 KiB for twice the MACs: 1.5x fewer staged bytes (and LDS-DMA pieces) per FLOP.  Its
 //   64 K accumulators need all eight waves of the block as MFMA waves (128 accumulator registers each), so there are no loader waves:
 //   the block's two wave GROUPS (waves 0-3 and 4-7, one wave of each per SIMD) alternate roles, offset by one barrier -- while a
 //   group runs the 16 MFMAs of one output QUADRANT (64 pixels x 32 couts x one 64-deep K-tile), its SIMD partners issue their next
@@ -2153,7 +2153,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
     // STEADY STATE, three K-steps (one window) at a time while every issue below is known to succeed: the waits are then compile-time
     // literals -- queue behind the weights of step gs + 1: r = 0, 1: the younger weight steps and the whole next window; r = 2: the
     // window is older than them, only the weight steps issued after IT may stay in flight.  The loader waves' issue stream is part of
-    // the K-step's critical path: the general step below re-derives `allow` from four counters and reaches its
+    // the K-step's critical path (NOTES 7.19 / 7.20): the general step below re-derives `allow` from four counters and reaches its
     // `s_waitcnt` through a 5-level compare tree (a switch over 18 literals) -- ~40 scalar instructions and half a dozen branches more
     // per K-step than this form.
     constexpr int ALLOW01 = WPW * (NW - 2) + WJ, ALLOW2 = WPW * ((NW - 2) < 2 ? (NW - 2) : 2);

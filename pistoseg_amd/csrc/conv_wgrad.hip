@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //      56 x 56 maps, 16 / 64 for 32 x 32 / 64 x 64).  A host-built table holds, per (tap, K-step mod P, loader wave, DMA instruction), the
 //      64-bit mask of valid LANES; a K-step costs one 32-byte scalar load (issued in front of the dY pieces, which hide its latency) and ONE
 //      v_cndmask per X piece instead of 11 VALU instructions per row (4 instead of 44 per wave and K-step: the loaders' issue stream is
-//      part of the K-step's critical path)
+//      part of the K-step's critical path, NOTES 7.19-7.21)
 // Q: items behind the block's first one come from the launch's ticket queue (a.queue; ps_internal.h).  Consumer wave 0 draws item s + 1 when item
 // s starts -- right behind item s - 1's atomics in its memory queue -- and publishes it in front of the barrier of the item's K-step len - 6: the
 // loaders cross into item s + 1 when they stage item s's last K-step, two K-steps ahead of the consumers.  As late as that allows: collecting
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
   // range the order is [cig cin tiles][taps][cog cout tiles][other cin groups][other cout groups] (plan_wgrad_ws2): the ~32 consecutive
   // items that run together on one XCD then need few DISTINCT dY / X rows per K-step -- the taps of a (cin, cout) tile pair read the same dY
   // rows, and X rows that coincide up to a skew of a few K-steps (r03: L2-miss traffic of the 3x3 layers, profiles/r03_pmc_hbm_traffic.json).
-  // One branch-free formula for every layer (a run-time SWITCH between orders made hipcc triplicate the loaders' issue code: -12 %).
+  // One branch-free formula for every layer (a run-time SWITCH between orders made hipcc triplicate the loaders' issue code: -12 %, NOTES 7.19).
   auto decode = [&](int item, int& tci, int& tco, int& tap, int& ks0, int& ks1) {
     const int t_lo = item % a.cig; item /= a.cig;
     tap = item % a.taps; item /= a.taps;
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws2_kernel(const WgradArgs 
     [[maybe_unused]] bool l_done = false;  // Q: the last K-step of the block's last item has been staged
     // stages the next K-step of the flat sequence: exactly NLD loads per wave.  The caller guarantees issued < total_steps (the loaders'
     // issue stream is on the K-step's critical path, ~0.1 % of the kernel per scalar instruction: no per-step end test, no selector test in
-    // the product build)
+    // the product build, NOTES 7.20)
     auto issue_next = [&]() {
       unsigned char* sg = smem + slot * STAGE;
       unsigned char* sx = sg + G_BYTES;

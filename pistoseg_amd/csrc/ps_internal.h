@@ -33,14 +33,14 @@ static inline unsigned ps_persistent_grid(long long nitems, int nb, int tpb) {
 
 // The ablation selectors of the conv kernels (IgemmArgs::ablate / WgradArgs::ablate: timing experiments with WRONG results) exist in the
 // debug library only.  In the product build they are the constant 0: every per-K-step test of them in a loader's issue path -- which is
-// part of the K-step's critical path, ~0.1 % of the kernel per scalar instruction -- compiles away.
+// part of the K-step's critical path, ~0.1 % of the kernel per scalar instruction (NOTES 7.20) -- compiles away.
 #ifdef PS_DEBUG_HOOKS
 #define PS_ABLATE(x) (x)
 #else
 #define PS_ABLATE(x) 0
 #endif
 
-// Static wave priority of the LOADER waves of the wave-specialised kernels (A/B builds: -DPS_LOADER_PRIO=n).
+// Static wave priority of the LOADER waves of the wave-specialised kernels (A/B builds: -DPS_LOADER_PRIO=n; see NOTES 7).
 #ifndef PS_LOADER_PRIO
 #define PS_LOADER_PRIO 0
 #endif

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(const BgemmArgs a) {
 // The same GEMM, same tile, same order of the K sum (bit-identical results), for operands that can be staged in 4-element vectors
 // (one of (m, k) resp. (k, n) contiguous, extents / strides / pointers multiples of 4 elements; dtypes at compile time): 32-deep K steps,
 // the NEXT step's global vectors are in registers while this step's MFMAs run, two LDS buffers and one barrier per step.  The
-// element-wise version above stages through a generic accessor (a dtype switch per load: one load per basic block) with
+// element-wise version above stages through a generic accessor (a dtype switch per load: one load per basic block, NOTES 7.17) with
 // two barriers per 16 MFMAs: 213 us per launch of the affinity products at bs = 32, this one see profiles/.
 template <int DT>
 __device__ __forceinline__ float4 bg_load4(const unsigned char* p, long long i) {  // 4 consecutive elements from element index i
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void softmax_rows_reg_kernel(float* __restrict
 
 // Channel loops of the two affinity kernels: the maps' channel count cc = 3 x classes is a template argument for 9 / 12 / 15 (CT > 0: a
 // pixel's V row is loaded back to back), any other count up to RFM_MAXCC takes the predicated form (CT == 0: `if (c < cc)` puts every
-// load into its own basic block, where it is consumed before the next is issued -- one L1 latency per load).
+// load into its own basic block, where it is consumed before the next is issued -- one L1 latency per load, NOTES 7.17).
 constexpr int RFM_MAXCC = 24;
 template <int CT, class F>
 __device__ __forceinline__ void for_cc(int cc, F&& f) {

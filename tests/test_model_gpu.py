@@ -539,7 +539,7 @@ def test_seg_trainer_deterministic_steps_are_bit_identical_under_the_tile_queue(
 def test_every_forward_conv_launch_is_bit_identical_under_the_tile_queue(precision, monkeypatch):
     """Launch by launch: the backbone's forward at a batch where the persistent kernels draw (24 tiles of 224 x 224), every output tensor of every
     `ops.conv2d_fwd` call under `tile_queue = 1` against the static schedule -- the shapes no single-op test lists exhaustively (the 1x1 stride-2
-    shortcut convs' two-K-step tiles are where the ws2 queue's first version read its mailbox one barrier early)."""
+    shortcut convs' two-K-step tiles are where the ws2 queue's first version read its mailbox one barrier early, NOTES 7.39)."""
     from pistoseg_amd import ops
     from pistoseg_amd.seg_model import ResNet38dSeg
     from pistoseg_amd.trainer import init_weights_he

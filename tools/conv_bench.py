@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--halo-ring", type=int, default=3)
     ap.add_argument("--data", default="randn", choices=["randn", "relu", "zeros"],
                     help="operand values: dense random | max(randn, 0) activations | all zeros.  The big kernels sit at the 1400 W package cap on random data "
-                         "(DESIGN 7.28): a sustained loop then measures energy per FLOP; --data zeros (2.4 GHz, ~950 W) measures CYCLES per FLOP")
+                         "(NOTES 7.28): a sustained loop then measures energy per FLOP; --data zeros (2.4 GHz, ~950 W) measures CYCLES per FLOP")
     ap.add_argument("--epi", default="raw", help="raw: store only | full: fwd = +residual -> raw + BN/ReLU out, dgrad = ReLU mask + add1 -> out")
     args = ap.parse_args()
     lib = _lib.use_debug_library()  # the ps_debug_* switches live in libpistoseg_hip_debug.so only

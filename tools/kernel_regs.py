@@ -1,7 +1,7 @@
 """Register / spill / LDS table of the kernels in a built library (from the code object's metadata notes):
     python tools/kernel_regs.py [pistoseg_amd/libpistoseg_hip.so] [name-filter]
 Lists vgpr / agpr / sgpr counts, spilled registers, scratch bytes and static LDS per kernel -- the check that a new template instantiation
-of a conv kernel did not start spilling (a spill in a consumer wave is a VMEM load with a vmcnt wait: DESIGN 7.9)."""
+of a conv kernel did not start spilling (a spill in a consumer wave is a VMEM load with a vmcnt wait: NOTES 7.9)."""
 import re
 import subprocess
 import sys
