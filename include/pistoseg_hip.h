@@ -151,6 +151,12 @@ int64_t ps_conv_sk_workspace_bytes(const ps_conv_geom* g, int32_t dgrad);
  * (2: conv_wgrad256_kernel, an experiment that only the debug library can select). */
 int ps_conv_wgrad_variant(const ps_conv_geom* g);
 
+/* Ticket counters of the `tile_queue` launch option: a 288 KiB ring per (device of the stream, stream), allocated and zeroed at the first queue-mode
+ * launch of a stream (one hipMalloc: synchronises the device once, not allowed under stream capture) -- or ahead of time by ps_queue_prepare.
+ * ps_queue_release frees all rings (no queue-mode launch may be in flight): after destroying streams, or after an aborted launch. */
+int ps_queue_prepare(void* stream);
+int ps_queue_release(void);
+
 /* y = conv(x, W_fwd) with epilogue.  x: [n,h,w,cin]; produces [n,ho,wo,cout], ho = (h-1)/stride+1. */
 int ps_conv2d_fwd(const ps_conv_geom* g, const void* x, const void* w_fwd, const ps_epilogue* epi, void* stream);
 

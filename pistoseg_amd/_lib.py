@@ -84,6 +84,8 @@ PROTOTYPES = {
     "ps_conv_supported": (C.c_int, [C.POINTER(ConvGeom)]),
     "ps_conv_variant": (C.c_int, [C.POINTER(ConvGeom), _I]),
     "ps_conv_sk_workspace_bytes": (C.c_int64, [C.POINTER(ConvGeom), _I]),
+    "ps_queue_prepare": (C.c_int, [_P]),
+    "ps_queue_release": (C.c_int, []),
     "ps_conv_wgrad_variant": (C.c_int, [C.POINTER(ConvGeom)]),
     "ps_conv2d_fwd": (C.c_int, [C.POINTER(ConvGeom), _P, _P, C.POINTER(Epilogue), _P]),
     "ps_conv2d_dgrad": (C.c_int, [C.POINTER(ConvGeom), _P, _P, C.POINTER(Epilogue), _P]),

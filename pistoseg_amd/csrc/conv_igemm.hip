@@ -3089,27 +3089,50 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s, bool allow_gemm256 = true) {
 // Ticket counters of the queue-mode launches: per (device, stream) a ring of counter blocks (nine counters, one 128-byte line each), zeroed once (on that stream); every launch takes the next
 // block of its stream's ring.  A launch leaves its block zeroed (ps_q_block_done) and launches of one stream run in order, so a block is
 // never shared by two launches in flight.
+namespace {
+struct QueueRing { unsigned* base; unsigned next; };
+std::mutex g_ring_mu;
+std::map<std::pair<int, hipStream_t>, QueueRing> g_rings;
+}  // namespace
+
 unsigned* ps_queue_slot(hipStream_t stream) {
   constexpr int kSlots = 256, kDwords = PS_Q_SLOT_DWORDS;
-  struct Ring { unsigned* base; unsigned next; };
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, Ring> rings;
+  // keyed by the STREAM's device (not the calling thread's current one: a stream of device 1 used while device 0 is current keeps its own ring)
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  auto it = rings.find({dev, stream});
-  if (it == rings.end()) {
+  hipDevice_t sdev;
+  if (stream != nullptr && hipStreamGetDevice(stream, &sdev) == hipSuccess) dev = (int)sdev;
+  else if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(g_ring_mu);
+  auto it = g_rings.find({dev, stream});
+  if (it == g_rings.end()) {
+    // first queue-mode launch on this stream: one 288 KiB allocation (hipMalloc synchronises the device once, and fails under stream capture:
+    // call ps_queue_prepare(stream) beforehand where that matters)
     unsigned* d = nullptr;
     if (hipMalloc(&d, kSlots * kDwords * sizeof(unsigned)) != hipSuccess) return nullptr;
     // zeroed ON THE LAUNCH STREAM: a null-stream hipMemset is not ordered with kernels on a non-blocking stream (torch's side streams), and
     // recycled device memory is not zero -- the first launches of a new stream would draw from garbage counters
     if (hipMemsetAsync(d, 0, kSlots * kDwords * sizeof(unsigned), stream) != hipSuccess) { (void)hipFree(d); return nullptr; }
-    it = rings.emplace(std::make_pair(dev, stream), Ring{d, 0u}).first;
+    it = g_rings.emplace(std::make_pair(dev, stream), QueueRing{d, 0u}).first;
   }
-  Ring& r = it->second;
+  QueueRing& r = it->second;
   unsigned* p = r.base + (size_t)(r.next % kSlots) * kDwords;
   ++r.next;
   return p;
+}
+
+// Allocate (and zero) the ticket-counter ring of `stream` now, outside any launch path.
+extern "C" int ps_queue_prepare(void* stream) {
+  PS_REQUIRE(ps_queue_slot(static_cast<hipStream_t>(stream)) != nullptr, "queue_prepare: hipMalloc / hipMemsetAsync failed");
+  return PS_OK;
+}
+
+// Free every ticket-counter ring of this process (a destroyed stream's ring would otherwise be inherited by a new stream that re-uses its handle,
+// and a queue-mode kernel that was aborted leaves its counters non-zero): the caller guarantees that no queue-mode launch is in flight.
+extern "C" int ps_queue_release(void) {
+  std::lock_guard<std::mutex> lock(g_ring_mu);
+  for (auto& kv : g_rings) (void)hipFree(kv.second.base);
+  g_rings.clear();
+  return PS_OK;
 }
 
 

@@ -320,6 +320,9 @@ def release_workspaces() -> None:
     _fc8_ws.clear()
     _HEAD_WS.clear()
     _SK_WS.clear()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()  # (no queue-mode launch in flight)
+        _lib.check(_lib.load().ps_queue_release(), "ps_queue_release")
 
 
 def conv2d_wgrad(spec: ConvSpec, x: Tensor, dy: Tensor, dw: Tensor, deterministic: Optional[bool] = None, split: bool = False,
