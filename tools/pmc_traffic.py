@@ -34,7 +34,7 @@ for k in sorted(set(fe) | set(wr)):
         n = 0.0
         for name, v in d.items():
             # template arguments: halo <traits, tile width, ring depth, WI[, queue]>, ws2 <traits, pixel tile, SPLIT[, queue]>
-            if re.search(r"conv_igemm_halo_kernel<.*, \d+, \d+, 2(?:, (?:true|false))?>\(", name):
+            if re.search(r"conv_igemm_halo_kernel<.*, \d+, \d+, 2(?:, (?:true|false))*>\(", name):
                 continue                       # tail dispatch of a launch already counted through its main dispatch
             n += len(v) / 4.0 if re.search(r"conv_igemm_ws2_kernel<.*, \d+, true(?:, (?:true|false))?>\(", name) else len(v)
         return max(n, 1.0)

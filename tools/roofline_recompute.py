@@ -26,7 +26,7 @@ peak = {"bf16": 2500.0, "fp16": 2500.0, "bf16x3": 2500.0 / 3, "fp16x3": 2500.0 /
 tag = {"bf16": "TraitsBF16,", "fp16": "TraitsF16,", "bf16x3": "TraitsBF16X3,", "fp16x3": "TraitsF16X3,", "fp32": "TraitsF32,"}[dt]
 rows = [r for r in csv.DictReader(open(stats_csv)) if "conv_igemm_halo_kernel" in r["Name"] and tag in r["Name"]]
 # fourth template argument <traits, tile width, ring depth, WI[, queue]>: cout fragments per wave (4 = main dispatch, 2 = tail half tiles)
-wi = lambda r: re.search(r"conv_igemm_halo_kernel<[^,]+(?:::[^,]+)*, \d+, \d+, (\d)(?:, (?:true|false))?>\(", r["Name"]).group(1)
+wi = lambda r: re.search(r"conv_igemm_halo_kernel<[^,]+(?:::[^,]+)*, \d+, \d+, (\d)(?:, (?:true|false))*>\(", r["Name"]).group(1)
 main = [r for r in rows if wi(r) == "4"]
 tail = [r for r in rows if wi(r) == "2"]
 ns = lambda rs: sum(float(r["TotalDurationNs"]) for r in rs)
