@@ -30,7 +30,7 @@ __device__ __forceinline__ void mfma(f32x4& c, const u32x4& a, const u32x4& b) {
 }
 
 // ---------------- window variant ----------------
-template <int PIECES>  // LDS-DMA pieces per loader wave per stage (19 = d 2; 17 = d 1; 0 = consumers alone)
+template <int PIECES, bool STREAM = false>  // LDS-DMA pieces per loader wave per stage (19 = d 2; 17 = d 1; 0 = consumers alone)
 __global__ __launch_bounds__(512, 2) void probe_window(const unsigned char* __restrict__ src, unsigned src_bytes, float* __restrict__ out, int stages) {
   constexpr int DY_BYTES = 224 * 128, STAGE = DY_BYTES + 384 * 128;  // 28 + 48 KiB
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -38,12 +38,26 @@ __global__ __launch_bounds__(512, 2) void probe_window(const unsigned char* __re
   if (wave >= 4) {  // loader
     const int lw = wave - 4;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)src_bytes, 0x00020000);
-    const unsigned voff = (unsigned)(lane * 16 + lw * 4096 + (blockIdx.x & 63) * 16384);
+    unsigned voff = (unsigned)(lane * 16 + lw * 4096 + (blockIdx.x & 63) * 16384);
+    // STREAM: the layer's real traffic pattern -- tensors [50176 pixels][512 channels] bf16 (dY at 0, X behind it); block = (cout tile, cin tile, pixel range):
+    // a piece = 8 pixel rows x 128 B of this block's 64-channel column; blocks of one range share the rows (L2), ranges walk the pixels
+    const int tile = blockIdx.x & 63, range = blockIdx.x >> 6;
+    if constexpr (STREAM) voff = (unsigned)((lane >> 3) * 1024 + (lane & 7) * 16);
     int buf = 0;
     for (int s = 0; s < stages; ++s) {
       unsigned char* dst = smem + buf * STAGE;
+      const int pix0 = (range * stages + s) * 224;
 #pragma unroll
-      for (int j = 0; j < PIECES; ++j) BLDS16(rs, dst + ((j * 4 + lw) & 75) * 1024, voff, (j * 1024 + s * 64) & 0xffff);
+      for (int j = 0; j < PIECES; ++j) {
+        if constexpr (STREAM) {
+          const int piece = j * 4 + lw;  // 0..27: dY rows 8 piece.., 28..75: X window rows
+          const bool isx = piece >= 28;
+          const unsigned so = (unsigned)(((isx ? 50176 : 0) + pix0 + (isx ? piece - 28 : piece) * 8) * 1024 + (isx ? (tile & 7) : (tile >> 3)) * 128);
+          BLDS16(rs, dst + (piece & 75) * 1024, voff, so);
+        } else {
+          BLDS16(rs, dst + ((j * 4 + lw) & 75) * 1024, voff, (j * 1024 + s * 64) & 0xffff);
+        }
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       buf ^= 1;
@@ -119,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void probe_window(const unsigned char* __re
 }
 
 // ---------------- today's mix (conv_wgrad_ws2_kernel) ----------------
-template <int PIECES>  // 12, or 0 = consumers alone
+template <int PIECES, bool STREAM = false>  // 12, or 0 = consumers alone
 __global__ __launch_bounds__(512, 2) void probe_ws2(const unsigned char* __restrict__ src, unsigned src_bytes, float* __restrict__ out, int steps) {
   constexpr int RBG = 512, RBX = 256, G_BYTES = 64 * RBG, STAGE = G_BYTES + 64 * RBX;  // 32 + 16 KiB
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -128,11 +142,23 @@ __global__ __launch_bounds__(512, 2) void probe_ws2(const unsigned char* __restr
     const int lw = wave - 4;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)src_bytes, 0x00020000);
     const unsigned voff = (unsigned)(lane * 16 + lw * 4096 + (blockIdx.x & 63) * 16384);
+    // STREAM: block = (cout tile of 256 [2], cin tile of 128 [4], tap [8 of 9], pixel range [4]); dY piece = 2 pixel rows x 512 B, X piece = 4 rows x 256 B
+    const int tt = blockIdx.x & 63, range = blockIdx.x >> 6, tco = tt & 1, tci = (tt >> 1) & 3, tap = tt >> 3;
+    const unsigned vg = (unsigned)((lane >> 5) * 1024 + (lane & 31) * 16), vx = (unsigned)((lane >> 4) * 1024 + (lane & 15) * 16);
     int slot = 0;
     for (int s = 0; s < steps; ++s) {
       unsigned char* dst = smem + slot * STAGE;
+      const int pix0 = (range * steps + s) * 64;
 #pragma unroll
-      for (int j = 0; j < PIECES; ++j) BLDS16(rs, dst + (j * 4 + lw) * 1024, voff, (j * 1024 + s * 64) & 0xffff);
+      for (int j = 0; j < PIECES; ++j) {
+        if constexpr (STREAM) {
+          const int piece = j * 4 + lw;  // 0..31 dY (2 rows each), 32..47 X (4 rows each)
+          if (piece < 32) BLDS16(rs, dst + piece * 1024, vg, (unsigned)((pix0 + piece * 2) * 1024 + tco * 512));
+          else BLDS16(rs, dst + piece * 1024, vx, (unsigned)((50176 + pix0 + (piece - 32) * 4 + tap * 3) * 1024 + tci * 256));
+        } else {
+          BLDS16(rs, dst + (j * 4 + lw) * 1024, voff, (j * 1024 + s * 64) & 0xffff);
+        }
+      }
       asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       slot = slot == 2 ? 0 : slot + 1;
@@ -227,6 +253,13 @@ int main() {
   hipMemcpy(src, h.data(), src_bytes, hipMemcpyHostToDevice);
   const int grid = 256, reps = 6;
   const int stages = 600, steps = 2400;
+  // the streaming runs: dY and X of a 512 -> 512 3x3 layer at bs 64 ([50176][512] bf16 each, + slack for the window's halo rows), random contents
+  const unsigned big_bytes = 2u * 50176u * 1024u + (4u << 20);
+  unsigned char* big;
+  hipMalloc(&big, big_bytes);
+  for (unsigned off = 0; off < big_bytes; off += src_bytes) hipMemcpy(big + off, h.data(), (big_bytes - off < src_bytes ? big_bytes - off : src_bytes), hipMemcpyHostToDevice);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_window<19, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 76 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_ws2<12, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 48 * 1024);
   hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_window<19>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 76 * 1024);
   hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_window<17>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 76 * 1024);
   hipFuncSetAttribute(reinterpret_cast<const void*>(&probe_window<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 76 * 1024);
@@ -245,6 +278,12 @@ int main() {
     printf("ws2     256x128 one tap, 12 pieces/loader/step: %7.1f TFLOP/s\n", f2 / t / 1e12);
     t = time_it([&] { hipLaunchKernelGGL((probe_ws2<0>), dim3(grid), dim3(512), 3 * 48 * 1024, 0, src, src_bytes, out, steps); }, reps);
     printf("ws2     consumers alone                       : %7.1f TFLOP/s\n", f2 / t / 1e12);
+    // streaming: 64 tiles x 4 pixel ranges x 56 stages of 224 pixels (the whole layer) / 64 tile-taps x 4 ranges x 196 steps of 64 pixels (8 of its 9 taps)
+    const double fws = 2.0 * 64 * 64 * 9 * 224 * 56.0 * grid, f2s = 2.0 * 256 * 128 * 64 * 196.0 * grid;
+    t = time_it([&] { hipLaunchKernelGGL((probe_window<19, true>), dim3(grid), dim3(512), 2 * 76 * 1024, 0, big, big_bytes, out, 56); }, 20);
+    printf("window  STREAMING the layer's tensors, 56 stages: %7.1f us  %7.1f TFLOP/s\n", t * 1e6, fws / t / 1e12);
+    t = time_it([&] { hipLaunchKernelGGL((probe_ws2<12, true>), dim3(grid), dim3(512), 3 * 48 * 1024, 0, big, big_bytes, out, 196); }, 20);
+    printf("ws2     STREAMING the layer's tensors, 196 steps: %7.1f us  %7.1f TFLOP/s\n", t * 1e6, f2s / t / 1e12);
   }
   return 0;
 }
