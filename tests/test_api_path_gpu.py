@@ -399,3 +399,51 @@ def test_deferred_optimizer_is_the_same_step(kind):
     assert l1 == l2 and k1 == k2 == 0, (l1, l2, k1, k2)
     for k in s1:
         assert torch.equal(s1[k], s2[k]), k
+
+
+def test_arena_adamw_under_torch_grad_scaler():
+    """Lightning's `precision=16` plugin wraps the step in `torch.cuda.amp.GradScaler`: `scaler.scale(loss).backward(); scaler.step(opt); scaler.update()`.
+    The scaler unscales `p.grad` in place (= the gradient arena) and skips `opt.step()` on overflow; with the fp16 model and `ArenaAdamW` that gives
+    the native trainer's loss-scaled step (same scale, no overflow): weights after 2 steps equal `SegTrainer(loss_scale=...)`'s to f32 rounding of
+    the unscale (the trainer divides inside the AdamW kernel, the scaler in a foreach pass)."""
+    from pistoseg_amd.segmentation_module import SegmentationModule
+    from pistoseg_amd.trainer import SegTrainer
+
+    sd = ref_cpu.make_state_dict(3, False, seed=42)
+    x, *_ = make_inputs(2, 64, 4, 55)
+    target = torch.randint(0, 4, (2, 64, 64), generator=torch.Generator().manual_seed(8)).to(D)
+    xd = x.to(D)
+    scale = 1024.0
+    res, drops = [], None
+    for api in (True, False):
+        if api:
+            mod = SegmentationModule(make_args(precision="fp16", lr=2e-4)).to(D)
+            model = mod.model
+            model.load_state_dict(sd)
+        else:
+            model = _seg_model(sd, precision="fp16")
+        model.train()
+        model.launch.deterministic = True
+        if drops is None:
+            drops = [model.sample_dropout(2, D) for _ in range(2)]
+        it = iter(drops)
+        model.sample_dropout = lambda n_, dev_: next(it)
+        if api:
+            (opt,), _ = mod.configure_optimizers()
+            scaler = torch.cuda.amp.GradScaler(init_scale=scale, growth_interval=10 ** 6)
+            for i in range(2):
+                loss = mod.training_step({"image": xd, "mask": target, "label": None}, i)
+                opt.zero_grad()
+                scaler.scale(loss).backward()
+                scaler.step(opt)
+                scaler.update()
+            assert scaler.get_scale() == scale  # no overflow, no growth
+        else:
+            tr = SegTrainer(model, lr=2e-4, weight_decay=0.05, ignore_index=3, deterministic=True, loss_scale=scale)
+            for _ in range(2):
+                tr.train_step(xd, target)
+        res.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    for k in res[0]:
+        if res[0][k].is_floating_point():
+            d = (res[0][k] - res[1][k]).abs()
+            assert float(d.max()) <= 2 * 2 * 2e-4 * 1.1 and float(d.mean()) < 1e-6, (k, float(d.max()), float(d.mean()))

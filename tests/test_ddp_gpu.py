@@ -201,6 +201,41 @@ def _rccl_world1(port, out):
         # (a finished bucket may hand the CUs back before the next one is launched: only the first and the last transition are fixed)
         ok = ok and seen[0] == (True, 32, None, 1) and seen[-1] == (False, None, None, None) and opts.cus_reserved is None and opts.tile_queue is None
         ok = ok and bool(torch.equal(flat, vals.to(torch.bfloat16).float()))
+        # the reference-API path's own reducer (arena.ParamArena.attach_reducer) through the same RCCL communicator: stage 5 as Lightning drives it,
+        # gradients all-reduced in buckets behind the autograd node's reverse plan -- one rank, so the weights must equal a run without a reducer
+        import argparse
+
+        from oracle import ref_cpu
+        from oracle.make_golden import make_inputs
+        from pistoseg_amd.arena import ParamArena
+        from pistoseg_amd.segmentation_module import SegmentationModule
+
+        sd = ref_cpu.make_state_dict(3, False, seed=42)
+        x, *_ = make_inputs(2, 64, 4, 91)
+        target = torch.randint(0, 4, (2, 64, 64), generator=torch.Generator().manual_seed(4)).cuda()
+        states, drops = [], None
+        for with_reducer in (False, True):
+            args = argparse.Namespace(patch_size=64, num_classes=3, dataset="wsss4luad", model="ResNet38d", encoder="resnet38d", lr=1e-3, weight_decay=0.05,
+                                      tta=False, log_path="/tmp", precision="bf16")
+            mod = SegmentationModule(args).cuda()
+            mod.model.load_state_dict(sd)
+            mod.model.launch.deterministic = True
+            if drops is None:
+                drops = [mod.model.sample_dropout(2, torch.device("cuda", 0)) for _ in range(2)]
+            it = iter(drops)
+            mod.model.sample_dropout = lambda n_, dev_: next(it)
+            (opt,), _ = mod.configure_optimizers()
+            if with_reducer:
+                red_api = ParamArena.of(mod.model).attach_reducer(dist.group.WORLD, bucket_mb=16.0)
+                assert len(red_api.buckets) >= 3 and mod.model.launch.stream_k is False
+            for i in range(2):
+                loss = mod.training_step({"image": x.cuda(), "mask": target, "label": None}, i)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+            torch.cuda.synchronize()
+            states.append({k: v.detach().cpu().clone() for k, v in mod.model.state_dict().items()})
+        ok = ok and all(torch.equal(states[0][k], states[1][k]) for k in states[0])
         out.put(("ok" if ok else "values wrong (side stream ran ahead of the producer?)"))
         dist.destroy_process_group()
     except Exception as e:  # pragma: no cover
