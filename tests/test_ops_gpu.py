@@ -368,6 +368,16 @@ def test_confusion_matches_golden(golden_dir):
     ops.confusion_accum(pred, torch.from_numpy(g["gt"]).to(D), cm, 3)
     ops.confusion_accum(pred, torch.from_numpy(g["gt"]).to(D), cm, 3)
     assert np.array_equal(cm.cpu().numpy().reshape(3, 3), 2 * g["cm"].astype(np.int64))
+    # the IoU formulas on the device (ps_iou_from_confusion) against the values the REFERENCE's mIoUMask returned for this matrix (loss.py:28-53):
+    # bit for bit -- a matrix counted twice has the same ratios
+    vals = ops.iou_from_confusion(cm, 3).cpu().numpy()
+    assert vals[0] == float(g["miou"]) and vals[1] == float(g["fwiou"]) and np.array_equal(vals[2:], g["tissue_iou"])
+    # ... and through the mirror's forward: lazily fetched values, the reference's return contract (Mean_IoU, FW_IoU)
+    from pistoseg_amd.metrics import mIoUMask
+
+    meter = mIoUMask(num_classes=3)
+    miou, fwiou = meter(logits, torch.from_numpy(g["gt"]).to(D))
+    assert float(miou) == float(g["miou"]) and float(fwiou) == float(g["fwiou"]) and f"{miou:.6f}" == f"{float(g['miou']):.6f}"
 
 
 def test_optimizers_match_torch():
