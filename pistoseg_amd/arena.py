@@ -244,16 +244,6 @@ def model_of(params) -> Optional[object]:
     return None
 
 
-def _flatten_params(params):
-    out = []
-    for g in params:
-        if isinstance(g, dict):
-            out += list(g["params"])
-        else:
-            out.append(g)
-    return out
-
-
 class _ArenaOptMixin:
     """Shared plumbing, mixed into a torch optimiser class: finds the owning model's arena, maps param groups to arena ranges, keeps
     per-parameter state entries as views of flat state buffers (so `state_dict()` / `load_state_dict()` have torch's layout), zeroes
@@ -313,6 +303,12 @@ class _ArenaOptMixin:
 
     def _state_is_live(self) -> bool:
         return False
+
+    @staticmethod
+    def _has_grads(group) -> bool:
+        """torch's optimisers skip parameters whose `.grad` is None; the fused launch covers a group's whole arena range, so it runs when ANY of the
+        group's parameters holds a gradient (the autograd nodes bind all of them at once) and is skipped when none does (a `step()` before any backward)."""
+        return any(p.grad is not None for p in group["params"])
 
     def group_plan(self):
         """[(group, [(lo, hi)], [parameters outside the arena])] -- recomputed when the groups change."""
@@ -424,7 +420,7 @@ class ArenaAdamW(_ArenaOptMixin, torch.optim.AdamW):
         a = self.arena()
         for gi, (group, ranges, outside) in enumerate(self.group_plan()):
             lr, betas, eps, wd = float(group["lr"]), group["betas"], group["eps"], group["weight_decay"]
-            if ranges:
+            if ranges and self._has_grads(group):
                 t = self._steps_applied.get(gi, 0) + 1
                 self._steps_applied[gi] = t
                 m, v = self._flat_state["exp_avg"], self._flat_state["exp_avg_sq"]
@@ -482,7 +478,7 @@ class PolyOptimizer(_ArenaOptMixin, torch.optim.SGD):
         stepped = False
         for group, ranges, outside in self.group_plan():
             lr, mom, wd = float(group["lr"]), group["momentum"], group["weight_decay"]
-            if ranges:
+            if ranges and self._has_grads(group):
                 buf = self._flat_state["momentum_buffer"]
                 for lo, hi in ranges:
                     ops.sgd_step(a.p_flat[lo:hi], a.g_flat[lo:hi], buf[lo:hi] if mom != 0 else None, None if a.pb_flat is None else a.pb_flat[lo:hi],

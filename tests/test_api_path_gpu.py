@@ -92,14 +92,14 @@ def test_arena_adamw_is_torch_adamw_over_the_arena():
         assert set(sda["state"][i]) == {"step", "exp_avg", "exp_avg_sq"} and int(sda["state"][i]["step"]) == 3 == int(sdt["state"][i]["step"])
         for key in ("exp_avg", "exp_avg_sq"):
             a_, t_ = sda["state"][i][key].float().cpu(), sdt["state"][i][key].float().cpu()
-            assert a_.shape == t_.shape and float((a_ - t_).abs().max()) <= 1e-3 * float(t_.abs().max()) + 1e-12, (i, key)  # (the weights differ by rounding after step 1, so do the later gradients)
+            assert a_.shape == t_.shape and float((a_ - t_).abs().max()) <= 5e-3 * float(t_.abs().max()) + 1e-12, (i, key)  # (the weights differ by rounding after step 1, so do the later gradients)
     ot.load_state_dict(sda)  # arena state into the stock optimiser ...
     before = oa._flat_state["exp_avg"].clone()
     oa.load_state_dict(sdt)  # ... and torch's back into the arena optimiser: still views of the flat buffers
     st0 = oa.state[pa[0]]
     hit = oa.arena().owns(pa[0])
     assert st0["exp_avg"].data_ptr() == oa._flat_state["exp_avg"].data_ptr() + 4 * hit[0]
-    assert float((oa._flat_state["exp_avg"] - before).abs().max()) <= 1e-3 * float(before.abs().max())
+    assert float((oa._flat_state["exp_avg"] - before).abs().max()) <= 5e-3 * float(before.abs().max())
     oa.step()
     assert int(oa.state[pa[0]]["step"]) == 4
 
