@@ -1277,6 +1277,7 @@ def _halo_tail_body(lib, ops, library, run, y, res, act, gx_ref, dtype):
     (32, 28, 28, 128, 512, 1, 0, False),   # 448 tiles of 2 K-lines: shares of 1.5 lines -- not worth the exchange, the static schedule stays
     (32, 28, 28, 512, 512, 1, 32, False),  # 448 tiles beside a collective that holds 32 CUs (ps_conv_geom.cus_reserved): 2 x 224, whole rounds, nothing to cut
     (30, 28, 28, 512, 512, 2, 32, True),   # 420 = 224 + 196 on 224 CUs: shares of 7 lines
+    (45, 28, 28, 1024, 512, 4, 0, True),   # odd image count: 157.5 pixel tiles -> the RAGGED last tile lies in the stream-K region (632 = 2 x 256 + 120; shares of 7.5 lines)
 ])
 def test_conv_halo_stream_k(case, dtype):
     """Stream-K finish of the halo kernel's partial last round (ps_epilogue.sk_ws): forward with the full epilogue (residual, raw + BN/ReLU outputs)
