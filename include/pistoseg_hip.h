@@ -125,7 +125,9 @@ typedef struct ps_epilogue {
                                              * shares, one per CU; tiles that span CUs are added up through f32 slabs here, in a fixed order (bit-identical from
                                              * run to run, same MFMA chain per element up to the split points).  >= ps_conv_sk_workspace_bytes(g, dgrad)
                                              * bytes, 256-byte aligned, ZEROED ONCE by the caller when allocated (its first 4 KiB are arrival counters that
-                                             * every launch leaves zeroed) and used by ONE stream at a time.  NULL / too small: the launch keeps the static
+                                             * every launch leaves zeroed) and used by ONE stream at a time.  The split points depend on the CU count the launch is sized for, and
+                                             * the other schedules (tile_queue, tiles_per_block) do not split: results with sk_ws agree with theirs up to f32 re-association; WITHOUT it
+                                             * every launch option is bit-identical.  NULL / too small: the launch keeps the static
                                              * schedule (half-tile tail launch or an idle partial round). */
 } ps_epilogue;
 

@@ -2819,7 +2819,9 @@ static SkPlan halo_sk_plan(long long T, int nb, int klines, int slab_bytes_per_p
   p.lines = p.R * klines;
   // lines < 4 nb: a share of fewer than four K-lines (36 K-steps) does not pay for the slab exchange -- measured per layer, profiles/r05c_convbench_stream_k.txt:
   // shares of 2 lines lose 2-6 %, of 4-6 lines win 0-1.5 %, of 8-12 lines win 3-7 %.  (And every block must own at least one line: the part numbering.)
-  if (p.R == 0 || p.R * 100LL > nb * 92LL || p.R > 1000 || p.lines < 4LL * nb) return p;
+  // full == 0 (fewer tiles than CUs: the whole launch would be parts): measured to LOSE 6-15 % against one tile per CU on T of the CUs at T / nb >= 0.66
+  // (profiles/r05o_convbench_sk_small_batches.txt: every tile is cut, twice the slabs per CU) -- the static schedule stays
+  if (p.full == 0 || p.R == 0 || p.R * 100LL > nb * 92LL || p.R > 1000 || p.lines < 4LL * nb) return p;
   for (int t = 0; t < p.R; ++t) {  // (the kernel's own formula for the blocks a tile is spread over)
     const long long x0 = (long long)t * klines, x1 = x0 + klines - 1;
     const int parts = (int)(((x1 + 1) * nb - 1) / p.lines) - (int)(((x0 + 1) * nb - 1) / p.lines) + 1;
@@ -2838,7 +2840,9 @@ static int pick_ws_variant(long long M, int Cd, int esize, bool halo_ok) {
   if (g_use_glds != 2 || Cd % 128 != 0) return 0;
   const long long n128 = Cd / 128;
   // 3x3 stride-1 layers whose 224-pixel tiles are whole feature-map rows: window + halo staging (less LDS fill traffic)
-  if (halo_ok && g_use_halo && (g_use_halo == 2 || (g_use_ws2 == 1 && esize == 2 && ((M + 223) / 224) * n128 >= 256))) return PS_CONV_HALO;
+  // (from HALF a round of tiles on: one tile per CU on half the chip already beats the small-tile kernels' 0.22-0.24 of peak, and with the stream-K
+  // workspace every CU gets a share of the K-lines -- run.sh's own batch size is 16, i.e. 224 tiles on the 512-channel layers: round 5)
+  if (halo_ok && g_use_halo && (g_use_halo == 2 || (g_use_ws2 == 1 && esize == 2 && ((M + 223) / 224) * n128 >= ps_num_cus() / 2))) return PS_CONV_HALO;
   if (g_use_ws2 && (g_use_ws2 > 1 || (esize == 2 && n128 >= 2 && ((M + 255) / 256) * n128 >= 256))) {
     const long long t256 = (M + 255) / 256, t224 = (M + 223) / 224;
     const long long c256 = ((t256 * n128 + 255) / 256) * 256, c224 = ((t224 * n128 + 255) / 256) * 224;

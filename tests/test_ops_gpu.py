@@ -1277,6 +1277,8 @@ def _halo_tail_body(lib, ops, library, run, y, res, act, gx_ref, dtype):
     (32, 28, 28, 128, 512, 1, 0, False),   # 448 tiles of 2 K-lines: shares of 1.5 lines -- not worth the exchange, the static schedule stays
     (32, 28, 28, 512, 512, 1, 32, False),  # 448 tiles beside a collective that holds 32 CUs (ps_conv_geom.cus_reserved): 2 x 224, whole rounds, nothing to cut
     (30, 28, 28, 512, 512, 2, 32, True),   # 420 = 224 + 196 on 224 CUs: shares of 7 lines
+    (16, 28, 28, 512, 512, 1, 0, False),   # run.sh's own batch size: 224 tiles < 256 CUs -- the halo kernel, one tile per CU on 224 of them (cutting EVERY tile loses: measured)
+    (10, 28, 28, 512, 512, 2, 0, False),   # 140 tiles: the smallest launches the halo kernel serves (half a round)
     (45, 28, 28, 1024, 512, 4, 0, True),   # odd image count: 157.5 pixel tiles -> the RAGGED last tile lies in the stream-K region (632 = 2 x 256 + 120; shares of 7.5 lines)
 ])
 def test_conv_halo_stream_k(case, dtype):
@@ -1377,6 +1379,7 @@ def test_tile_queue_launch_option_is_exact(case, dtype, library):
         ops.conv2d_wgrad(spec, x, gy, dw, deterministic=det)
         return y, a, gx, dw
 
+    stream_k_before, ops.STREAM_K = ops.STREAM_K, False  # like for like: the queue hands out whole tiles; the static schedule's stream-K finish re-associates sums
     try:
         ops.TILE_QUEUE = 0
         ref, ref_det = run(False), run(True)
@@ -1406,6 +1409,7 @@ def test_tile_queue_launch_option_is_exact(case, dtype, library):
         assert all(torch.equal(o, ref[2]) for o in outs)
     finally:
         ops.TILE_QUEUE = 0
+        ops.STREAM_K = stream_k_before
 
 
 @debug_only

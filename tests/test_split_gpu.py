@@ -197,6 +197,7 @@ def test_split_convs_through_the_tile_queue_are_bit_identical(dt, GEOM):
         ops.conv2d_wgrad(spec, x, gy, dw, split=True)
         return y, gx, dw
 
+    stream_k_before, ops.STREAM_K = ops.STREAM_K, False  # like for like: the queue hands out whole tiles (stream-K re-associates the static schedule's sums)
     try:
         ops.TILE_QUEUE = 0
         ref = run()
@@ -204,6 +205,7 @@ def test_split_convs_through_the_tile_queue_are_bit_identical(dt, GEOM):
         got = run()
     finally:
         ops.TILE_QUEUE = 0
+        ops.STREAM_K = stream_k_before
     assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
     assert rel_err(got[2].cpu(), ref[2].cpu()) < 1e-5
 
