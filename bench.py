@@ -970,7 +970,7 @@ def main():
         api_value = args.batch * args.api_steps / dta
         out["api_path"] = {
             "train_tiles_s": round(api_value, 2), "ms_per_step": round(1e3 * dta / args.api_steps, 3), "steps": args.api_steps,
-            "ratio_to_native": round(api_value / value, 4), "final_loss": float(api_step()),
+            "ratio_to_native": round(api_value / value, 4), "final_loss": float(api_step().detach()),
             "what": "SegmentationModule(args); [opt], _ = configure_optimizers(); per step: loss = training_step(batch, i); opt.zero_grad(); "
                     "loss.backward(); opt.step() -- the calls pl.Trainer.fit makes (models/segmentation_module.py:86-111); opt = " + type(optimizer).__name__}
         del module, optimizer, api_step

@@ -170,6 +170,7 @@ DEBUG_PROTOTYPES = {
     "ps_debug_set_halo_ring": (None, [C.c_int]),
     "ps_debug_set_halo_tail": (None, [C.c_int]),
     "ps_debug_set_halo_sk": (None, [C.c_int]),
+    "ps_debug_set_halo_stagger": (None, [C.c_int]),
     "ps_debug_set_s2split": (None, [C.c_int]),
     "ps_debug_set_wgrad_ws": (None, [C.c_int]),
     "ps_debug_set_wgrad_ws2": (None, [C.c_int]),

@@ -69,6 +69,7 @@ struct IgemmArgs {
   float* sk_slabs;            // [tile - sk_tile0][part < sk_maxparts][consumer wave][MI * WI fragments][64 lanes] float4
   unsigned* sk_cnt;           // [tile - sk_tile0][consumer wave] arrival counters, zeroed by the host in front of the launch
   unsigned sk_slab_bytes;     // extent of sk_slabs (buffer descriptor)
+  int stagger, stagger_phases; // halo kernel: block b starts its first tile ((b / 8) % stagger_phases) * stagger * 2048 shader cycles late (0 = off), see g_halo_stagger
   ps_epilogue epi;
 };
 
@@ -1895,7 +1896,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(const IgemmArgs a)
 // behind the existing lgkmcnt(0) waits / the barrier, where the LDS queue is empty) and add them up per wave: [first half: reads +
 // MFMAs + wait], [second half], [barrier].  ps_debug_read_stamps copies the sums out.  (+ ~3 short SMEM round trips per K-step.)
 #ifdef PS_HALO_STAMPS
-__device__ unsigned long long g_halo_stamps[256 * 4 * 6];  // [block][consumer wave][seg0, seg1, seg2, steps, shader cycles, 100 MHz ticks]
+__device__ unsigned long long g_halo_stamps[256 * 4 * 8];  // [block][consumer wave][seg0, seg1, seg2, steps, shader cycles, 100 MHz ticks, tail MFMAs, epilogue]
 #define PS_STAMP(var)                                            \
   do {                                                           \
     var = __builtin_amdgcn_s_memtime();                          \
@@ -2232,11 +2233,22 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
       return;
     }
   }
+  // Staggered start (a.stagger): the blocks of a persistent launch run their tiles in lock step, so all CUs reach the epilogue within the
+  // same few microseconds and its loads / stores (172 KB per tile with a residual and two outputs) queue up at the memory fabric while every
+  // matrix pipe idles (profiles/r05t_halo_epilogue_stamps.txt).  Phase-shifting the blocks of each XCD spreads that burst over the tile period.
+  // (Measured, debug library only: no gain at 1-3 x 2048 cycles in 2 / 4 / 8 phases on any layer -- the epilogue's rate is the CU's own store
+  // path, not the fabric's: profiles/r05t_halo_stagger_ab.txt.)
+#ifdef PS_DEBUG_HOOKS
+  if (a.stagger > 0) {
+    const int ph = ((int)blockIdx.x >> 3) % a.stagger_phases;
+    for (int i = 0; i < ph * a.stagger; ++i) __builtin_amdgcn_s_sleep(32);  // 32 x 64 cycles
+  }
+#endif
   __builtin_amdgcn_s_barrier();  // window 0 / weights of step 0 visible
 
   int cur = 0, wbuf = 0;
 #ifdef PS_HALO_STAMPS
-  unsigned long long st_seg0 = 0, st_seg1 = 0, st_seg2 = 0, st_steps = 0, st_prev;
+  unsigned long long st_seg0 = 0, st_seg1 = 0, st_seg2 = 0, st_steps = 0, st_tail = 0, st_epi = 0, st_prev;
   PS_STAMP(st_prev);
   const unsigned long long st_c0 = st_prev, st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -2381,6 +2393,15 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int i = 0; i < WI; ++i) Tr::mma(wf1[i], Tr::split ? xf0[mi] : xf1[mi], acc[mi][i]);  // (split: the last step's x_hi . w_lo)
+#ifdef PS_HALO_STAMPS
+    {
+      asm volatile("s_nop 15\n s_nop 15" ::: "memory");  // (the MFMA queue drains before the stamp: the last results' 16 passes)
+      unsigned long long t_m;
+      PS_STAMP(t_m);
+      st_tail += t_m - st_prev;
+      st_prev = t_m;
+    }
+#endif
 #else
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -2469,9 +2490,18 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
         }
       }
     }
+    // (A row-wise version of this epilogue -- every tile-shaped operand transposed through 2 KiB of LDS scratch per wave so that each
+    // store / load instruction covers eight whole 128-byte rows, 3 x faster per CU in tools/epilogue_shape_probe.hip -- was built, bit-identical,
+    // and measured 25 % SLOWER in this kernel (consumer stamps: 6.1 k instead of 4.8 k cycles store-only, 17-18 k instead of 13-14 k with a
+    // residual and two outputs): tools/experiments/r05_halo_rows_epilogue.diff, profiles/r05u_halo_rows_epilogue_stamps.txt.)
     if (finish) conv_epilogue<typename Tr::epi, MI, WI, 1>(a, acc, rb * TR * W + (tm - rb * ncb) * TW + wm * (TW / 2), tn * BN + wn * WN, lane);
 #ifdef PS_HALO_STAMPS
-    PS_STAMP(st_prev);  // the epilogue is not part of segment 0 of the next tile's first step
+    {
+      unsigned long long t_e;
+      PS_STAMP(t_e);  // the epilogue is not part of segment 0 of the next tile's first step
+      st_epi += t_e - st_prev;
+      st_prev = t_e;
+    }
 #endif
     if constexpr (SK) {
       if (++sk_i < sk_nitems) sk_item(sk_i, tile, kl0, kl1);
@@ -2488,9 +2518,10 @@ __global__ __launch_bounds__(512, 2) void conv_igemm_halo_kernel(const IgemmArgs
   }
 #ifdef PS_HALO_STAMPS
   if (lane == 0 && blockIdx.x < 256) {
-    unsigned long long* o = g_halo_stamps + (blockIdx.x * 4 + wave) * 6;
+    unsigned long long* o = g_halo_stamps + (blockIdx.x * 4 + wave) * 8;
     o[0] = st_seg0; o[1] = st_seg1; o[2] = st_seg2; o[3] = st_steps;
     o[4] = __builtin_amdgcn_s_memtime() - st_c0; o[5] = __builtin_amdgcn_s_memrealtime() - st_r0;
+    o[6] = st_tail; o[7] = st_epi;
   }
 #endif
 }
@@ -2684,6 +2715,7 @@ PS_TUNABLE g_use_halo = 1;     // window + halo staging for 3x3 stride-1 layers 
 #define PS_HALO_SK 2  // (A/B builds: -DPS_HALO_SK=0|1)
 #endif
 PS_TUNABLE g_halo_sk = PS_HALO_SK;  // halo kernel: stream-K finish of a partial last round (needs ps_epilogue.sk_ws): 0 off, 1 on unless gpu_shared, 2 on
+PS_TUNABLE g_halo_stagger = 0, g_halo_stagger_phases = 4;  // halo kernel: staggered start of a launch's blocks (IgemmArgs::stagger), units of 2048 cycles
 PS_TUNABLE g_halo_tail = 1;   // halo kernel: a partial last round (<= half the CUs) as a second launch of 64-cout half tiles: 0 off, 1 on
 PS_TUNABLE g_halo_ring = 3;   // weight ring depth of the halo kernel (3 | 4 | 5 stages of 16 KiB; 256-pixel tiles: <= 4)
 PS_TUNABLE g_gemm256 = 1;      // 256 x 256 tile kernel for the plain GEMMs (1x1 stride-1, 16-bit): 0 off, 1 by shape, 2 whenever legal
@@ -2834,6 +2866,10 @@ static SkPlan halo_sk_plan(long long T, int nb, int klines, int slab_bytes_per_p
   return p;
 }
 
+// dynamic LDS of a halo launch: two windows + the weight ring + the ticket mailbox
+static constexpr unsigned halo_lds_bytes(int tw, int nw, int wi = 4) {
+  return 2u * (tw == 28 ? 9 : 10) * 4096u + (unsigned)nw * (wi == 4 ? 16384u : 8192u) + 16u;
+}
 static int halo_tile_width(int w) { return (w <= 0 || w > 256) ? 0 : (w % 28 == 0 ? 28 : (w % 32 == 0 ? 32 : 0)); }
 
 static int pick_ws_variant(long long M, int Cd, int esize, bool halo_ok) {
@@ -2957,6 +2993,8 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s, bool allow_gemm256 = true) {
       b.ntm = (a.M / a.Ws + 7) / 8 * (a.Ws / tw);  // blocks of 8 global rows x column blocks of tw
       b.nb = usable_cus(a.reserved);
       b.tpb = a.tpb;
+      b.stagger = g_halo_stagger;
+      b.stagger_phases = g_halo_stagger_phases > 0 ? g_halo_stagger_phases : 1;
       // The partial last round.  With T = ntm x ntn tiles on nb CUs, R = T mod nb <= nb / 2 tiles would keep R CUs busy for a whole round
       // (512-channel layers at bs=64: 896 tiles = 3.5 rounds).  Those R tiles -- whole pixel tiles, R % ntn == 0 -- go to a second launch
       // as 2 R half tiles of 64 couts (half the MFMAs, 8 instead of 16 KiB of weights per K-step: ~0.6 of a round on every CU).
@@ -2976,8 +3014,8 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s, bool allow_gemm256 = true) {
             b.sk_slabs = reinterpret_cast<float*>(static_cast<unsigned char*>(a.epi.sk_ws) + kSkCounterBytes);
             b.sk_slab_bytes = (unsigned)(p.ws_bytes - kSkCounterBytes);
             const dim3 sgrid((unsigned)b.nb);
-            if (tw == 28) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 3, 4, false, true>), sgrid, dim3(512), 2 * 9 * 4096 + 3 * 16384, s, b);
-            else hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32, 3, 4, false, true>), sgrid, dim3(512), 2 * 10 * 4096 + 3 * 16384, s, b);
+            if (tw == 28) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 3, 4, false, true>), sgrid, dim3(512), halo_lds_bytes(28, 3), s, b);
+            else hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32, 3, 4, false, true>), sgrid, dim3(512), halo_lds_bytes(32, 3), s, b);
             PS_CHECK_LAUNCH("conv_igemm_halo<stream-K>");
             return PS_OK;
           }
@@ -2995,8 +3033,8 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s, bool allow_gemm256 = true) {
           b.queue = ps_queue_slot(s);
           PS_REQUIRE(b.queue != nullptr, "conv: no ticket counters (hipMalloc failed)");
           const dim3 qgrid((unsigned)b.nb);
-          if (tw == 28) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 3, 4, true>), qgrid, dim3(512), 2 * 9 * 4096 + 3 * 16384 + 16, s, b);
-          else hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32, 3, 4, true>), qgrid, dim3(512), 2 * 10 * 4096 + 3 * 16384 + 16, s, b);
+          if (tw == 28) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 3, 4, true>), qgrid, dim3(512), halo_lds_bytes(28, 3), s, b);
+          else hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32, 3, 4, true>), qgrid, dim3(512), halo_lds_bytes(32, 3), s, b);
           PS_CHECK_LAUNCH("conv_igemm_halo<queue>");
           goto halo_tail;
         }
@@ -3005,17 +3043,17 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s, bool allow_gemm256 = true) {
       const dim3 hgrid(ps_persistent_grid((long long)b.ntm * b.ntn, b.nb, b.tpb));
       if (tw == 28) {
 #ifdef PS_DEBUG_HOOKS
-        if (g_halo_ring == 5) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 5>), hgrid, dim3(512), 2 * 9 * 4096 + 5 * 16384, s, b);
-        else if (g_halo_ring == 4) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 4>), hgrid, dim3(512), 2 * 9 * 4096 + 4 * 16384, s, b);
+        if (g_halo_ring == 5) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 5>), hgrid, dim3(512), halo_lds_bytes(28, 5), s, b);
+        else if (g_halo_ring == 4) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 4>), hgrid, dim3(512), halo_lds_bytes(28, 4), s, b);
         else
 #endif
-        hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 3>), hgrid, dim3(512), 2 * 9 * 4096 + 3 * 16384, s, b);
+        hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 3>), hgrid, dim3(512), halo_lds_bytes(28, 3), s, b);
       } else {
 #ifdef PS_DEBUG_HOOKS
-        if (g_halo_ring >= 4) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32, 4>), hgrid, dim3(512), 2 * 10 * 4096 + 4 * 16384, s, b);
+        if (g_halo_ring >= 4) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32, 4>), hgrid, dim3(512), halo_lds_bytes(32, 4), s, b);
         else
 #endif
-        hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32, 3>), hgrid, dim3(512), 2 * 10 * 4096 + 3 * 16384, s, b);
+        hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32, 3>), hgrid, dim3(512), halo_lds_bytes(32, 3), s, b);
       }
       PS_CHECK_LAUNCH("conv_igemm_halo");
       }
@@ -3027,8 +3065,8 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s, bool allow_gemm256 = true) {
           c.ntm = tail_ptiles;
           c.ntn = a.Cd / 64;
           const dim3 tgrid(ps_persistent_grid((long long)c.ntm * c.ntn, c.nb, 0));
-          if (tw == 28) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 3, 2>), tgrid, dim3(512), 2 * 9 * 4096 + 3 * 8192, s, c);
-          else hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32, 3, 2>), tgrid, dim3(512), 2 * 10 * 4096 + 3 * 8192, s, c);
+          if (tw == 28) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 3, 2>), tgrid, dim3(512), halo_lds_bytes(28, 3, 2), s, c);
+          else hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32, 3, 2>), tgrid, dim3(512), halo_lds_bytes(32, 3, 2), s, c);
           PS_CHECK_LAUNCH("conv_igemm_halo<tail>");
         }
       }
@@ -3155,17 +3193,18 @@ extern "C" void ps_debug_set_gemm256_tail(int v) { g_gemm256_tail = v; }
 extern "C" void ps_debug_set_gemm256_rule(int code) { g_gemm256_min_klines = code / 10000; g_gemm256_min_cd = code % 10000; }
 extern "C" void ps_debug_set_gemm256_min_tiles(int v) { g_gemm256_min_tiles = v; }
 #ifdef PS_HALO_STAMPS
-extern "C" int ps_debug_read_stamps(unsigned long long* host_out) {  // 256 x 4 x 4 values; synchronises the device
+extern "C" int ps_debug_read_stamps(unsigned long long* host_out) {  // 256 x 4 x 8 values; synchronises the device
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_halo_stamps), sizeof(g_halo_stamps)) == hipSuccess ? 0 : -2;
 }
 #endif
 extern "C" void ps_debug_set_halo_ring(int v) { g_halo_ring = v; }
 extern "C" void ps_debug_set_halo_tail(int v) { g_halo_tail = v; }
 extern "C" void ps_debug_set_halo_sk(int v) { g_halo_sk = v; }
+extern "C" void ps_debug_set_halo_stagger(int v) { g_halo_stagger = v & 0xff; g_halo_stagger_phases = (v >> 8) ? (v >> 8) : 4; }
 extern "C" void ps_debug_set_supertile(int v) { g_supertile = v; }
 // every tunable of this translation unit back to its default (one list, next to the definitions: the tools call ps_debug_reset())
 void ps_debug_reset_igemm(void) {
-  g_use_glds = 2; g_use_pp = 0; g_use_ws = 1; g_use_ws2 = 1; g_use_halo = 1; g_halo_sk = PS_HALO_SK; g_halo_tail = 1; g_halo_ring = 3; g_gemm256 = 1;
+  g_use_glds = 2; g_use_pp = 0; g_use_ws = 1; g_use_ws2 = 1; g_use_halo = 1; g_halo_sk = PS_HALO_SK; g_halo_stagger = 0; g_halo_stagger_phases = 4; g_halo_tail = 1; g_halo_ring = 3; g_gemm256 = 1;
   g_gemm256_min_klines = 32; g_gemm256_min_cd = 1024; g_gemm256_min_tiles = 0; g_gemm256_tail = 1; g_use_3stage = 0; g_ablate = 0;
   g_supertile = 4; g_force_bm = 0; g_force_bn = 0; g_s2split = 1;
 }

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--data", default="randn", choices=["randn", "relu", "zeros"],
                     help="operand values: dense random | max(randn, 0) activations | all zeros.  The big kernels sit at the 1400 W package cap on random data "
                          "(NOTES 7.28): a sustained loop then measures energy per FLOP; --data zeros (2.4 GHz, ~950 W) measures CYCLES per FLOP")
+    ap.add_argument("--tile", type=int, default=224, choices=[224, 256], help="input tile edge: the table's maps are for 224 (28 / 56 / 112 wide); 256 scales them to 32 / 64 / 128")
     ap.add_argument("--epi", default="raw", help="raw: store only | full: fwd = +residual -> raw + BN/ReLU out, dgrad = ReLU mask + add1 -> out")
     args = ap.parse_args()
     lib = _lib.use_debug_library()  # the ps_debug_* switches live in libpistoseg_hip_debug.so only
@@ -42,6 +43,7 @@ def main():
     sel = [int(i) for i in args.layers.split(",")] if args.layers else range(len(LAYERS))
     for li in sel:
         name, cin, cout, k, s, d, H, cnt = LAYERS[li]
+        H = H * args.tile // 224
         n = args.batch
         spec = ops.ConvSpec(cin, cout, k, s, d)
         ho, wo = spec.out_hw(H, H)
