@@ -147,7 +147,7 @@ enum {
 };
 int ps_conv_variant(const ps_conv_geom* g, int32_t dgrad);
 /* Bytes of ps_epilogue.sk_ws with which ps_conv2d_fwd (dgrad = 0) / ps_conv2d_dgrad (dgrad = 1) finishes this geometry's partial last round by
- * stream-K; 0 when the launch would not use it (no partial round, another kernel family, batch / queue launch options, ...). */
+ * stream-K; 0 when the launch would not use it (no partial round, another kernel family, feature maps that are not a multiple of 28 wide, batch / queue launch options, ...). */
 int64_t ps_conv_sk_workspace_bytes(const ps_conv_geom* g, int32_t dgrad);
 /* 1 if ps_conv2d_wgrad will launch conv_wgrad_ws2_kernel (256x128 tile, persistent, wave-specialised), 0 for conv_wgrad_kernel, -1 unsupported
  * (2: conv_wgrad256_kernel, an experiment that only the debug library can select). */

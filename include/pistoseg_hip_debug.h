@@ -52,7 +52,7 @@ void ps_debug_set_halo_ring(int v);
 /* Testing hook: halo kernel, partial last round as a second launch of 64-cout half tiles: 0 off, 1 (default) on. */
 void ps_debug_set_halo_tail(int v);
 void ps_debug_set_halo_stagger(int v); /* staggered start of the halo kernel's blocks: low byte = step in units of 2048 shader cycles (0 = off, default), bits 8.. = phases per XCD (0 -> 4) */
-void ps_debug_set_halo_sk(int v);   /* stream-K finish of the halo kernel's partial last round: 0 off, 1 on unless gpu_shared, 2 on (default) */
+void ps_debug_set_halo_sk(int v);   /* stream-K finish of the halo kernel's partial last round: 0 off, 1 on unless gpu_shared, 2 on (default) -- 224-pixel tiles only */
 void ps_debug_set_s2split(int v);  /* stride-2 3x3 data gradient as four parity-class launches: 0 off, 1 big 16-bit problems (default), 2 whenever legal */
 /* Testing hook: 1 (default) = 128x128 weight-gradient tiles use the wave-specialised variant, 0 = the 4-wave kernel. */
 void ps_debug_set_wgrad_ws(int v);

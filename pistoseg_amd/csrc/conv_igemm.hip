@@ -3002,8 +3002,10 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s, bool allow_gemm256 = true) {
       // split then COSTS 2 % of a training step (profiles/r03_tail_split_two_streams.txt).
       // Stream-K finish of the partial round (ps_epilogue.sk_ws given): one launch, every CU busy to the end.
       if constexpr (sizeof(typename Tr::elem) == 2) {
-        if (g_halo_sk && (g_halo_sk == 2 || !a.shared) && a.tpb == 0 && !a.use_queue && a.epi.sk_ws) {
-          const int slab = (tw == 28 ? 7 : 8) * 4 * 1024 * 4;  // MI x WI fragments x 1 KiB x 4 consumer waves
+        // (224-pixel tiles only: the 256-pixel instance -- 8 pixel fragments per wave, 128 accumulator registers -- did not fit its slab hand-off into 256
+        // registers (174 spilled) and measured -10 % on the 512-channel layers, +-2 % on the others: profiles/r05v_convbench_tw32_stream_k.txt)
+        if (g_halo_sk && tw == 28 && (g_halo_sk == 2 || !a.shared) && a.tpb == 0 && !a.use_queue && a.epi.sk_ws) {
+          const int slab = 7 * 4 * 1024 * 4;  // MI x WI fragments x 1 KiB x 4 consumer waves
           const SkPlan p = halo_sk_plan((long long)b.ntm * b.ntn, b.nb, a.klines, slab);
           if (p.on && a.epi.sk_ws_bytes >= p.ws_bytes && (reinterpret_cast<uintptr_t>(a.epi.sk_ws) & 255u) == 0) {
             b.sk_dp = p.full;
@@ -3014,8 +3016,7 @@ int dispatch_bn(const IgemmArgs& a, hipStream_t s, bool allow_gemm256 = true) {
             b.sk_slabs = reinterpret_cast<float*>(static_cast<unsigned char*>(a.epi.sk_ws) + kSkCounterBytes);
             b.sk_slab_bytes = (unsigned)(p.ws_bytes - kSkCounterBytes);
             const dim3 sgrid((unsigned)b.nb);
-            if (tw == 28) hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 3, 4, false, true>), sgrid, dim3(512), halo_lds_bytes(28, 3), s, b);
-            else hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 32, 3, 4, false, true>), sgrid, dim3(512), halo_lds_bytes(32, 3), s, b);
+            hipLaunchKernelGGL((conv_igemm_halo_kernel<Tr, 28, 3, 4, false, true>), sgrid, dim3(512), halo_lds_bytes(28, 3), s, b);
             PS_CHECK_LAUNCH("conv_igemm_halo<stream-K>");
             return PS_OK;
           }
@@ -3231,10 +3232,11 @@ extern "C" int64_t ps_conv_sk_workspace_bytes(const ps_conv_geom* g, int32_t dgr
   if (g_halo_sk != 2 && g->gpu_shared) return 0;
   if (ps_conv_variant(g, dgrad) != PS_CONV_HALO) return 0;
   const int tw = halo_tile_width(g->w);
+  if (tw != 28) return 0;  // (224-pixel tiles only: see the dispatcher)
   const long long M = (long long)g->n * g->h * g->w;  // stride 1: both directions produce on the input grid
   const long long ntm = (M / g->w + 7) / 8 * (g->w / tw), ntn = (dgrad ? g->cin : g->cout) / 128;
   const int klines = ps_planes(g->dtype) * (dgrad ? g->cout : g->cin) * 2 / 128;
-  const SkPlan p = halo_sk_plan(ntm * ntn, usable_cus(g->cus_reserved), klines, (tw == 28 ? 7 : 8) * 4 * 1024 * 4);
+  const SkPlan p = halo_sk_plan(ntm * ntn, usable_cus(g->cus_reserved), klines, 7 * 4 * 1024 * 4);
   return p.on ? p.ws_bytes : 0;
 }
 

@@ -1273,7 +1273,7 @@ def _halo_tail_body(lib, ops, library, run, y, res, act, gx_ref, dtype):
     # (shares of >= 4 K-lines only: the library's rule, measured in profiles/r05c_convbench_stream_k.txt)
     (32, 28, 28, 512, 512, 1, 0, True),    # BASELINE configs[3]'s per-GPU layer: 448 tiles = 1 round + 192; 8 K-lines -> shares of 6 lines, two parts per tile
     (24, 28, 28, 1024, 512, 2, 0, True),   # 336 = 256 + 80; 16 K-lines -> shares of 5 lines, tiles in 3-5 parts (the ordered re-sum path)
-    (20, 32, 32, 1024, 512, 4, 0, True),   # 256-pixel tiles: 320 = 256 + 64; shares of exactly 4 lines, 4 parts per tile
+    (20, 32, 32, 1024, 512, 4, 0, False),  # 256-pixel tiles: 320 = 256 + 64 -- the static schedule (+ its half-tile tail): the 256-pixel stream-K instance spills, measured slower
     (32, 28, 28, 128, 512, 1, 0, False),   # 448 tiles of 2 K-lines: shares of 1.5 lines -- not worth the exchange, the static schedule stays
     (32, 28, 28, 512, 512, 1, 32, False),  # 448 tiles beside a collective that holds 32 CUs (ps_conv_geom.cus_reserved): 2 x 224, whole rounds, nothing to cut
     (30, 28, 28, 512, 512, 2, 32, True),   # 420 = 224 + 196 on 224 CUs: shares of 7 lines
