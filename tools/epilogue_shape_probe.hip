@@ -14,7 +14,7 @@
 #include <vector>
 #include <algorithm>
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k(unsigned char* out, int ldc_bytes, int reps, int shape, int tiles_per_rep, unsigned long long* cyc, unsigned total_bytes, int loads) {
+__global__ __launch_bounds__(256) void k(unsigned char* out, int ldc_bytes, int reps, int shape, int tiles_per_rep, unsigned long long* cyc, unsigned total_bytes, int loads, int colmap) {
   __shared__ __attribute__((aligned(16))) unsigned char scratch[4][2][2048];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int frow = lane & 15, g = lane >> 4;
@@ -27,6 +27,33 @@ __global__ __launch_bounds__(256) void k(unsigned char* out, int ldc_bytes, int 
   for (int r = 0; r < reps; ++r) {
     const int tile = r * tiles_per_rep + blockIdx.x;
     const int base = (tile * 224 + (wave >> 1) * 112) * ldc_bytes + (wave & 1) * 128;
+    if (colmap) {
+      // the halo kernel's tile: 8 rows x 28 columns of a 28-wide map (row stride 28 * ldc), wave = 14 columns x 64 channels; fragment mi = columns 2 mi, 2 mi + 1
+      const int W = 28, cbase = (tile * 8 * W + (wave >> 1) * 14) * ldc_bytes + (wave & 1) * 128;
+      if (shape == 0) {
+#pragma unroll
+        for (int mi = 0; mi < 7; ++mi) {
+          const int p = cbase + ((frow & 7) * W + 2 * mi + (frow >> 3)) * ldc_bytes + 32 * g;
+          if (loads) { v[2 * mi] += __builtin_amdgcn_raw_buffer_load_b128(rs, p + (int)(total_bytes / 2), 0, 0); v[2 * mi + 1] += __builtin_amdgcn_raw_buffer_load_b128(rs, p + 16 + (int)(total_bytes / 2), 0, 0); }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 7; ++mi) {
+          const int p = cbase + ((frow & 7) * W + 2 * mi + (frow >> 3)) * ldc_bytes + 32 * g;
+          __builtin_amdgcn_raw_buffer_store_b128(v[2 * mi], rs, p, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(v[2 * mi + 1], rs, p + 16, 0, 0);
+        }
+      } else {
+        const int q = lane >> 3, c = lane & 7;
+#pragma unroll
+        for (int j = 0; j < 14; ++j)
+          if (loads) v[j] += __builtin_amdgcn_raw_buffer_load_b128(rs, cbase + (q * W + j) * ldc_bytes + 16 * c + (int)(total_bytes / 2), 0, 0);
+#pragma unroll
+        for (int j = 0; j < 14; ++j) __builtin_amdgcn_raw_buffer_store_b128(v[j], rs, cbase + (q * W + j) * ldc_bytes + 16 * c, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 14; ++i) v[i][0] += 1;
+      continue;
+    }
     if (loads) {  // the residual: 14 loads in front of the stores (shape 0 / 1: MFMA layout; 2 / 3: a pixel's 128 B per 8 lanes), consumed before the first store
       if (shape <= 1) {
 #pragma unroll
@@ -85,20 +112,21 @@ int main() {
   unsigned long long* c; hipMalloc(&c, 256 * 4 * 2 * 8);
   std::vector<unsigned long long> h(256 * 4 * 2);
   hipMemset(d, 1, bytes);
+  for (int colmap = 0; colmap < 2; ++colmap)
   for (int loads = 0; loads < 2; ++loads)
   for (int reps : {8, 1})  // 8: a sustained stream (the chip's write bandwidth binds at 256 blocks); 1: ONE tile per CU, the burst a round of tiles ends in
   for (int tiles : {256, 64, 16})  // fewer blocks = fewer CUs storing at once: the CU's own store path vs the chip's
-    for (int shape = 0; shape < 4; ++shape) {
+    for (int shape = 0; shape < (colmap ? 3 : 4); shape += (colmap ? 2 : 1)) {
       double best_issue = 1e30, best_done = 1e30;
       for (int it = 0; it < 5; ++it) {
-        hipLaunchKernelGGL(k, dim3(tiles), dim3(256), 0, 0, d, ldc_bytes, reps, shape, tiles, c, (unsigned)bytes, loads);
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(256), 0, 0, d, ldc_bytes, reps, shape, tiles, c, (unsigned)bytes, loads, colmap);
         hipMemcpy(h.data(), c, tiles * 4 * 2 * 8, hipMemcpyDeviceToHost);
         double si = 0, sd = 0;
         for (int i = 0; i < tiles * 4; ++i) si += h[2 * i], sd += h[2 * i + 1];
         best_issue = std::min(best_issue, si / (tiles * 4) / reps);
         best_done = std::min(best_done, sd / (tiles * 4) / reps);
       }
-      printf("%s reps %d blocks %3d shape %d: issue %.0f cycles per 14-KiB wave tile (%.0f per store instruction), to completion %.0f\n", loads ? "14 loads + 14 stores" : "14 stores", reps, tiles, shape, best_issue, best_issue / 14, best_done);
+      printf("%s%s reps %d blocks %3d shape %d: issue %.0f cycles per 14-KiB wave tile (%.0f per store instruction), to completion %.0f\n", colmap ? "[8 x 28 tile of a 28-wide map] " : "", loads ? "14 loads + 14 stores" : "14 stores", reps, tiles, shape, best_issue, best_issue / 14, best_done);
     }
   return 0;
 }
