@@ -562,6 +562,42 @@ def test_conv_halo_weight_ring_depths(case, ring):
     _halo_case(case, torch.bfloat16, ring)
 
 
+@debug_only
+def test_conv_halo_staggered_start_is_bit_identical():
+    """The diagnostic staggered start of the halo kernel's persistent blocks (ps_debug_set_halo_stagger: blocks of an XCD begin up to 3 x 2048 cycles apart,
+    NOTES R5.7) only delays blocks: same bytes out, forward with the full epilogue and data gradient."""
+    from pistoseg_amd import _lib, ops
+
+    lib = _lib.load()
+    n, h, w, cin, cout, d = 7, 28, 28, 192, 384, 2
+    g = torch.Generator().manual_seed(11)
+    D, dtype = dev(), torch.bfloat16
+    xd = torch.randn(n, h, w, cin, generator=g).to(D, dtype)
+    wf = (torch.randn(cout, 3, 3, cin, generator=g) * 0.03).to(D, dtype)
+    wd = (torch.randn(cin, 3, 3, cout, generator=g) * 0.03).to(D, dtype)
+    resd, gyd = torch.randn(n, h, w, cout, generator=g).to(D, dtype), torch.randn(n, h, w, cout, generator=g).to(D, dtype)
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).to(D), (torch.randn(cout, generator=g) * 0.1).to(D)
+    spec = ops.ConvSpec(cin, cout, 3, 1, d)
+
+    def run():
+        out_raw, out_act = torch.empty(n, h, w, cout, device=D, dtype=dtype), torch.empty(n, h, w, cout, device=D, dtype=dtype)
+        ops.conv2d_fwd(spec, xd, wf, add0=resd, out_raw=out_raw, bn_scale=scale, bn_shift=shift, out_act=out_act)
+        gx = torch.empty(n, h, w, cin, device=D, dtype=dtype)
+        ops.conv2d_dgrad(spec, gyd, wd, (h, w), out_raw=gx)
+        return out_raw, out_act, gx
+
+    try:
+        lib.ps_debug_set_halo(2)
+        plain = run()
+        lib.ps_debug_set_halo_stagger((4 << 8) | 3)  # 4 phases per XCD, 3 x 2048 cycles apart
+        late = run()
+    finally:
+        lib.ps_debug_set_halo_stagger(0)
+        lib.ps_debug_set_halo(1)
+    assert all(torch.isfinite(t.float()).all() for t in plain)
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(plain, late))
+
+
 def _halo_case(case, dtype, ring):
     """conv_igemm_halo_kernel (pixel window + halo staged once per tap row, K order (K-line, ty, tx)) forced on small problems:
     forward with the full epilogue and the data gradient against the CPU, plus agreement with the gathered-tile kernels."""
